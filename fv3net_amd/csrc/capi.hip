@@ -1,0 +1,106 @@
+// Library-level entry points of libfv3hip.so: error reporting, device selection, HIP-event timers.
+#include "common.h"
+
+namespace fv3hip {
+
+char *last_error_buffer()
+{
+    static thread_local char buf[512] = {0};
+    return buf;
+}
+
+int fail(int code, const char *fmt, ...)
+{
+    va_list ap;
+    va_start(ap, fmt);
+    vsnprintf(last_error_buffer(), 512, fmt, ap);
+    va_end(ap);
+    return code;
+}
+
+}  // namespace fv3hip
+
+using namespace fv3hip;
+
+extern "C" const char *fv3hip_last_error(void) { return last_error_buffer(); }
+
+extern "C" int fv3hip_abi_version(void) { return FV3HIP_ABI_VERSION; }
+
+extern "C" int fv3hip_init(int device)
+{
+    int n = 0;
+    FV3HIP_CHECK_HIP(hipGetDeviceCount(&n));
+    FV3HIP_REQUIRE(device >= 0 && device < n, "device %d out of range (%d visible)", device, n);
+    FV3HIP_CHECK_HIP(hipSetDevice(device));
+    hipDeviceProp_t prop;
+    FV3HIP_CHECK_HIP(hipGetDeviceProperties(&prop, device));
+    if (strncmp(prop.gcnArchName, "gfx950", 6) != 0)
+        return fail(FV3HIP_EUNSUPPORTED, "libfv3hip is built for gfx950 (MI355X) only; device %d is %s",
+                    device, prop.gcnArchName);
+    return FV3HIP_OK;
+}
+
+extern "C" int fv3hip_device_info(fv3hip_device_info_t *out)
+{
+    FV3HIP_REQUIRE(out, "null pointer");
+    int dev = 0;
+    FV3HIP_CHECK_HIP(hipGetDevice(&dev));
+    hipDeviceProp_t prop;
+    FV3HIP_CHECK_HIP(hipGetDeviceProperties(&prop, dev));
+    memset(out, 0, sizeof(*out));
+    strncpy(out->name, prop.name, sizeof(out->name) - 1);
+    strncpy(out->arch, prop.gcnArchName, sizeof(out->arch) - 1);
+    out->compute_units = prop.multiProcessorCount;
+    out->wavefront_size = prop.warpSize;
+    out->lds_bytes_per_cu = (int)prop.maxSharedMemoryPerMultiProcessor;
+    out->clock_mhz = prop.clockRate / 1000;
+    out->hbm_bytes = prop.totalGlobalMem;
+    return FV3HIP_OK;
+}
+
+struct fv3hip_timer {
+    hipEvent_t start, stop;
+};
+
+extern "C" int fv3hip_timer_create(fv3hip_timer_t *out)
+{
+    FV3HIP_REQUIRE(out, "null pointer");
+    fv3hip_timer *t = new fv3hip_timer();
+    if (hipEventCreate(&t->start) != hipSuccess || hipEventCreate(&t->stop) != hipSuccess) {
+        delete t;
+        return fail(FV3HIP_EHIP, "hipEventCreate failed");
+    }
+    *out = t;
+    return FV3HIP_OK;
+}
+
+extern "C" int fv3hip_timer_start(fv3hip_timer_t t, void *stream)
+{
+    FV3HIP_REQUIRE(t, "null timer");
+    FV3HIP_CHECK_HIP(hipEventRecord(t->start, as_stream(stream)));
+    return FV3HIP_OK;
+}
+
+extern "C" int fv3hip_timer_stop(fv3hip_timer_t t, void *stream)
+{
+    FV3HIP_REQUIRE(t, "null timer");
+    FV3HIP_CHECK_HIP(hipEventRecord(t->stop, as_stream(stream)));
+    return FV3HIP_OK;
+}
+
+extern "C" int fv3hip_timer_elapsed_ms(fv3hip_timer_t t, float *ms)
+{
+    FV3HIP_REQUIRE(t && ms, "null pointer");
+    FV3HIP_CHECK_HIP(hipEventSynchronize(t->stop));
+    FV3HIP_CHECK_HIP(hipEventElapsedTime(ms, t->start, t->stop));
+    return FV3HIP_OK;
+}
+
+extern "C" int fv3hip_timer_destroy(fv3hip_timer_t t)
+{
+    if (!t) return FV3HIP_OK;
+    hipEventDestroy(t->start);
+    hipEventDestroy(t->stop);
+    delete t;
+    return FV3HIP_OK;
+}

@@ -1,0 +1,525 @@
+// Horizontal block coarse-graining kernels for gfx950 (MI355X).
+//
+// Reference behaviour restated (paths relative to the reference checkout):
+//   external/vcm/vcm/cubedsphere/coarsen.py:183-218  weighted_block_average
+//   external/vcm/vcm/cubedsphere/coarsen.py:221-273  edge_weighted_block_average
+//   external/vcm/vcm/cubedsphere/coarsen.py:795-840  block_coarsen (sum/min/max/mean)
+//   external/vcm/vcm/cubedsphere/coarsen.py:557-588, 750-786  block_median, _block_mode
+//   external/vcm/vcm/cubedsphere/coarsen.py:869-938  block_upsample(_like)
+//
+// All of these are HBM-bound: the fast path streams each fine-grid row with one 16-byte load
+// per lane (a wave covers 1 KiB of a row), keeps the 2-D weights of its f x f blocks in
+// registers while it walks the vertical levels that share them, and finishes a block with a
+// couple of cross-lane adds.  There is no data reuse to stage through LDS.
+#include "common.h"
+
+namespace fv3hip {
+namespace {
+
+template <typename T>
+__device__ __forceinline__ bool is_nan(T x)
+{
+    return x != x;
+}
+
+// N elements of T as one register tuple; 16-byte ones become global_load_dwordx4.
+template <typename T, int N>
+struct VecOf {
+    typedef T type __attribute__((ext_vector_type(N)));
+};
+template <typename T, int N>
+using Vec = typename VecOf<T, N>::type;
+
+template <typename A, typename B>
+struct Promote {
+    using type = float;
+};
+template <>
+struct Promote<double, double> {
+    using type = double;
+};
+template <>
+struct Promote<double, float> {
+    using type = double;
+};
+template <>
+struct Promote<float, double> {
+    using type = double;
+};
+
+// ---------------------------------------------------------------------------------------
+// Generic windowed weighted mean: one thread per output element, any window / stride.
+// Used for edge-weighted averages and for shapes the fast path does not cover.
+// ---------------------------------------------------------------------------------------
+template <typename To, typename Tw>
+__global__ void wavg_generic_kernel(const To *__restrict__ obj, const Tw *__restrict__ w,
+                                    typename Promote<To, Tw>::type *__restrict__ out,
+                                    int64_t n_outer, int ny, int nx, int64_t w_repeat, int by,
+                                    int bx, int sy, int sx, int nyo, int nxo)
+{
+    using P = typename Promote<To, Tw>::type;
+    const int64_t total = n_outer * nyo * nxo;
+    for (int64_t idx = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; idx < total;
+         idx += (int64_t)gridDim.x * blockDim.x) {
+        const int X = (int)(idx % nxo);
+        const int64_t t = idx / nxo;
+        const int Y = (int)(t % nyo);
+        const int64_t o = t / nyo;
+        const int64_t sp = (int64_t)Y * sy * nx + (int64_t)X * sx;
+        const To *po = obj + o * ny * (int64_t)nx + sp;
+        const Tw *pw = w + (o / w_repeat) * ny * (int64_t)nx + sp;
+        // the denominator is the block sum of the weights alone, accumulated in the weights' own
+        // dtype as `weights.coarsen(...).sum()` does (coarsen.py:212), then promoted
+        P num = 0;
+        Tw den = 0;
+        for (int dy = 0; dy < by; ++dy) {
+            for (int dx = 0; dx < bx; ++dx) {
+                const Tw w0 = pw[(int64_t)dy * nx + dx];
+                const P p = (P)po[(int64_t)dy * nx + dx] * (P)w0;
+                if (!is_nan(p)) num += p;
+                if (!is_nan(w0)) den += w0;
+            }
+        }
+        out[idx] = num / (P)den;
+    }
+}
+
+// ---------------------------------------------------------------------------------------
+// Fast path: full F x F blocks, rows read with 16-byte loads.
+//   VEC  = elements of the promoted type in 16 bytes (4 for f32, 2 for f64)
+//   LPB  = lanes that share one block row  (F / VEC, when F >= VEC)
+//   BPL  = blocks held by one lane         (VEC / F, when F <  VEC)
+// Thread s of a spatial slab handles vector column xv = s % (nx/VEC) of block row
+// Y = s / (nx/VEC); gridDim.y walks (weight slice, z-chunk) pairs.
+// ---------------------------------------------------------------------------------------
+template <typename To, typename Tw, int F>
+__global__ __launch_bounds__(256) void wavg_block_kernel(
+    const To *__restrict__ obj, const Tw *__restrict__ w,
+    typename Promote<To, Tw>::type *__restrict__ out, int64_t n_outer, int ny, int nx,
+    int64_t w_repeat, int zsplit, int64_t n_gy)
+{
+    using P = typename Promote<To, Tw>::type;
+    constexpr int VEC = 16 / sizeof(P);
+    constexpr int LPB = (F >= VEC) ? F / VEC : 1;
+    constexpr int BPL = (F >= VEC) ? 1 : VEC / F;
+    constexpr int EPB = VEC / BPL;  // elements of one lane's vector that fall in one block
+    constexpr bool kCacheW = (F * VEC <= 64);
+
+    const int XV = nx / VEC;
+    const int nyo = ny / F, nxo = nx / F;
+    const int64_t S = (int64_t)nyo * XV;
+    const int64_t s = blockIdx.x * (int64_t)blockDim.x + threadIdx.x;
+    const bool active = s < S;
+    const int Y = active ? (int)(s / XV) : 0;
+    const int xv = active ? (int)(s % XV) : 0;
+    const int64_t sp = (int64_t)Y * F * nx + (int64_t)xv * VEC;  // offset inside one slice
+    const int64_t slice = (int64_t)ny * nx;
+    const int64_t zper = (w_repeat + zsplit - 1) / zsplit;
+
+    for (int64_t gy = blockIdx.y; gy < n_gy; gy += gridDim.y) {
+        const int64_t g = gy / zsplit;
+        const int part = (int)(gy % zsplit);
+        const int64_t o_begin = g * w_repeat + part * zper;
+        int64_t o_end = o_begin + zper;
+        if (o_end > (g + 1) * w_repeat) o_end = (g + 1) * w_repeat;
+        if (o_end > n_outer) o_end = n_outer;
+
+        const Tw *pw = w + g * slice + sp;
+        P wreg[kCacheW ? F : 1][VEC];
+        Tw den[BPL];  // accumulated in the weights' dtype, like weights.coarsen(...).sum()
+#pragma unroll
+        for (int b = 0; b < BPL; ++b) den[b] = 0;
+#pragma unroll
+        for (int dy = 0; dy < F; ++dy) {
+            Vec<Tw, VEC> wv;
+            if (active) {
+                wv = *reinterpret_cast<const Vec<Tw, VEC> *>(pw + (int64_t)dy * nx);
+            } else {
+#pragma unroll
+                for (int e = 0; e < VEC; ++e) wv[e] = 0;
+            }
+#pragma unroll
+            for (int e = 0; e < VEC; ++e) {
+                const Tw w0 = wv[e];
+                if (kCacheW) wreg[kCacheW ? dy : 0][e] = (P)w0;
+                den[e / EPB] += is_nan(w0) ? (Tw)0 : w0;
+            }
+        }
+#pragma unroll
+        for (int m = 1; m < LPB; m <<= 1) den[0] += __shfl_xor(den[0], m);
+
+        for (int64_t o = o_begin; o < o_end; ++o) {
+            const To *po = obj + o * slice + sp;
+            Vec<To, VEC> ov[F];
+#pragma unroll
+            for (int dy = 0; dy < F; ++dy) {
+                if (active) {
+                    ov[dy] = __builtin_nontemporal_load(
+                        reinterpret_cast<const Vec<To, VEC> *>(po + (int64_t)dy * nx));
+                } else {
+#pragma unroll
+                    for (int e = 0; e < VEC; ++e) ov[dy][e] = 0;
+                }
+            }
+            P num[BPL];
+#pragma unroll
+            for (int b = 0; b < BPL; ++b) num[b] = 0;
+#pragma unroll
+            for (int dy = 0; dy < F; ++dy) {
+                Vec<Tw, VEC> wv;
+                if (!kCacheW) {
+                    if (active) {
+                        wv = *reinterpret_cast<const Vec<Tw, VEC> *>(pw + (int64_t)dy * nx);
+                    } else {
+#pragma unroll
+                        for (int e = 0; e < VEC; ++e) wv[e] = 0;
+                    }
+                }
+#pragma unroll
+                for (int e = 0; e < VEC; ++e) {
+                    const P ww = kCacheW ? wreg[kCacheW ? dy : 0][e] : (P)wv[e];
+                    const P p = (P)ov[dy][e] * ww;
+                    num[e / EPB] += is_nan(p) ? (P)0 : p;
+                }
+            }
+#pragma unroll
+            for (int m = 1; m < LPB; m <<= 1) num[0] += __shfl_xor(num[0], m);
+            if (active && (xv % LPB) == 0) {
+                P *dst = out + (o * nyo + Y) * (int64_t)nxo + (int64_t)(xv / LPB) * BPL;
+                if (BPL == 1) {
+                    dst[0] = num[0] / (P)den[0];
+                } else {
+                    Vec<P, BPL> r;
+#pragma unroll
+                    for (int b = 0; b < BPL; ++b) r[b] = num[b] / (P)den[b];
+                    *reinterpret_cast<Vec<P, BPL> *>(dst) = r;
+                }
+            }
+        }
+    }
+}
+
+template <typename To, typename Tw, int F>
+int launch_wavg_block(const To *obj, const Tw *w, void *out, int64_t n_outer, int ny, int nx,
+                      int64_t w_repeat, hipStream_t stream)
+{
+    using P = typename Promote<To, Tw>::type;
+    constexpr int VEC = 16 / sizeof(P);
+    const int64_t S = (int64_t)(ny / F) * (nx / VEC);
+    const int64_t n_groups = n_outer / w_repeat;
+    const int64_t gx = ceil_div(S, 256);
+    // Split the levels that share a weight slice until the grid fills the chip several times
+    // over (256 CUs x 8 blocks of 256 threads), but keep chunks long enough to amortise the
+    // weight loads.
+    int zsplit = 1;
+    const int64_t want_blocks = 256 * 16;
+    while (gx * n_groups * zsplit < want_blocks && (w_repeat / (zsplit * 2)) >= 4) zsplit *= 2;
+    const int64_t n_gy = n_groups * zsplit;
+    dim3 grid((unsigned)gx, (unsigned)(n_gy < 65535 ? n_gy : 65535));
+    hipLaunchKernelGGL((wavg_block_kernel<To, Tw, F>), grid, dim3(256), 0, stream, obj, w,
+                       reinterpret_cast<P *>(out), n_outer, ny, nx, w_repeat, zsplit, n_gy);
+    return check_launch("wavg_block_kernel");
+}
+
+template <typename To, typename Tw>
+int dispatch_wavg(const void *obj_, const void *w_, void *out, int64_t n_outer, int ny, int nx,
+                  int64_t w_repeat, int by, int bx, int sy, int sx, hipStream_t stream)
+{
+    using P = typename Promote<To, Tw>::type;
+    constexpr int VEC = 16 / sizeof(P);
+    const To *obj = static_cast<const To *>(obj_);
+    const Tw *w = static_cast<const Tw *>(w_);
+    const bool full_blocks = (by == bx && sy == by && sx == bx);
+    const bool vec_ok = (nx % VEC == 0) && (nx % bx == 0) && (ny % by == 0) &&
+                        ((reinterpret_cast<uintptr_t>(obj) % (sizeof(To) * VEC)) == 0) &&
+                        ((reinterpret_cast<uintptr_t>(w) % (sizeof(Tw) * VEC)) == 0) &&
+                        ((reinterpret_cast<uintptr_t>(out) % 16) == 0);
+    if (full_blocks && vec_ok) {
+        switch (by) {
+            case 2: return launch_wavg_block<To, Tw, 2>(obj, w, out, n_outer, ny, nx, w_repeat, stream);
+            case 4: return launch_wavg_block<To, Tw, 4>(obj, w, out, n_outer, ny, nx, w_repeat, stream);
+            case 8: return launch_wavg_block<To, Tw, 8>(obj, w, out, n_outer, ny, nx, w_repeat, stream);
+            case 16: return launch_wavg_block<To, Tw, 16>(obj, w, out, n_outer, ny, nx, w_repeat, stream);
+            case 32: return launch_wavg_block<To, Tw, 32>(obj, w, out, n_outer, ny, nx, w_repeat, stream);
+            default: break;
+        }
+    }
+    const int nyo = (ny - by) / sy + 1, nxo = (nx - bx) / sx + 1;
+    const int64_t total = n_outer * nyo * nxo;
+    if (total == 0) return FV3HIP_OK;
+    int64_t blocks = ceil_div(total, 256);
+    if (blocks > 256 * 64) blocks = 256 * 64;
+    hipLaunchKernelGGL((wavg_generic_kernel<To, Tw>), dim3((unsigned)blocks), dim3(256), 0, stream,
+                       obj, w, reinterpret_cast<P *>(out), n_outer, ny, nx, w_repeat, by, bx, sy,
+                       sx, nyo, nxo);
+    return check_launch("wavg_generic_kernel");
+}
+
+int wavg_entry(const void *obj, int obj_dtype, const void *w, int w_dtype, int64_t n_outer, int ny,
+               int nx, int64_t w_repeat, int by, int bx, int sy, int sx, void *out, void *stream)
+{
+    FV3HIP_REQUIRE(obj_dtype == FV3HIP_F32 || obj_dtype == FV3HIP_F64,
+                   "obj dtype must be F32 or F64, got %d", obj_dtype);
+    FV3HIP_REQUIRE(w_dtype == FV3HIP_F32 || w_dtype == FV3HIP_F64,
+                   "weights dtype must be F32 or F64, got %d", w_dtype);
+    FV3HIP_REQUIRE(n_outer >= 0 && ny >= 0 && nx >= 0, "negative extent");
+    FV3HIP_REQUIRE(w_repeat >= 1, "w_repeat must be >= 1, got %lld", (long long)w_repeat);
+    FV3HIP_REQUIRE(n_outer % w_repeat == 0, "n_outer (%lld) is not a multiple of w_repeat (%lld)",
+                   (long long)n_outer, (long long)w_repeat);
+    if (n_outer == 0 || ny == 0 || nx == 0) return FV3HIP_OK;
+    FV3HIP_REQUIRE(obj && w && out, "null pointer");
+    hipStream_t st = as_stream(stream);
+    if (obj_dtype == FV3HIP_F32 && w_dtype == FV3HIP_F32)
+        return dispatch_wavg<float, float>(obj, w, out, n_outer, ny, nx, w_repeat, by, bx, sy, sx, st);
+    if (obj_dtype == FV3HIP_F64 && w_dtype == FV3HIP_F64)
+        return dispatch_wavg<double, double>(obj, w, out, n_outer, ny, nx, w_repeat, by, bx, sy, sx, st);
+    if (obj_dtype == FV3HIP_F64 && w_dtype == FV3HIP_F32)
+        return dispatch_wavg<double, float>(obj, w, out, n_outer, ny, nx, w_repeat, by, bx, sy, sx, st);
+    return dispatch_wavg<float, double>(obj, w, out, n_outer, ny, nx, w_repeat, by, bx, sy, sx, st);
+}
+
+// ---------------------------------------------------------------------------------------
+// Generic block reductions (sum / mean / min / max / median / mode).
+// ---------------------------------------------------------------------------------------
+template <typename T>
+struct IsFloat {
+    static constexpr bool value = false;
+};
+template <>
+struct IsFloat<float> {
+    static constexpr bool value = true;
+};
+template <>
+struct IsFloat<double> {
+    static constexpr bool value = true;
+};
+
+template <typename T>
+__device__ __forceinline__ bool nan_of(T x)
+{
+    if constexpr (IsFloat<T>::value) return x != x;
+    return false;
+}
+
+template <typename T>
+__device__ __forceinline__ T quiet_nan()
+{
+    if constexpr (sizeof(T) == 4) return (T)__builtin_nanf("");
+    return (T)__builtin_nan("");
+}
+
+template <typename T>
+__global__ void block_reduce_kernel(const T *__restrict__ in, T *__restrict__ out, int64_t n_outer,
+                                    int ny, int nx, int by, int bx, int sy, int sx, int nyo, int nxo,
+                                    int op, int nan_policy)
+{
+    const int64_t total = n_outer * nyo * nxo;
+    const int n = by * bx;
+    for (int64_t idx = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; idx < total;
+         idx += (int64_t)gridDim.x * blockDim.x) {
+        const int X = (int)(idx % nxo);
+        const int64_t t = idx / nxo;
+        const int Y = (int)(t % nyo);
+        const int64_t o = t / nyo;
+        const T *p = in + o * ny * (int64_t)nx + (int64_t)Y * sy * nx + (int64_t)X * sx;
+        auto at = [&](int i) { return p[(int64_t)(i / bx) * nx + (i % bx)]; };
+        T result;
+        if (op == FV3HIP_OP_SUM || op == FV3HIP_OP_MEAN) {
+            T acc = 0;
+            int cnt = 0;
+            for (int i = 0; i < n; ++i) {
+                const T v = at(i);
+                if (!nan_of(v)) {
+                    acc += v;
+                    ++cnt;
+                }
+            }
+            if (op == FV3HIP_OP_MEAN) {
+                if constexpr (IsFloat<T>::value)
+                    result = acc / (T)cnt;  // 0/0 = NaN for an all-NaN block (numpy.nanmean)
+                else
+                    result = acc;
+            } else {
+                result = acc;
+            }
+        } else if (op == FV3HIP_OP_MIN || op == FV3HIP_OP_MAX) {
+            bool have = false;
+            T best = 0;
+            for (int i = 0; i < n; ++i) {
+                const T v = at(i);
+                if (nan_of(v)) continue;
+                if (!have || (op == FV3HIP_OP_MIN ? v < best : v > best)) best = v;
+                have = true;
+            }
+            if constexpr (IsFloat<T>::value)
+                result = have ? best : quiet_nan<T>();
+            else
+                result = best;
+        } else if (op == FV3HIP_OP_MEDIAN) {
+            // numpy.median: NaN if any NaN, else the mean of the two middle order statistics.
+            bool any_nan = false;
+            for (int i = 0; i < n; ++i) any_nan |= nan_of(at(i));
+            if (any_nan) {
+                result = quiet_nan<T>();
+            } else {
+                const int r1 = (n - 1) / 2, r2 = n / 2;
+                T m1 = 0, m2 = 0;
+                for (int i = 0; i < n; ++i) {
+                    const T v = at(i);
+                    int less = 0, eq = 0;
+                    for (int j = 0; j < n; ++j) {
+                        const T u = at(j);
+                        less += (u < v);
+                        eq += (u == v);
+                    }
+                    if (less <= r1 && r1 < less + eq) m1 = v;
+                    if (less <= r2 && r2 < less + eq) m2 = v;
+                }
+                if constexpr (IsFloat<T>::value)
+                    result = (r1 == r2) ? m1 : (m1 + m2) / (T)2;
+                else
+                    result = m1;
+            }
+        } else {
+            // scipy.stats.mode (1.7.3): the most frequent non-NaN value, smallest value on ties.
+            int best_cnt = 0;
+            T best = 0;
+            for (int i = 0; i < n; ++i) {
+                const T v = at(i);
+                if (nan_of(v)) continue;
+                int eq = 0;
+                for (int j = 0; j < n; ++j) eq += (at(j) == v);
+                if (eq > best_cnt || (eq == best_cnt && v < best)) {
+                    best_cnt = eq;
+                    best = v;
+                }
+            }
+            if constexpr (IsFloat<T>::value) {
+                // all-NaN block: "propagate" gives 0.0 in scipy 1.7.3 (count 0); for "omit"
+                // the masked result is reported as NaN here.
+                result = (best_cnt > 0) ? best
+                                        : (nan_policy == FV3HIP_NAN_OMIT ? quiet_nan<T>() : (T)0);
+            } else {
+                result = best;
+            }
+        }
+        out[idx] = result;
+    }
+}
+
+template <typename T>
+int launch_block_reduce(const void *in, void *out, int64_t n_outer, int ny, int nx, int by, int bx,
+                        int sy, int sx, int op, int nan_policy, hipStream_t stream)
+{
+    const int nyo = (ny - by) / sy + 1, nxo = (nx - bx) / sx + 1;
+    const int64_t total = n_outer * nyo * nxo;
+    if (total <= 0) return FV3HIP_OK;
+    int64_t blocks = ceil_div(total, 256);
+    if (blocks > 256 * 64) blocks = 256 * 64;
+    hipLaunchKernelGGL((block_reduce_kernel<T>), dim3((unsigned)blocks), dim3(256), 0, stream,
+                       static_cast<const T *>(in), static_cast<T *>(out), n_outer, ny, nx, by, bx,
+                       sy, sx, nyo, nxo, op, nan_policy);
+    return check_launch("block_reduce_kernel");
+}
+
+// ---------------------------------------------------------------------------------------
+// block_upsample: out[o][y][x] = in[o][y / f][x / f]
+// ---------------------------------------------------------------------------------------
+template <typename U>
+__global__ void upsample_kernel(const U *__restrict__ in, U *__restrict__ out, int64_t n_outer,
+                                int ny_in, int nx_in, int ny_out, int nx_out, int f)
+{
+    const int64_t total = n_outer * ny_out * nx_out;
+    for (int64_t idx = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; idx < total;
+         idx += (int64_t)gridDim.x * blockDim.x) {
+        const int x = (int)(idx % nx_out);
+        const int64_t t = idx / nx_out;
+        const int y = (int)(t % ny_out);
+        const int64_t o = t / ny_out;
+        out[idx] = in[(o * ny_in + y / f) * nx_in + x / f];
+    }
+}
+
+}  // namespace
+}  // namespace fv3hip
+
+using namespace fv3hip;
+
+extern "C" int fv3hip_weighted_block_average(const void *obj, int obj_dtype, const void *weights,
+                                             int w_dtype, int64_t n_outer, int ny, int nx,
+                                             int64_t w_repeat, int factor, void *out, void *stream)
+{
+    FV3HIP_REQUIRE(factor >= 1, "coarsening factor must be >= 1, got %d", factor);
+    FV3HIP_REQUIRE(ny % factor == 0 && nx % factor == 0,
+                   "horizontal extents (%d, %d) are not multiples of the coarsening factor %d", ny,
+                   nx, factor);
+    return wavg_entry(obj, obj_dtype, weights, w_dtype, n_outer, ny, nx, w_repeat, factor, factor,
+                      factor, factor, out, stream);
+}
+
+extern "C" int fv3hip_edge_weighted_block_average(const void *obj, int obj_dtype,
+                                                  const void *spacing, int w_dtype, int64_t n_outer,
+                                                  int ny, int nx, int64_t w_repeat, int factor,
+                                                  int edge, void *out, void *stream)
+{
+    FV3HIP_REQUIRE(factor >= 1, "coarsening factor must be >= 1, got %d", factor);
+    FV3HIP_REQUIRE(edge == 0 || edge == 1, "edge must be 0 ('x') or 1 ('y'), got %d", edge);
+    if (edge == 0) {
+        FV3HIP_REQUIRE(nx % factor == 0, "x extent %d is not a multiple of the factor %d", nx, factor);
+        return wavg_entry(obj, obj_dtype, spacing, w_dtype, n_outer, ny, nx, w_repeat, 1, factor,
+                          factor, factor, out, stream);
+    }
+    FV3HIP_REQUIRE(ny % factor == 0, "y extent %d is not a multiple of the factor %d", ny, factor);
+    return wavg_entry(obj, obj_dtype, spacing, w_dtype, n_outer, ny, nx, w_repeat, factor, 1, factor,
+                      factor, out, stream);
+}
+
+extern "C" int fv3hip_block_reduce(const void *in, int dtype, int64_t n_outer, int ny, int nx, int by,
+                                   int bx, int sy, int sx, int op, int nan_policy, void *out,
+                                   void *stream)
+{
+    FV3HIP_REQUIRE(by >= 1 && bx >= 1 && sy >= 1 && sx >= 1, "window and stride must be >= 1");
+    FV3HIP_REQUIRE(op >= FV3HIP_OP_SUM && op <= FV3HIP_OP_MODE, "unknown reduction op %d", op);
+    FV3HIP_REQUIRE(n_outer >= 0 && ny >= 0 && nx >= 0, "negative extent");
+    if (n_outer == 0 || ny < by || nx < bx) return FV3HIP_OK;
+    FV3HIP_REQUIRE(in && out, "null pointer");
+    hipStream_t st = as_stream(stream);
+    switch (dtype) {
+        case FV3HIP_F32: return launch_block_reduce<float>(in, out, n_outer, ny, nx, by, bx, sy, sx, op, nan_policy, st);
+        case FV3HIP_F64: return launch_block_reduce<double>(in, out, n_outer, ny, nx, by, bx, sy, sx, op, nan_policy, st);
+        case FV3HIP_I32:
+        case FV3HIP_I64:
+            if (op == FV3HIP_OP_MEAN || op == FV3HIP_OP_MEDIAN)
+                return fail(FV3HIP_EUNSUPPORTED, "mean/median of integer fields is not supported");
+            return dtype == FV3HIP_I32
+                       ? launch_block_reduce<int32_t>(in, out, n_outer, ny, nx, by, bx, sy, sx, op, nan_policy, st)
+                       : launch_block_reduce<int64_t>(in, out, n_outer, ny, nx, by, bx, sy, sx, op, nan_policy, st);
+        default: return fail(FV3HIP_EINVAL, "unknown dtype %d", dtype);
+    }
+}
+
+extern "C" int fv3hip_block_upsample(const void *in, int elem_size, int64_t n_outer, int ny_in,
+                                     int nx_in, int factor, void *out, void *stream)
+{
+    FV3HIP_REQUIRE(factor >= 1, "upsampling factor must be >= 1, got %d", factor);
+    FV3HIP_REQUIRE(elem_size == 4 || elem_size == 8, "elem_size must be 4 or 8, got %d", elem_size);
+    FV3HIP_REQUIRE(n_outer >= 0 && ny_in >= 0 && nx_in >= 0, "negative extent");
+    if (n_outer == 0 || ny_in == 0 || nx_in == 0) return FV3HIP_OK;
+    FV3HIP_REQUIRE(in && out, "null pointer");
+    // odd size = staggered (interface) dimension: the last point is not repeated
+    const int ny_out = (ny_in % 2 == 1) ? (ny_in - 1) * factor + 1 : ny_in * factor;
+    const int nx_out = (nx_in % 2 == 1) ? (nx_in - 1) * factor + 1 : nx_in * factor;
+    const int64_t total = n_outer * ny_out * nx_out;
+    int64_t blocks = ceil_div(total, 256);
+    if (blocks > 256 * 64) blocks = 256 * 64;
+    hipStream_t st = as_stream(stream);
+    if (elem_size == 4)
+        hipLaunchKernelGGL((upsample_kernel<uint32_t>), dim3((unsigned)blocks), dim3(256), 0, st,
+                           static_cast<const uint32_t *>(in), static_cast<uint32_t *>(out), n_outer,
+                           ny_in, nx_in, ny_out, nx_out, factor);
+    else
+        hipLaunchKernelGGL((upsample_kernel<uint64_t>), dim3((unsigned)blocks), dim3(256), 0, st,
+                           static_cast<const uint64_t *>(in), static_cast<uint64_t *>(out), n_outer,
+                           ny_in, nx_in, ny_out, nx_out, factor);
+    return check_launch("upsample_kernel");
+}

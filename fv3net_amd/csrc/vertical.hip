@@ -1,0 +1,441 @@
+// Vertical kernels for gfx950: interface pressures, weight masking, and the PPM remap (mappm).
+//
+// Reference behaviour restated (paths relative to the reference checkout):
+//   external/vcm/vcm/calc/thermo/vertically_dependent.py:41-66   pressure_at_interface
+//   external/vcm/vcm/cubedsphere/regridz.py:200-220               _mask_weights
+//   external/mappm/mappm/mappm.f90:10-126, 614-851, 854-931       mappm, ppm_profile, ppm_limiters
+//
+// This file is compiled with -ffp-contract=off: the remap is single precision with the exact
+// association order of the Fortran, so that its results are bit-identical to the reference
+// built without FMA contraction (and to oracle/mappm_oracle.c).
+#include "common.h"
+
+namespace fv3hip {
+namespace {
+
+// ---------------------------------------------------------------------------------------
+// pressure_at_interface: sequential cumulative sum down each column, in the array's dtype.
+// ---------------------------------------------------------------------------------------
+template <typename T>
+__global__ void pressure_at_interface_kernel(const T *__restrict__ delp, T *__restrict__ out,
+                                             int64_t n_batch, int nz, int64_t n_inner, T toa)
+{
+    const int64_t ncol = n_batch * n_inner;
+    for (int64_t col = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; col < ncol;
+         col += (int64_t)gridDim.x * blockDim.x) {
+        const int64_t b = col / n_inner, c = col % n_inner;
+        const T *pd = delp + b * nz * n_inner + c;
+        T *po = out + b * (nz + 1) * n_inner + c;
+        T p = toa;
+        po[0] = p;
+        for (int k = 0; k < nz; ++k) {
+            p = p + pd[(int64_t)k * n_inner];
+            po[(int64_t)(k + 1) * n_inner] = p;
+        }
+    }
+}
+
+// ---------------------------------------------------------------------------------------
+// _mask_weights (extrapolate=False): keep the weight where the bottom interface of coarse
+// layer k lies above the fine-grid surface pressure.
+// ---------------------------------------------------------------------------------------
+template <typename Tw, typename Tp>
+__global__ void mask_weights_kernel(const Tw *__restrict__ w, const Tp *__restrict__ pc,
+                                    const Tp *__restrict__ pf, Tw *__restrict__ out,
+                                    int64_t n_batch, int nz, int64_t n_inner, int64_t w_repeat)
+{
+    const int64_t total = n_batch * nz * n_inner;
+    for (int64_t idx = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; idx < total;
+         idx += (int64_t)gridDim.x * blockDim.x) {
+        const int64_t c = idx % n_inner;
+        const int64_t t = idx / n_inner;
+        const int k = (int)(t % nz);
+        const int64_t b = t / nz;
+        const Tp bottom = pc[(b * (nz + 1) + (k + 1)) * n_inner + c];
+        const Tp ps = pf[(b * (nz + 1) + nz) * n_inner + c];
+        out[idx] = (bottom < ps) ? w[(b / w_repeat) * n_inner + c] : (Tw)0;
+    }
+}
+
+// ---------------------------------------------------------------------------------------
+// mappm, version 1: one thread per column, the Fortran control flow verbatim, the
+// reconstruction (AL, AR, A6) and the slopes DC / H2 kept in a global workspace laid out
+// [array][level][column-in-chunk] so that every access of a wave is one coalesced row.
+// ---------------------------------------------------------------------------------------
+__device__ __forceinline__ float f_sign(float a, float b) { return copysignf(fabsf(a), b); }
+__device__ __forceinline__ float f_min2(float a, float b) { return (a < b) ? a : b; }
+__device__ __forceinline__ float f_max2(float a, float b) { return (a > b) ? a : b; }
+__device__ __forceinline__ float f_min3(float a, float b, float c) { return f_min2(f_min2(a, b), c); }
+__device__ __forceinline__ float f_max3(float a, float b, float c) { return f_max2(f_max2(a, b), c); }
+
+// mappm.f90:854-931 for one (column, level)
+__device__ __forceinline__ void ppm_limiters1(float dm, float a1, float &a2, float &a3, float &a4,
+                                              int lmt)
+{
+    const float r12 = 1.f / 12.f;
+    if (lmt == 3) return;
+    if (lmt == 0) {
+        if (dm == 0.f) {
+            a2 = a1;
+            a3 = a1;
+            a4 = 0.f;
+        } else {
+            const float da1 = a3 - a2;
+            const float da2 = da1 * da1;
+            const float a6da = a4 * da1;
+            if (a6da < -da2) {
+                a4 = 3.f * (a2 - a1);
+                a3 = a2 - a4;
+            } else if (a6da > da2) {
+                a4 = 3.f * (a3 - a1);
+                a2 = a3 - a4;
+            }
+        }
+    } else if (lmt == 1) {
+        const float qmp = 2.f * dm;
+        a2 = a1 - f_sign(f_min2(fabsf(qmp), fabsf(a2 - a1)), qmp);
+        a3 = a1 + f_sign(f_min2(fabsf(qmp), fabsf(a3 - a1)), qmp);
+        a4 = 3.f * (2.f * a1 - (a2 + a3));
+    } else if (lmt == 2) {
+        if (fabsf(a3 - a2) < -a4) {
+            const float d = a3 - a2;
+            const float fmin = a1 + 0.25f * (d * d) / a4 + a4 * r12;
+            if (fmin < 0.f) {
+                if (a1 < a3 && a1 < a2) {
+                    a3 = a1;
+                    a2 = a1;
+                    a4 = 0.f;
+                } else if (a3 > a2) {
+                    a4 = 3.f * (a2 - a1);
+                    a3 = a2 - a4;
+                } else {
+                    a4 = 3.f * (a3 - a1);
+                    a2 = a3 - a4;
+                }
+            }
+        }
+    }
+}
+
+template <typename Tin>
+__global__ __launch_bounds__(256) void mappm_simple_kernel(
+    const Tin *__restrict__ pe1_, const Tin *__restrict__ q1_, const Tin *__restrict__ pe2_,
+    float *__restrict__ q2_, int64_t col0, int64_t col_end, int64_t n_inner, int km, int kn, int iv,
+    int kord, int layout, float *__restrict__ ws, int64_t ws_cols)
+{
+    const int64_t lc = blockIdx.x * (int64_t)blockDim.x + threadIdx.x;  // column inside the chunk
+    const int64_t col = col0 + lc;
+    if (col >= col_end) return;
+
+    // element (column, level k) of an array with `nlev` levels lives at base + (k-1)*ks
+    int64_t ks;
+    int64_t o_pe1, o_q1, o_pe2, o_q2;
+    if (layout == FV3HIP_LAYOUT_COL_LEVEL) {
+        ks = 1;
+        o_pe1 = col * (km + 1);
+        o_q1 = col * km;
+        o_pe2 = col * (kn + 1);
+        o_q2 = col * kn;
+    } else {
+        ks = n_inner;
+        const int64_t b = col / n_inner, c = col % n_inner;
+        o_pe1 = b * (km + 1) * n_inner + c;
+        o_q1 = b * km * n_inner + c;
+        o_pe2 = b * (kn + 1) * n_inner + c;
+        o_q2 = b * kn * n_inner + c;
+    }
+    auto PE1 = [&](int k) { return (float)pe1_[o_pe1 + (int64_t)(k - 1) * ks]; };
+    auto Q = [&](int k) { return (float)q1_[o_q1 + (int64_t)(k - 1) * ks]; };
+    auto PE2 = [&](int k) { return (float)pe2_[o_pe2 + (int64_t)(k - 1) * ks]; };
+    auto DP = [&](int k) { return PE1(k + 1) - PE1(k); };          // dp1(i,k)
+    auto DELQ = [&](int k) { return Q(k + 1) - Q(k); };            // delq(i,k)
+    auto D4 = [&](int k) { return DP(k - 1) + DP(k); };            // d4(i,k)
+
+    const int64_t plane = (int64_t)km * ws_cols;
+    float *AL = ws + 0 * plane + lc, *AR = ws + 1 * plane + lc, *A6 = ws + 2 * plane + lc,
+          *DC = ws + 3 * plane + lc, *H2 = ws + 4 * plane + lc;
+#define W_(arr, k) arr[(int64_t)((k)-1) * ws_cols]
+
+    const int km1 = km - 1;
+    // ---- ppm_profile (mappm.f90:651-683) ----
+    for (int k = 2; k <= km1; ++k) {
+        const float dpk = DP(k), d4k = D4(k), d4k1 = D4(k + 1);
+        const float c1 = (DP(k - 1) + 0.5f * dpk) / d4k1;
+        const float c2 = (DP(k + 1) + 0.5f * dpk) / d4k;
+        const float df2 = dpk * (c1 * DELQ(k) + c2 * DELQ(k - 1)) / (d4k + DP(k + 1));
+        const float qm1 = Q(k - 1), q0 = Q(k), qp1 = Q(k + 1);
+        W_(DC, k) = f_sign(f_min3(fabsf(df2), f_max3(qm1, q0, qp1) - q0, q0 - f_min3(qm1, q0, qp1)), df2);
+    }
+    for (int k = 3; k <= km1; ++k) {
+        const float d4k = D4(k);
+        const float c1 = DELQ(k - 1) * DP(k - 1) / d4k;
+        const float a1 = D4(k - 1) / (d4k + DP(k - 1));
+        const float a2 = D4(k + 1) / (d4k + DP(k));
+        W_(AL, k) = Q(k - 1) + c1 +
+                    2.f / (D4(k - 1) + D4(k + 1)) *
+                        (DP(k) * (c1 * (a1 - a2) + a2 * W_(DC, k - 1)) - DP(k - 1) * a1 * W_(DC, k));
+    }
+    {
+        // Top (mappm.f90:689-725)
+        const float d1 = DP(1), d2 = DP(2);
+        const float qm = (d2 * Q(1) + d1 * Q(2)) / (d1 + d2);
+        const float dq = 2.f * (Q(2) - Q(1)) / (d1 + d2);
+        const float c1 = 4.f * (W_(AL, 3) - qm - d2 * dq) / (d2 * (2.f * d2 * d2 + d1 * (d2 + 3.f * d1)));
+        const float c3 = dq - 0.5f * c1 * (d2 * (5.f * d1 + d2) - 3.f * d1 * d1);
+        float al2 = qm - 0.25f * c1 * d1 * d2 * (d2 + 3.f * d1);
+        float al1 = d1 * (2.f * c1 * (d1 * d1) - c3) + al2;
+        al2 = f_max2(al2, f_min2(Q(1), Q(2)));
+        al2 = f_min2(al2, f_max2(Q(1), Q(2)));
+        W_(DC, 1) = 0.5f * (al2 - Q(1));
+        if (iv == 0) {
+            al1 = f_max2(0.f, al1);
+            al2 = f_max2(0.f, al2);
+        } else if (iv == -1) {
+            if (al1 * Q(1) <= 0.f) al1 = 0.f;
+        } else if (iv == 2 || iv == -2) {
+            al1 = Q(1);
+            // a4(3,i,1) = a4(1,i,1) is overwritten below by a4(3,i,1) = a4(2,i,2)
+        }
+        W_(AL, 1) = al1;
+        W_(AL, 2) = al2;
+    }
+    {
+        // Bottom (mappm.f90:729-761)
+        const float d1 = DP(km), d2 = DP(km1);
+        const float qm = (d2 * Q(km) + d1 * Q(km1)) / (d1 + d2);
+        const float dq = 2.f * (Q(km1) - Q(km)) / (d1 + d2);
+        const float c1 = (W_(AL, km1) - qm - d2 * dq) / (d2 * (2.f * d2 * d2 + d1 * (d2 + 3.f * d1)));
+        const float c3 = dq - 2.0f * c1 * (d2 * (5.f * d1 + d2) - 3.f * d1 * d1);
+        float alk = qm - c1 * d1 * d2 * (d2 + 3.f * d1);
+        float ark = d1 * (8.f * c1 * (d1 * d1) - c3) + alk;
+        alk = f_max2(alk, f_min2(Q(km), Q(km1)));
+        alk = f_min2(alk, f_max2(Q(km), Q(km1)));
+        W_(DC, km) = 0.5f * (Q(km) - alk);
+        if (iv == 0) {
+            alk = f_max2(0.f, alk);
+            ark = f_max2(0.f, ark);
+        } else if (iv < 0) {
+            if (Q(km) * ark <= 0.f) ark = 0.f;
+        }
+        W_(AL, km) = alk;
+        W_(AR, km) = ark;
+    }
+    for (int k = 1; k <= km1; ++k) W_(AR, k) = W_(AL, k + 1);
+
+    auto finish_level = [&](int k, int lmt, bool recompute_a6, bool limit) {
+        const float q0 = Q(k);
+        float al = W_(AL, k), ar = W_(AR, k), a6 = W_(A6, k);
+        if (recompute_a6) a6 = 3.f * (2.f * q0 - (al + ar));
+        if (limit) ppm_limiters1(W_(DC, k), q0, al, ar, a6, lmt);
+        W_(AL, k) = al;
+        W_(AR, k) = ar;
+        W_(A6, k) = a6;
+    };
+    // Top 2 layers always use monotonic mapping (mappm.f90:773-778)
+    for (int k = 1; k <= 2; ++k) finish_level(k, 0, true, true);
+
+    if (kord >= 7) {
+        // Huynh's 2nd constraint (mappm.f90:780-826)
+        for (int k = 2; k <= km1; ++k) {
+            const float dpk = DP(k);
+            W_(H2, k) = 2.f * (W_(DC, k + 1) / DP(k + 1) - W_(DC, k - 1) / DP(k - 1)) /
+                        (dpk + 0.5f * (DP(k - 1) + DP(k + 1))) * (dpk * dpk);
+        }
+        const float fac = 1.5f;
+        for (int k = 3; k <= km - 2; ++k) {
+            const float q0 = Q(k), dck = W_(DC, k);
+            float al = W_(AL, k), ar = W_(AR, k), a6;
+            const float pmp = 2.f * dck;
+            float qmp = q0 + pmp;
+            float lac = q0 + fac * W_(H2, k - 1) + dck;
+            ar = f_min2(f_max2(ar, f_min3(q0, qmp, lac)), f_max3(q0, qmp, lac));
+            qmp = q0 - pmp;
+            lac = q0 + fac * W_(H2, k + 1) - dck;
+            al = f_min2(f_max2(al, f_min3(q0, qmp, lac)), f_max3(q0, qmp, lac));
+            a6 = 3.f * (2.f * q0 - (al + ar));
+            if (iv == 0 && kord >= 6) ppm_limiters1(dck, q0, al, ar, a6, 2);
+            W_(AL, k) = al;
+            W_(AR, k) = ar;
+            W_(A6, k) = a6;
+        }
+    } else {
+        int lmt = kord - 3;
+        lmt = (lmt > 0) ? lmt : 0;
+        if (iv == 0) lmt = (lmt < 2) ? lmt : 2;
+        for (int k = 3; k <= km - 2; ++k) finish_level(k, lmt, kord != 4, kord != 6);
+    }
+    for (int k = km1; k <= km; ++k) finish_level(k, 0, true, true);
+
+    // ---- remap (mappm.f90:58-124) ----
+    const float r3 = 1.f / 3.f, r23 = 2.f / 3.f;
+    int k0 = 1, k1 = 1;
+    float qsum = 0.f, dpsum = 0.f;
+    const float pe1_top = PE1(1), pe1_bot = PE1(km + 1);
+    for (int k = 1; k <= kn; ++k) {
+        const float p2k = PE2(k);
+        float result;
+        if (p2k <= pe1_top) {
+            result = Q(1);
+        } else if (p2k >= pe1_bot) {
+            result = Q(km);
+        } else {
+            const float p2k1 = PE2(k + 1);
+            bool done = false;
+            for (int L = k0; L <= km; ++L) {
+                const float pL = PE1(L), pL1 = PE1(L + 1);
+                if (p2k >= pL && p2k <= pL1) {
+                    k0 = L;
+                    const float dpL = pL1 - pL;
+                    const float al = W_(AL, L), ar = W_(AR, L), a6 = W_(A6, L);
+                    const float PL = (p2k - pL) / dpL;
+                    if (p2k1 <= pL1) {
+                        const float PR = (p2k1 - pL) / dpL;
+                        const float TT = r3 * (PR * (PR + PL) + PL * PL);
+                        result = al + 0.5f * (a6 + ar - al) * (PR + PL) - a6 * TT;
+                        done = true;
+                    } else {
+                        const float delp = pL1 - p2k;
+                        const float TT = r3 * (1.f + PL * (1.f + PL));
+                        qsum = delp * (al + 0.5f * (a6 + ar - al) * (1.f + PL) - a6 * TT);
+                        dpsum = delp;
+                        k1 = L + 1;
+                    }
+                    break;
+                }
+            }
+            if (!done) {
+                bool finished = false;
+                for (int L = k1; L <= km; ++L) {
+                    const float pL = PE1(L), pL1 = PE1(L + 1);
+                    const float dpL = pL1 - pL;
+                    if (p2k1 > pL1) {
+                        qsum = qsum + dpL * Q(L);
+                        dpsum = dpsum + dpL;
+                    } else {
+                        const float delp = p2k1 - pL;
+                        const float esl = delp / dpL;
+                        const float al = W_(AL, L), ar = W_(AR, L), a6 = W_(A6, L);
+                        qsum = qsum + delp * (al + 0.5f * esl * (ar - al + a6 * (1.f - r23 * esl)));
+                        dpsum = dpsum + delp;
+                        k0 = L;
+                        finished = true;
+                        break;
+                    }
+                }
+                if (!finished) {
+                    const float delp = p2k1 - pe1_bot;
+                    if (delp > 0.f) {
+                        qsum = qsum + delp * Q(km);
+                        dpsum = dpsum + delp;
+                    }
+                }
+                result = qsum / dpsum;
+            }
+        }
+        q2_[o_q2 + (int64_t)(k - 1) * ks] = result;
+    }
+#undef W_
+}
+
+constexpr int64_t kMappmChunk = 1 << 20;  // columns per launch; bounds the workspace
+constexpr int kMappmPlanes = 5;           // AL, AR, A6, DC, H2
+
+}  // namespace
+}  // namespace fv3hip
+
+using namespace fv3hip;
+
+extern "C" int fv3hip_pressure_at_interface(const void *delp, int dtype, int64_t n_batch, int nz,
+                                            int64_t n_inner, double toa_pressure, void *out,
+                                            void *stream)
+{
+    FV3HIP_REQUIRE(dtype == FV3HIP_F32 || dtype == FV3HIP_F64, "dtype must be F32 or F64, got %d", dtype);
+    FV3HIP_REQUIRE(n_batch >= 0 && nz >= 0 && n_inner >= 0, "negative extent");
+    const int64_t ncol = n_batch * n_inner;
+    if (ncol == 0) return FV3HIP_OK;
+    FV3HIP_REQUIRE(delp && out, "null pointer");
+    int64_t blocks = ceil_div(ncol, 256);
+    if (blocks > 256 * 64) blocks = 256 * 64;
+    hipStream_t st = as_stream(stream);
+    if (dtype == FV3HIP_F32)
+        hipLaunchKernelGGL((pressure_at_interface_kernel<float>), dim3((unsigned)blocks), dim3(256), 0,
+                           st, static_cast<const float *>(delp), static_cast<float *>(out), n_batch,
+                           nz, n_inner, (float)toa_pressure);
+    else
+        hipLaunchKernelGGL((pressure_at_interface_kernel<double>), dim3((unsigned)blocks), dim3(256),
+                           0, st, static_cast<const double *>(delp), static_cast<double *>(out),
+                           n_batch, nz, n_inner, toa_pressure);
+    return check_launch("pressure_at_interface_kernel");
+}
+
+extern "C" int fv3hip_mask_weights(const void *weights, int w_dtype, const void *p_coarse,
+                                   const void *p_fine, int p_dtype, int64_t n_batch, int nz,
+                                   int64_t n_inner, int64_t w_repeat, void *out, void *stream)
+{
+    FV3HIP_REQUIRE(w_dtype == FV3HIP_F32 || w_dtype == FV3HIP_F64, "weights dtype must be F32 or F64");
+    FV3HIP_REQUIRE(p_dtype == FV3HIP_F32 || p_dtype == FV3HIP_F64, "pressure dtype must be F32 or F64");
+    FV3HIP_REQUIRE(w_repeat >= 1 && n_batch % w_repeat == 0, "bad w_repeat %lld", (long long)w_repeat);
+    const int64_t total = n_batch * nz * n_inner;
+    if (total <= 0) return FV3HIP_OK;
+    FV3HIP_REQUIRE(weights && p_coarse && p_fine && out, "null pointer");
+    int64_t blocks = ceil_div(total, 256);
+    if (blocks > 256 * 64) blocks = 256 * 64;
+    hipStream_t st = as_stream(stream);
+#define LAUNCH_(TW, TP)                                                                              \
+    hipLaunchKernelGGL((mask_weights_kernel<TW, TP>), dim3((unsigned)blocks), dim3(256), 0, st,      \
+                       static_cast<const TW *>(weights), static_cast<const TP *>(p_coarse),          \
+                       static_cast<const TP *>(p_fine), static_cast<TW *>(out), n_batch, nz, n_inner, \
+                       w_repeat)
+    if (w_dtype == FV3HIP_F32 && p_dtype == FV3HIP_F32) LAUNCH_(float, float);
+    else if (w_dtype == FV3HIP_F32) LAUNCH_(float, double);
+    else if (p_dtype == FV3HIP_F32) LAUNCH_(double, float);
+    else LAUNCH_(double, double);
+#undef LAUNCH_
+    return check_launch("mask_weights_kernel");
+}
+
+extern "C" size_t fv3hip_mappm_workspace_bytes(int64_t ncol, int km)
+{
+    if (ncol <= 0 || km <= 0) return 0;
+    const int64_t cols = ncol < kMappmChunk ? ncol : kMappmChunk;
+    return (size_t)kMappmPlanes * (size_t)km * (size_t)cols * sizeof(float);
+}
+
+extern "C" int fv3hip_mappm(const void *pe1, const void *q1, const void *pe2, int in_dtype, float *q2,
+                            int64_t n_batch, int64_t n_inner, int km, int kn, int iv, int kord,
+                            int layout, void *workspace, size_t workspace_bytes, void *stream)
+{
+    FV3HIP_REQUIRE(in_dtype == FV3HIP_F32 || in_dtype == FV3HIP_F64, "in_dtype must be F32 or F64, got %d", in_dtype);
+    FV3HIP_REQUIRE(layout == FV3HIP_LAYOUT_COL_LEVEL || layout == FV3HIP_LAYOUT_LEVEL_COL, "unknown layout %d", layout);
+    FV3HIP_REQUIRE(n_batch >= 0 && n_inner >= 0 && kn >= 0, "negative extent");
+    FV3HIP_REQUIRE(iv >= -2 && iv <= 2, "iv must be in [-2, 2], got %d", iv);
+    if (kord > 7)
+        return fail(FV3HIP_EUNSUPPORTED, "kord=%d selects cs_profile (mappm.f90:132-611), which is not implemented; kord <= 7 only", kord);
+    FV3HIP_REQUIRE(km >= 4, "km must be >= 4 (ppm_profile reads a4(2,i,3)), got %d", km);
+    if (layout == FV3HIP_LAYOUT_COL_LEVEL)
+        FV3HIP_REQUIRE(n_inner == 1, "COL_LEVEL layout requires n_inner == 1");
+    const int64_t ncol = n_batch * n_inner;
+    if (ncol == 0 || kn == 0) return FV3HIP_OK;
+    FV3HIP_REQUIRE(pe1 && q1 && pe2 && q2, "null pointer");
+    FV3HIP_REQUIRE(workspace && workspace_bytes >= fv3hip_mappm_workspace_bytes(ncol, km),
+                   "workspace too small: need %zu bytes, got %zu", fv3hip_mappm_workspace_bytes(ncol, km), workspace_bytes);
+    hipStream_t st = as_stream(stream);
+    const int64_t ws_cols = ncol < kMappmChunk ? ncol : kMappmChunk;
+    for (int64_t col0 = 0; col0 < ncol; col0 += kMappmChunk) {
+        const int64_t col_end = (col0 + kMappmChunk < ncol) ? col0 + kMappmChunk : ncol;
+        const int64_t blocks = ceil_div(col_end - col0, 256);
+        if (in_dtype == FV3HIP_F32)
+            hipLaunchKernelGGL((mappm_simple_kernel<float>), dim3((unsigned)blocks), dim3(256), 0, st,
+                               static_cast<const float *>(pe1), static_cast<const float *>(q1),
+                               static_cast<const float *>(pe2), q2, col0, col_end, n_inner, km, kn, iv,
+                               kord, layout, static_cast<float *>(workspace), ws_cols);
+        else
+            hipLaunchKernelGGL((mappm_simple_kernel<double>), dim3((unsigned)blocks), dim3(256), 0, st,
+                               static_cast<const double *>(pe1), static_cast<const double *>(q1),
+                               static_cast<const double *>(pe2), q2, col0, col_end, n_inner, km, kn,
+                               iv, kord, layout, static_cast<float *>(workspace), ws_cols);
+        int rc = check_launch("mappm_simple_kernel");
+        if (rc) return rc;
+    }
+    return FV3HIP_OK;
+}

@@ -1,0 +1,354 @@
+"""Array-level entry points: torch device tensors in, torch device tensors out.
+
+Every function here is a thin shape/dtype check around one C-ABI call into ``libfv3hip.so``
+(``include/fv3hip.h``), enqueued on torch's current HIP stream.  PyTorch only supplies device
+memory and the stream; no torch kernel does any of the arithmetic.  There is no CPU path:
+tensors must live on a ``cuda`` (ROCm) device.
+"""
+import ctypes
+import math
+from typing import Optional, Sequence
+
+import numpy as np
+import torch
+
+from . import _lib
+
+_DTYPE_CODE = {
+    torch.float32: _lib.F32,
+    torch.float64: _lib.F64,
+    torch.int32: _lib.I32,
+    torch.int64: _lib.I64,
+}
+
+_OPS = {
+    "sum": _lib.OP_SUM,
+    "mean": _lib.OP_MEAN,
+    "min": _lib.OP_MIN,
+    "max": _lib.OP_MAX,
+    "median": _lib.OP_MEDIAN,
+    "mode": _lib.OP_MODE,
+}
+
+_initialised_devices = set()
+
+
+def _require_device(*tensors):
+    dev = None
+    for t in tensors:
+        if not isinstance(t, torch.Tensor):
+            raise TypeError(f"expected a torch.Tensor, got {type(t)}")
+        if not t.is_cuda:
+            raise RuntimeError(
+                "fv3net_amd.ops works on device tensors only (there is no CPU fallback); "
+                "move the input to a 'cuda' (ROCm) device first"
+            )
+        if dev is None:
+            dev = t.device
+        elif t.device != dev:
+            raise RuntimeError(f"tensors live on different devices: {dev} and {t.device}")
+    idx = dev.index if dev.index is not None else torch.cuda.current_device()
+    if idx not in _initialised_devices:
+        _lib.call("fv3hip_init", idx)
+        _initialised_devices.add(idx)
+    return dev
+
+
+def _code(t: torch.Tensor) -> int:
+    try:
+        return _DTYPE_CODE[t.dtype]
+    except KeyError:
+        raise TypeError(f"unsupported dtype {t.dtype}") from None
+
+
+def _float_code(t: torch.Tensor) -> int:
+    if t.dtype not in (torch.float32, torch.float64):
+        raise TypeError(f"expected float32 or float64, got {t.dtype}")
+    return _DTYPE_CODE[t.dtype]
+
+
+def _ptr(t: Optional[torch.Tensor]):
+    return ctypes.c_void_p(t.data_ptr()) if t is not None else ctypes.c_void_p(0)
+
+
+def _stream(dev) -> ctypes.c_void_p:
+    return ctypes.c_void_p(torch.cuda.current_stream(dev).cuda_stream)
+
+
+def _prod(xs) -> int:
+    return int(math.prod(int(x) for x in xs))
+
+
+def _weights_repeat(obj: torch.Tensor, weights: torch.Tensor):
+    """Return (weights_contiguous, w_repeat) such that weight slice ``o // w_repeat`` applies to
+    outer slice ``o`` of ``obj`` (both viewed as [n_outer, ny, nx])."""
+    if weights.shape[-2:] != obj.shape[-2:]:
+        raise ValueError(
+            f"horizontal shape of weights {tuple(weights.shape[-2:])} does not match "
+            f"the field's {tuple(obj.shape[-2:])}"
+        )
+    o_outer, w_outer = tuple(obj.shape[:-2]), tuple(weights.shape[:-2])
+    if w_outer == o_outer:
+        return weights.contiguous(), 1
+    # weights' outer dims are a prefix of the field's: shared by the trailing outer dims
+    if len(w_outer) <= len(o_outer) and o_outer[: len(w_outer)] == w_outer:
+        return weights.contiguous(), max(_prod(o_outer[len(w_outer):]), 1)
+    # anything else: materialise the broadcast (numpy broadcasting rules)
+    expanded = torch.broadcast_to(weights, obj.shape).contiguous()
+    return expanded, 1
+
+
+def _promoted(a: torch.Tensor, b: torch.Tensor) -> torch.dtype:
+    return torch.float64 if torch.float64 in (a.dtype, b.dtype) else torch.float32
+
+
+def weighted_block_average(obj: torch.Tensor, weights: torch.Tensor, factor: int) -> torch.Tensor:
+    """``nansum(obj*w)/nansum(w)`` over factor x factor blocks of the last two dims
+    (vcm.cubedsphere.weighted_block_average, coarsen.py:183-218)."""
+    dev = _require_device(obj, weights)
+    factor = int(factor)
+    if obj.dim() < 2:
+        raise ValueError("field must have at least two (horizontal) dimensions")
+    obj = obj.contiguous()
+    weights, w_repeat = _weights_repeat(obj, weights)
+    ny, nx = int(obj.shape[-2]), int(obj.shape[-1])
+    if factor < 1 or ny % factor or nx % factor:
+        raise ValueError(
+            f"horizontal extents ({ny}, {nx}) are not multiples of the coarsening factor {factor}"
+        )
+    n_outer = _prod(obj.shape[:-2])
+    out = torch.empty(
+        tuple(obj.shape[:-2]) + (ny // factor, nx // factor), dtype=_promoted(obj, weights), device=dev
+    )
+    _lib.call(
+        "fv3hip_weighted_block_average", _ptr(obj), _float_code(obj), _ptr(weights), _float_code(weights),
+        n_outer, ny, nx, w_repeat, factor, _ptr(out), _stream(dev),
+    )
+    return out
+
+
+def edge_weighted_block_average(
+    obj: torch.Tensor, spacing: torch.Tensor, factor: int, edge: str = "x"
+) -> torch.Tensor:
+    """Weighted mean over ``factor`` cells along one horizontal dim, every factor-th line kept
+    along the other (vcm.cubedsphere.edge_weighted_block_average, coarsen.py:221-273).
+    The last two dims are (y, x)."""
+    if edge not in ("x", "y"):
+        raise ValueError(f"'edge' most be either 'x' or 'y'; got {edge}.")
+    dev = _require_device(obj, spacing)
+    factor = int(factor)
+    obj = obj.contiguous()
+    spacing, w_repeat = _weights_repeat(obj, spacing)
+    ny, nx = int(obj.shape[-2]), int(obj.shape[-1])
+    if edge == "x":
+        if nx % factor:
+            raise ValueError(f"x extent {nx} is not a multiple of the coarsening factor {factor}")
+        oshape = (-(-ny // factor), nx // factor)
+    else:
+        if ny % factor:
+            raise ValueError(f"y extent {ny} is not a multiple of the coarsening factor {factor}")
+        oshape = (ny // factor, -(-nx // factor))
+    out = torch.empty(tuple(obj.shape[:-2]) + oshape, dtype=_promoted(obj, spacing), device=dev)
+    _lib.call(
+        "fv3hip_edge_weighted_block_average", _ptr(obj), _float_code(obj), _ptr(spacing),
+        _float_code(spacing), _prod(obj.shape[:-2]), ny, nx, w_repeat, factor, 0 if edge == "x" else 1,
+        _ptr(out), _stream(dev),
+    )
+    return out
+
+
+def block_reduce(
+    x: torch.Tensor,
+    window: Sequence[int],
+    stride: Optional[Sequence[int]] = None,
+    op: str = "sum",
+    nan_policy: str = "skip",
+) -> torch.Tensor:
+    """Windowed reduction over the last two dims: window (by, bx), stride (sy, sx) (default =
+    window).  ops: sum, mean, min, max (NaN-skipping like xarray's coarsen), median (numpy.median),
+    mode (scipy.stats.mode 1.7.3, ``nan_policy`` 'propagate' or 'omit')."""
+    dev = _require_device(x)
+    by, bx = (int(v) for v in window)
+    sy, sx = (by, bx) if stride is None else (int(v) for v in stride)
+    if op not in _OPS:
+        raise ValueError(f"unknown block reduction {op!r}")
+    policy = {"skip": _lib.NAN_SKIP, "propagate": _lib.NAN_PROPAGATE, "omit": _lib.NAN_OMIT}[nan_policy]
+    x = x.contiguous()
+    ny, nx = int(x.shape[-2]), int(x.shape[-1])
+    if ny < by or nx < bx:
+        raise ValueError(f"window ({by}, {bx}) is larger than the field ({ny}, {nx})")
+    nyo, nxo = (ny - by) // sy + 1, (nx - bx) // sx + 1
+    out = torch.empty(tuple(x.shape[:-2]) + (nyo, nxo), dtype=x.dtype, device=dev)
+    _lib.call(
+        "fv3hip_block_reduce", _ptr(x), _code(x), _prod(x.shape[:-2]), ny, nx, by, bx, sy, sx, _OPS[op],
+        policy, _ptr(out), _stream(dev),
+    )
+    return out
+
+
+def block_upsample(x: torch.Tensor, factor: int) -> torch.Tensor:
+    """Repeat each value ``factor`` times along the last two dims; a dim of odd size is treated
+    as staggered and its last point is not repeated (coarsen.py:843-897)."""
+    dev = _require_device(x)
+    factor = int(factor)
+    x = x.contiguous()
+    if x.element_size() not in (4, 8):
+        raise TypeError(f"unsupported dtype {x.dtype}")
+    ny, nx = int(x.shape[-2]), int(x.shape[-1])
+    nyo = (ny - 1) * factor + 1 if ny % 2 == 1 else ny * factor
+    nxo = (nx - 1) * factor + 1 if nx % 2 == 1 else nx * factor
+    out = torch.empty(tuple(x.shape[:-2]) + (nyo, nxo), dtype=x.dtype, device=dev)
+    _lib.call(
+        "fv3hip_block_upsample", _ptr(x), x.element_size(), _prod(x.shape[:-2]), ny, nx, factor, _ptr(out),
+        _stream(dev),
+    )
+    return out
+
+
+def pressure_at_interface(delp: torch.Tensor, toa_pressure: float, z_axis: int) -> torch.Tensor:
+    """``p[0] = toa; p[k+1] = p[k] + delp[k]`` along ``z_axis`` (size nz -> nz + 1), accumulated
+    sequentially in delp's dtype (vertically_dependent.py:41-66)."""
+    dev = _require_device(delp)
+    delp = delp.contiguous()
+    z_axis = z_axis % delp.dim()
+    nz = int(delp.shape[z_axis])
+    n_batch, n_inner = _prod(delp.shape[:z_axis]), _prod(delp.shape[z_axis + 1:])
+    shape = list(delp.shape)
+    shape[z_axis] = nz + 1
+    out = torch.empty(shape, dtype=delp.dtype, device=dev)
+    _lib.call(
+        "fv3hip_pressure_at_interface", _ptr(delp), _float_code(delp), n_batch, nz, n_inner,
+        float(toa_pressure), _ptr(out), _stream(dev),
+    )
+    return out
+
+
+def mask_weights(
+    weights: torch.Tensor, p_coarse: torch.Tensor, p_fine: torch.Tensor, z_axis: int
+) -> torch.Tensor:
+    """``weights where p_coarse[k+1] < p_fine[surface] else 0`` (regridz.py:200-220,
+    extrapolate=False).  ``p_*`` have nz+1 levels along ``z_axis``; ``weights`` has p's shape
+    without the z axis, or without the z axis and any of the dims right before it
+    (e.g. p [tile, z+1, y, x] and weights [tile, y, x])."""
+    dev = _require_device(weights, p_coarse, p_fine)
+    if p_coarse.shape != p_fine.shape or p_coarse.dtype != p_fine.dtype:
+        raise ValueError("p_coarse and p_fine must have the same shape and dtype")
+    p_coarse, p_fine, weights = p_coarse.contiguous(), p_fine.contiguous(), weights.contiguous()
+    z_axis = z_axis % p_fine.dim()
+    nz = int(p_fine.shape[z_axis]) - 1
+    batch_shape, inner_shape = tuple(p_fine.shape[:z_axis]), tuple(p_fine.shape[z_axis + 1:])
+    n_batch, n_inner = _prod(batch_shape), _prod(inner_shape)
+    if tuple(weights.shape) != batch_shape + inner_shape:
+        raise ValueError(
+            f"weights shape {tuple(weights.shape)} must be the pressure shape without its z axis "
+            f"{batch_shape + inner_shape}"
+        )
+    out_shape = batch_shape + (nz,) + inner_shape
+    out = torch.empty(out_shape, dtype=weights.dtype, device=dev)
+    _lib.call(
+        "fv3hip_mask_weights", _ptr(weights), _float_code(weights), _ptr(p_coarse), _ptr(p_fine),
+        _float_code(p_fine), n_batch, nz, n_inner, 1, _ptr(out), _stream(dev),
+    )
+    return out
+
+
+_workspaces = {}
+
+
+def _workspace(dev, nbytes: int) -> torch.Tensor:
+    key = (dev.type, dev.index)
+    ws = _workspaces.get(key)
+    if ws is None or ws.numel() < nbytes:
+        ws = torch.empty(max(nbytes, 1), dtype=torch.uint8, device=dev)
+        _workspaces[key] = ws
+    return ws
+
+
+def mappm(
+    pe1: torch.Tensor,
+    q1: torch.Tensor,
+    pe2: torch.Tensor,
+    iv: int = 1,
+    kord: int = 1,
+    z_axis: int = -1,
+) -> torch.Tensor:
+    """PPM vertical remap of ``q1`` from interface pressures ``pe1`` to ``pe2`` (mappm.f90).
+    ``z_axis`` is the level axis of all three arrays (km+1, km, kn+1 levels); the other dims
+    must match.  ``z_axis=-1`` is the [column, level] layout f2py callers use; any other
+    position is handled in place as the native [.., level, .. columns ..] layout.
+    Returns float32 with kn levels along ``z_axis``."""
+    dev = _require_device(pe1, q1, pe2)
+    if not (pe1.dtype == q1.dtype == pe2.dtype):
+        common = torch.float64 if torch.float64 in (pe1.dtype, q1.dtype, pe2.dtype) else torch.float32
+        pe1, q1, pe2 = pe1.to(common), q1.to(common), pe2.to(common)
+    pe1, q1, pe2 = pe1.contiguous(), q1.contiguous(), pe2.contiguous()
+    nd = q1.dim()
+    z_axis = z_axis % nd
+    km, kn = int(q1.shape[z_axis]), int(pe2.shape[z_axis]) - 1
+    if int(pe1.shape[z_axis]) != km + 1:
+        raise ValueError("f_in must have a vertical dimension one shorter than p_in")
+
+    def others(t):
+        return tuple(t.shape[:z_axis]) + tuple(t.shape[z_axis + 1:])
+
+    if not (others(pe1) == others(q1) == others(pe2)):
+        raise ValueError("All dimensions except vertical must be same size for p_in, f_in and p_out")
+    n_batch, n_inner = _prod(q1.shape[:z_axis]), _prod(q1.shape[z_axis + 1:])
+    if z_axis == nd - 1:
+        layout, nb, ni = _lib.LAYOUT_COL_LEVEL, n_batch, 1
+    else:
+        layout, nb, ni = _lib.LAYOUT_LEVEL_COL, n_batch, n_inner
+    shape = list(q1.shape)
+    shape[z_axis] = kn
+    out = torch.empty(shape, dtype=torch.float32, device=dev)
+    ncol = nb * ni
+    nbytes = int(_lib.load().fv3hip_mappm_workspace_bytes(ncol, km))
+    ws = _workspace(dev, nbytes)
+    _lib.call(
+        "fv3hip_mappm", _ptr(pe1), _ptr(q1), _ptr(pe2), _float_code(q1), _ptr(out), nb, ni, km, kn,
+        int(iv), int(kord), layout, _ptr(ws), ws.numel(), _stream(dev),
+    )
+    return out
+
+
+class HipTimer:
+    """HIP events recorded on torch's current stream (used by bench.py)."""
+
+    def __init__(self):
+        self._h = ctypes.c_void_p()
+        _lib.call("fv3hip_timer_create", ctypes.byref(self._h))
+
+    def start(self, dev=None):
+        _lib.call("fv3hip_timer_start", self._h, _stream(dev))
+
+    def stop(self, dev=None):
+        _lib.call("fv3hip_timer_stop", self._h, _stream(dev))
+
+    def elapsed_ms(self) -> float:
+        ms = ctypes.c_float()
+        _lib.call("fv3hip_timer_elapsed_ms", self._h, ctypes.byref(ms))
+        return float(ms.value)
+
+    def __del__(self):
+        try:
+            _lib.load().fv3hip_timer_destroy(self._h)
+        except Exception:
+            pass
+
+
+def device_info() -> dict:
+    info = _lib.DeviceInfo()
+    _lib.call("fv3hip_device_info", ctypes.byref(info))
+    return {
+        "name": info.name.decode(),
+        "arch": info.arch.decode(),
+        "compute_units": info.compute_units,
+        "wavefront_size": info.wavefront_size,
+        "lds_bytes_per_cu": info.lds_bytes_per_cu,
+        "clock_mhz": info.clock_mhz,
+        "hbm_bytes": int(info.hbm_bytes),
+    }
+
+
+def as_numpy(t: torch.Tensor) -> np.ndarray:
+    return t.detach().cpu().numpy()

@@ -1,0 +1,269 @@
+/*
+ * fv3hip.h -- C ABI of libfv3hip.so, the MI355X (gfx950) implementation of fv3net's
+ * column-wise ML tendency inference and cubed-sphere coarse-graining hot path.
+ *
+ * The reference has no native ABI for this path except the f2py-generated `mappm.mappm`
+ * module; everything else is Python on top of TensorFlow / xarray / numpy.  Each entry point
+ * below therefore cites the reference *Python or Fortran interface* it replaces (paths are
+ * relative to the reference checkout).  INTEGRATION.md shows the ctypes stub a maintainer
+ * of the reference would add for each one.
+ *
+ * Conventions
+ *   - every function returns 0 on success or a negative FV3HIP_E* code; the message for the
+ *     calling thread's last failure is returned by fv3hip_last_error();
+ *   - all data pointers are DEVICE pointers (hipMalloc / torch.cuda tensors), caller-owned,
+ *     never freed or retained by the library beyond the call (model handles copy their
+ *     weights at create time);
+ *   - `stream` is a hipStream_t passed as void* (NULL = the null stream); every call only
+ *     enqueues work on that stream and never synchronises, so calls can be captured in a
+ *     hipGraph;
+ *   - arrays are dense, row-major, "x fastest": horizontal fields are [n_outer][ny][nx].
+ */
+#ifndef FV3HIP_H
+#define FV3HIP_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define FV3HIP_ABI_VERSION 1
+
+/* status codes */
+#define FV3HIP_OK 0
+#define FV3HIP_EINVAL -1      /* bad argument (shape, dtype, factor ...)            */
+#define FV3HIP_EUNSUPPORTED -2 /* valid in the reference but not implemented here    */
+#define FV3HIP_EHIP -3        /* a HIP runtime call failed                           */
+#define FV3HIP_ENOMEM -4
+
+/* element types */
+#define FV3HIP_F32 0
+#define FV3HIP_F64 1
+#define FV3HIP_I32 2
+#define FV3HIP_I64 3
+
+/* block reductions (fv3hip_block_reduce) */
+#define FV3HIP_OP_SUM 0
+#define FV3HIP_OP_MEAN 1
+#define FV3HIP_OP_MIN 2
+#define FV3HIP_OP_MAX 3
+#define FV3HIP_OP_MEDIAN 4
+#define FV3HIP_OP_MODE 5
+
+/* NaN handling for fv3hip_block_reduce */
+#define FV3HIP_NAN_SKIP 0      /* xarray coarsen().sum()/min()/max()/mean() default (skipna) */
+#define FV3HIP_NAN_PROPAGATE 1 /* numpy.median / scipy.stats.mode(nan_policy="propagate")    */
+#define FV3HIP_NAN_OMIT 2      /* scipy.stats.mode(nan_policy="omit")                        */
+
+/* column layouts (fv3hip_mappm, fv3hip_pressure_at_interface) */
+#define FV3HIP_LAYOUT_COL_LEVEL 0 /* [column][level]: level fastest (what f2py callers pass)  */
+#define FV3HIP_LAYOUT_LEVEL_COL 1 /* [batch][level][inner]: column fastest (native [z,y,x])   */
+
+const char *fv3hip_last_error(void);
+int fv3hip_abi_version(void);
+
+/* Select the device for the calling thread and cache its properties. */
+int fv3hip_init(int device);
+
+typedef struct {
+    char name[128];
+    char arch[64];
+    int compute_units;
+    int wavefront_size;
+    int lds_bytes_per_cu;
+    int clock_mhz;
+    size_t hbm_bytes;
+} fv3hip_device_info_t;
+int fv3hip_device_info(fv3hip_device_info_t *out);
+
+/* ------------------------------------------------------------------------------------------
+ * Horizontal coarse-graining
+ * ------------------------------------------------------------------------------------------ */
+
+/*
+ * Replaces vcm.cubedsphere.weighted_block_average
+ * (external/vcm/vcm/cubedsphere/coarsen.py:183-218):
+ *     out = nansum_block(obj * w) / nansum_block(w)      over factor x factor blocks
+ * obj: [n_outer][ny][nx]; weights: [n_outer / w_repeat][ny][nx], each weight slice shared by
+ * w_repeat consecutive outer slices (w_repeat = 1: same shape as obj; w_repeat = nz: 2-D
+ * area weights of a [tile][z][y][x] field).  out: [n_outer][ny/factor][nx/factor] in the
+ * promoted type (F64 if either input is F64, else F32).  NaN products/weights are skipped as
+ * xarray's skipna sums do; an all-zero denominator gives NaN (0/0) as in the reference.
+ */
+int fv3hip_weighted_block_average(const void *obj, int obj_dtype, const void *weights,
+                                  int w_dtype, int64_t n_outer, int ny, int nx,
+                                  int64_t w_repeat, int factor, void *out, void *stream);
+
+/*
+ * Replaces vcm.cubedsphere.edge_weighted_block_average
+ * (external/vcm/vcm/cubedsphere/coarsen.py:221-273).  edge = 0 ('x'): weighted mean over
+ * `factor` cells along x, every factor-th row kept along y (out [n_outer][ceil(ny/f)][nx/f]);
+ * edge = 1 ('y'): the transpose of that (out [n_outer][ny/f][ceil(nx/f)]).
+ */
+int fv3hip_edge_weighted_block_average(const void *obj, int obj_dtype, const void *spacing,
+                                       int w_dtype, int64_t n_outer, int ny, int nx,
+                                       int64_t w_repeat, int factor, int edge, void *out,
+                                       void *stream);
+
+/*
+ * Replaces vcm.cubedsphere.block_coarsen / block_median / _block_mode / block_edge_coarsen
+ * (external/vcm/vcm/cubedsphere/coarsen.py:795-840, 557-588, 750-786, 629-683) and the
+ * vendored block_reduce they sit on (external/vcm/vcm/cubedsphere/_skimage.py:125-202):
+ *     out[o][Y][X] = op over in[o][Y*sy .. Y*sy+by-1][X*sx .. X*sx+bx-1]
+ * with ny_out = (ny - by)/sy + 1, nx_out = (nx - bx)/sx + 1.  Full blocks: by=bx=sy=sx=f;
+ * edge 'x' coarsening: by=1, bx=f, sy=sx=f.  The output has the input's dtype except MEAN /
+ * MEDIAN of integers, which is not supported (the reference only applies them to floats).
+ */
+int fv3hip_block_reduce(const void *in, int dtype, int64_t n_outer, int ny, int nx, int by,
+                        int bx, int sy, int sx, int op, int nan_policy, void *out,
+                        void *stream);
+
+/*
+ * Replaces vcm.cubedsphere.block_upsample / block_upsample_like
+ * (external/vcm/vcm/cubedsphere/coarsen.py:869-938): out[o][y][x] = in[o][y/f][x/f], where a
+ * coarse dimension of odd size is a staggered one whose last point is not repeated
+ * (ny_out = (ny_in-1)*f+1) and an even one is repeated uniformly (ny_out = ny_in*f).
+ * elem_size is 4 or 8 bytes.
+ */
+int fv3hip_block_upsample(const void *in, int elem_size, int64_t n_outer, int ny_in, int nx_in,
+                          int factor, void *out, void *stream);
+
+/* ------------------------------------------------------------------------------------------
+ * Vertical: interface pressures and the PPM remap
+ * ------------------------------------------------------------------------------------------ */
+
+/*
+ * Replaces vcm.pressure_at_interface
+ * (external/vcm/vcm/calc/thermo/vertically_dependent.py:41-66): p[0] = toa,
+ * p[k+1] = p[k] + delp[k], accumulated sequentially in the array's own dtype (as
+ * numpy.cumsum does).  delp: [n_batch][nz][n_inner] -> out: [n_batch][nz+1][n_inner]
+ * (LEVEL_COL) or [ncol][nz] -> [ncol][nz+1] (COL_LEVEL, n_batch = ncol, n_inner = 1).
+ */
+int fv3hip_pressure_at_interface(const void *delp, int dtype, int64_t n_batch, int nz,
+                                 int64_t n_inner, double toa_pressure, void *out, void *stream);
+
+/*
+ * Replaces vcm.cubedsphere.regridz._mask_weights
+ * (external/vcm/vcm/cubedsphere/regridz.py:200-220), extrapolate=False branch:
+ *     out[b][k][c] = weights[b / w_repeat][c]  if p_coarse[b][k+1][c] < p_fine[b][nz][c] else 0
+ * p_* are [n_batch][nz+1][n_inner] in p_dtype; weights [n_batch / w_repeat][n_inner] and out
+ * [n_batch][nz][n_inner] in w_dtype.
+ */
+int fv3hip_mask_weights(const void *weights, int w_dtype, const void *p_coarse,
+                        const void *p_fine, int p_dtype, int64_t n_batch, int nz,
+                        int64_t n_inner, int64_t w_repeat, void *out, void *stream);
+
+/*
+ * Replaces the f2py module function mappm.mappm(p_in, f_in, p_out, i1, i2, iv, kord, ptop)
+ * (external/mappm/mappm/mappm.f90:10-126 with ppm_profile :614-851 and ppm_limiters
+ * :854-931; caller external/vcm/vcm/cubedsphere/regridz.py:304-338).  Single precision
+ * inside, as in the Fortran (default REAL); inputs may be F32 or F64 (F64 is rounded to F32
+ * on load, which is what f2py's argument conversion does).  q2 is always F32.
+ *   COL_LEVEL: pe1 [ncol][km+1], q1 [ncol][km], pe2 [ncol][kn+1], q2 [ncol][kn]
+ *              (n_batch = ncol, n_inner = 1)
+ *   LEVEL_COL: pe1 [n_batch][km+1][n_inner], ... ; ncol = n_batch * n_inner
+ * kord <= 7 only (ppm_profile); kord > 7 (cs_profile) returns FV3HIP_EUNSUPPORTED.
+ * `workspace` must hold fv3hip_mappm_workspace_bytes(...) bytes of device memory.
+ */
+size_t fv3hip_mappm_workspace_bytes(int64_t ncol, int km);
+int fv3hip_mappm(const void *pe1, const void *q1, const void *pe2, int in_dtype, float *q2,
+                 int64_t n_batch, int64_t n_inner, int km, int kn, int iv, int kord, int layout,
+                 void *workspace, size_t workspace_bytes, void *stream);
+
+/* ------------------------------------------------------------------------------------------
+ * Column MLP (fv3fit dense model / Zhao-Carr microphysics emulator)
+ * ------------------------------------------------------------------------------------------ */
+
+#define FV3HIP_TRANSFORM_NONE 0
+#define FV3HIP_TRANSFORM_LOG 1 /* log(max(x, eps)) : fv3fit/emulation/transforms/transforms.py:111-129 */
+
+#define FV3HIP_ACT_LINEAR 0
+#define FV3HIP_ACT_RELU 1
+
+/*
+ * Description of the fused predict graph of
+ *   fv3fit.keras._models.dense.build_model (external/fv3fit/fv3fit/keras/_models/dense.py:239-310)
+ *   fv3fit.emulation MicrophysicsConfig.build with the "dense" architecture
+ *     (external/fv3fit/fv3fit/emulation/models/microphysics.py:123-139,
+ *      layers/architecture.py:27-50,228-282,304-343, layers/fields.py:33-66)
+ * i.e.  x_i -> (optional log) -> clip slice -> (x - center) / scale -> concat ->
+ *       [Dense + activation] * n_hidden -> Dense per output -> y * out_scale + out_center ->
+ *       limit to [out_min, out_max] -> multiply by 0/1 level mask
+ *       -> optional residual outputs  after = before + difference.
+ * All arrays are HOST pointers, copied (and re-laid-out for the MFMA kernel) at create time.
+ */
+typedef struct {
+    /* inputs */
+    int n_sources;           /* number of distinct arrays the caller passes to predict()     */
+    int n_inputs;            /* network input variables, concatenated in this order          */
+    const int *in_source;    /* [n_inputs] which source array feeds input i                  */
+    const int *in_feat_start;/* [n_inputs] first feature (level) of the source that is used  */
+    const int *in_nfeat;     /* [n_inputs] number of features used (K = sum)                 */
+    const int *in_transform; /* [n_inputs] FV3HIP_TRANSFORM_*                                */
+    const float *in_eps;     /* [n_inputs] epsilon of the log transform                      */
+    const float *in_center;  /* [K] subtracted                                               */
+    const float *in_scale;   /* [K] divided by (the reference's scale + epsilon, in f32)     */
+    /* hidden layers: n_hidden dense layers of `width` units, Keras kernels [in][out]        */
+    int n_hidden;
+    int width;
+    int hidden_activation;   /* FV3HIP_ACT_* */
+    const float *const *hidden_kernels; /* [n_hidden] -> [in][width] row-major               */
+    const float *const *hidden_biases;  /* [n_hidden] -> [width]                             */
+    /* output heads, concatenated: F = sum(out_nfeat) */
+    int n_outputs;
+    const int *out_nfeat;    /* [n_outputs] */
+    const float *out_kernel; /* [width (or K if n_hidden == 0)][F] row-major                 */
+    const float *out_bias;   /* [F] */
+    const float *out_scale;  /* [F] y = yhat * scale + center                                */
+    const float *out_center; /* [F] */
+    const float *out_min;    /* [F] or NULL; -inf = no lower limit                           */
+    const float *out_max;    /* [F] or NULL; +inf = no upper limit                           */
+    const float *out_mask;   /* [F] of 0/1 or NULL (ClipConfig.zero_mask_clipped_layer)      */
+    /* residual outputs: derived d = source[res_source[d]] + output[res_output[d]]           */
+    int n_residual;
+    const int *res_source;   /* [n_residual] */
+    const int *res_output;   /* [n_residual] */
+} fv3hip_mlp_desc_t;
+
+typedef struct fv3hip_mlp *fv3hip_mlp_t;
+
+int fv3hip_mlp_create(const fv3hip_mlp_desc_t *desc, fv3hip_mlp_t *out);
+int fv3hip_mlp_destroy(fv3hip_mlp_t model);
+
+/*
+ * Replaces the Keras call inside fv3fit._shared.xr_prediction._predict
+ * (external/fv3fit/fv3fit/_shared/xr_prediction.py:75-108: `model(inputs)`) and inside
+ * emulation.models.ModelWithClassifier.__call__ (external/emulation/emulation/models.py:37-53:
+ * `model.predict(inputs, batch_size=...)`).
+ *   sources[s]: device pointer to source array s, dtype src_dtype[s] (F32/F64), element
+ *               (feature f, sample n) at  f * src_feat_stride[s] + n * src_sample_stride[s]
+ *               (so both [feature][sample] and [sample][feature] are accepted without a copy);
+ *   outputs[j]: n_outputs + n_residual device pointers, dtype out_dtype (F32 or F64),
+ *               element (f, n) at f * out_feat_stride[j] + n * out_sample_stride[j].
+ */
+int fv3hip_mlp_predict(fv3hip_mlp_t model, const void *const *sources, const int *src_dtype,
+                       const int64_t *src_feat_stride, const int64_t *src_sample_stride,
+                       int64_t n_samples, void *const *outputs, int out_dtype,
+                       const int64_t *out_feat_stride, const int64_t *out_sample_stride,
+                       void *stream);
+
+/* FLOPs of the dense contraction per sample (2 * sum(in * out)), for roofline accounting. */
+int64_t fv3hip_mlp_flops_per_sample(fv3hip_mlp_t model);
+
+/* ------------------------------------------------------------------------------------------
+ * Timing helper: HIP events on the caller's stream (bench.py measures kernels with these
+ * because torch.cuda.Event only sees torch's current stream).
+ * ------------------------------------------------------------------------------------------ */
+typedef struct fv3hip_timer *fv3hip_timer_t;
+int fv3hip_timer_create(fv3hip_timer_t *out);
+int fv3hip_timer_start(fv3hip_timer_t t, void *stream);
+int fv3hip_timer_stop(fv3hip_timer_t t, void *stream);
+int fv3hip_timer_elapsed_ms(fv3hip_timer_t t, float *ms); /* synchronises on the stop event */
+int fv3hip_timer_destroy(fv3hip_timer_t t);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* FV3HIP_H */

@@ -1,0 +1,103 @@
+"""ORACLE -- TEST INFRASTRUCTURE ONLY.
+
+numpy restatement of the column-MLP predict graph.  Arrays are [sample, feature] as in Keras.
+
+Follows (paths relative to the reference checkout):
+  external/fv3fit/fv3fit/keras/_models/dense.py:239-310            build_model (predict_model)
+  external/fv3fit/fv3fit/keras/_models/shared/utils.py:34-105      standard_normalize / denormalize
+  external/fv3fit/fv3fit/emulation/layers/normalization.py:21-49,117-164  NormLayer, fit of mean/std
+  external/fv3fit/fv3fit/keras/_models/shared/dense_network.py:59-81  Dense(relu) * (depth-1)
+  external/fv3fit/fv3fit/keras/_models/shared/clip.py:21-62, output_limit.py:29-48
+  external/fv3fit/fv3fit/emulation/layers/fields.py:33-66, architecture.py:27-50,262-269,332-343
+  external/fv3fit/fv3fit/emulation/transforms/transforms.py:17-58 (Difference), 111-129 (LogTransform)
+
+The dense contraction itself is TensorFlow 2.8 / Keras 2.8 (constraints.txt:143,282), which is
+not in the reference tree and not installed: its published semantics are restated
+(``Dense``: ``activation(x @ kernel + bias)``, kernel [in, out]).  PARITY UNPINNED for the
+contraction: no reference test holds a TensorFlow-free golden output on fixed weights.  The
+normalisation pieces ARE pinned by the reference's regtest outputs (tests/golden/).
+``dtype=np.float64`` gives the high-precision truth the fp32 paths are measured against.
+"""
+import numpy as np
+
+
+def fit_mean_per_feature(sample):
+    return np.asarray(sample).mean(axis=tuple(range(np.ndim(sample) - 1))).astype(np.float32)
+
+
+def fit_std_per_feature(sample):
+    return np.asarray(sample).std(axis=tuple(range(np.ndim(sample) - 1))).astype(np.float32)
+
+
+def fit_std_all(sample):
+    """StdDevMethod.all: one std over all features, centred per feature."""
+    s = np.asarray(sample)
+    mean = s.mean(axis=tuple(range(s.ndim - 1))).astype(np.float32)
+    return np.sqrt(np.mean((s - mean) ** 2)).astype(np.float32)
+
+
+def norm_forward(x, center, scale, epsilon=None):
+    x = np.asarray(x)
+    fs = np.float32(scale) if epsilon is None else (np.asarray(scale, np.float32) + np.float32(epsilon))
+    return (x - np.asarray(center, x.dtype)) / np.asarray(fs, x.dtype)
+
+
+def norm_backward(y, center, scale):
+    y = np.asarray(y)
+    return y * np.asarray(scale, y.dtype) + np.asarray(center, y.dtype)
+
+
+def limit_output(y, vmin=None, vmax=None):
+    """OutputLimit._limit_activation."""
+    x = y
+    if vmin is not None:
+        x = np.where(y < vmin, np.asarray(vmin, y.dtype), x)
+        if vmax is not None:
+            x = np.where((y >= vmin) & (y < vmax), y, x)
+    if vmax is not None:
+        x = np.where(y >= vmax, np.asarray(vmax, y.dtype), x)
+    return x
+
+
+def forward(spec, sources, dtype=np.float32):
+    """Evaluate an ``fv3net_amd.mlp.MlpSpec``-shaped description.
+
+    ``spec`` is duck-typed (attributes inputs / hidden_kernels / hidden_biases / outputs /
+    out_kernel / out_bias / residuals), so that the oracle does not import the product.
+    ``sources``: name -> [sample, feature] (or [sample]) arrays.  Returns name -> [sample, feature].
+    """
+    cols = []
+    src = {}
+    for name, arr in sources.items():
+        a = np.asarray(arr)
+        if a.ndim == 1:
+            a = a[:, None]
+        # Keras casts float64 inputs to the layer dtype (float32) first
+        src[name] = a.astype(np.float32).astype(dtype)
+    for i in spec.inputs:
+        x = src[i.source][:, i.start:i.start + i.nfeat]
+        if i.transform == "log":
+            x = np.log(np.maximum(x, np.asarray(i.eps, np.float32).astype(dtype)))
+        center = np.zeros(i.nfeat, np.float32) if i.center is None else np.broadcast_to(np.asarray(i.center, np.float32), (i.nfeat,))
+        scale = np.ones(i.nfeat, np.float32) if i.scale is None else np.broadcast_to(np.asarray(i.scale, np.float32), (i.nfeat,))
+        cols.append((x - center.astype(dtype)) / scale.astype(dtype))
+    h = np.concatenate(cols, axis=1)
+    for kern, b in zip(spec.hidden_kernels, spec.hidden_biases):
+        h = h @ np.asarray(kern, np.float32).astype(dtype) + np.asarray(b, np.float32).astype(dtype)
+        h = np.maximum(h, 0)
+    yhat = h @ np.asarray(spec.out_kernel, np.float32).astype(dtype) + np.asarray(spec.out_bias, np.float32).astype(dtype)
+    out = {}
+    f0 = 0
+    for o in spec.outputs:
+        y = yhat[:, f0:f0 + o.nfeat]
+        f0 += o.nfeat
+        scale = np.ones(o.nfeat, np.float32) if o.scale is None else np.broadcast_to(np.asarray(o.scale, np.float32), (o.nfeat,))
+        center = np.zeros(o.nfeat, np.float32) if o.center is None else np.broadcast_to(np.asarray(o.center, np.float32), (o.nfeat,))
+        y = y * scale.astype(dtype) + center.astype(dtype)
+        y = limit_output(y, o.min, o.max)
+        if o.mask is not None:
+            y = y * np.asarray(o.mask, np.float32).astype(dtype)
+        out[o.name] = y
+    for r in getattr(spec, "residuals", []):
+        out[r.name] = src[r.source][:, : out[r.output].shape[1]] + out[r.output]
+    return out

@@ -1,0 +1,215 @@
+"""Parity of the HIP coarsening kernels (through the C ABI) with the numpy oracle.
+
+Tolerances: block sums are accumulated in a different order than numpy's, so values agree to
+rounding of the accumulation: |gpu - oracle| <= 1e-5 * sum|obj*w| / sum(w) for float32
+(1e-13 for float64).  NaN patterns and integer results must match exactly.
+"""
+import numpy as np
+import pytest
+import torch
+
+from oracle import coarsen_np as onp
+
+pytestmark = pytest.mark.gpu
+
+
+def _dev(a, device):
+    return torch.from_numpy(np.ascontiguousarray(a)).to(device)
+
+
+def _check_wavg(res, obj, w, factor, tol):
+    ref = onp.weighted_block_average(obj, w, factor)
+    scale = onp._nansum_blocks(np.abs(obj * w), factor, factor) / np.abs(onp._nansum_blocks(np.broadcast_to(w, obj.shape) * 1.0, factor, factor))
+    assert res.shape == ref.shape
+    assert res.dtype == ref.dtype
+    assert np.array_equal(np.isnan(res), np.isnan(ref))
+    ok = ~np.isnan(ref)
+    err = np.abs(res[ok] - ref[ok])
+    assert np.all(err <= tol * np.maximum(scale[ok], 1e-30)), err.max()
+
+
+@pytest.mark.parametrize("factor", [1, 2, 4, 8, 16, 32])
+@pytest.mark.parametrize("odt,wdt", [(np.float32, np.float32), (np.float64, np.float64), (np.float64, np.float32), (np.float32, np.float64)])
+def test_weighted_block_average_2d_weights(device, factor, odt, wdt):
+    from fv3net_amd import ops
+
+    rng = np.random.default_rng(factor)
+    n = 64 if factor <= 16 else 128
+    obj = rng.uniform(-1000, 1000, (3, 5, n, n)).astype(odt)
+    w = rng.uniform(0.5, 1, (3, n, n)).astype(wdt)
+    res = ops.as_numpy(ops.weighted_block_average(_dev(obj, device), _dev(w, device), factor))
+    # a float32 operand caps the accuracy at float32 rounding of its own sums
+    tol = 1e-13 if (odt == np.float64 and wdt == np.float64) else 1e-5
+    _check_wavg(res, obj, w[:, None], factor, tol)
+
+
+@pytest.mark.parametrize("shape,factor", [((2, 7, 6, 10), 2), ((1, 3, 9, 6), 3), ((4, 12, 20), 4), ((2, 2, 48, 48), 8), ((24, 40), 8)])
+def test_weighted_block_average_3d_weights_and_odd_shapes(device, shape, factor):
+    from fv3net_amd import ops
+
+    rng = np.random.default_rng(1)
+    obj = rng.uniform(-1000, 1000, shape).astype(np.float32)
+    w = rng.uniform(3, 5, shape).astype(np.float32)
+    res = ops.as_numpy(ops.weighted_block_average(_dev(obj, device), _dev(w, device), factor))
+    _check_wavg(res, obj, w, factor, 1e-5)
+
+
+def test_weighted_block_average_nan_and_zero_weights(device):
+    from fv3net_amd import ops
+
+    rng = np.random.default_rng(2)
+    obj = rng.uniform(-10, 10, (2, 3, 16, 16)).astype(np.float32)
+    w = rng.uniform(0.5, 1, (2, 3, 16, 16)).astype(np.float32)
+    obj[0, 0, :2, :2] = np.nan          # fully-NaN block: numerator 0
+    obj[0, 1, 3, 5] = np.nan            # partially NaN block
+    w[1, 0, 4:8, 4:8] = 0.0             # zero denominator: 0/0 = NaN
+    w[1, 1, 8, 8] = np.nan              # NaN weight is skipped in both sums
+    for f in (2, 4):
+        res = ops.as_numpy(ops.weighted_block_average(_dev(obj, device), _dev(w, device), f))
+        ref = onp.weighted_block_average(obj, w, f)
+        assert np.array_equal(np.isnan(res), np.isnan(ref))
+        np.testing.assert_allclose(res, ref, rtol=2e-6, atol=1e-5)
+
+
+def test_weighted_block_average_reference_known_answer(device):
+    # external/vcm/tests/test_cubedsphere.py:206-237
+    from fv3net_amd import ops
+
+    data = np.array([[2.0, 6.0], [6.0, 2.0]])
+    weights = np.array([[6.0, 2.0], [2.0, 6.0]])
+    res = ops.as_numpy(ops.weighted_block_average(_dev(data, device), _dev(weights, device), 2))
+    assert res.dtype == np.float64
+    np.testing.assert_array_equal(res, np.array([[3.0]]))
+
+
+def test_weighted_block_average_rejects_bad_factor(device):
+    from fv3net_amd import ops
+
+    x = torch.zeros(2, 6, 6, device=device)
+    with pytest.raises(ValueError):
+        ops.weighted_block_average(x, x, 4)
+
+
+@pytest.mark.parametrize("edge", ["x", "y"])
+@pytest.mark.parametrize("dt", [np.float32, np.float64])
+def test_edge_weighted_block_average(device, edge, dt):
+    from fv3net_amd import ops
+
+    rng = np.random.default_rng(3)
+    f = 4
+    shape = (2, 3, 4 * f + 1, 5 * f) if edge == "x" else (2, 3, 4 * f, 5 * f + 1)
+    obj = rng.uniform(-50, 50, shape).astype(dt)
+    sp = rng.uniform(0.5, 1, (2,) + shape[-2:]).astype(dt)
+    res = ops.as_numpy(ops.edge_weighted_block_average(_dev(obj, device), _dev(sp, device), f, edge))
+    ref = onp.edge_weighted_block_average(obj, sp[:, None], f, edge)
+    assert res.shape == ref.shape and res.dtype == ref.dtype
+    np.testing.assert_allclose(res, ref, rtol=1e-5 if dt == np.float32 else 1e-13)
+
+
+def test_edge_weighted_reference_known_answers(device):
+    # external/vcm/tests/test_cubedsphere.py:240-259, arrays given as [x_dim, y_dim]
+    from fv3net_amd import ops
+
+    data = np.array([[2, 6, 2], [6, 2, 6]], dtype=np.float64)  # dims (x, y)
+    spacing = np.array([[6, 2, 6], [2, 6, 2]], dtype=np.float64)
+    res = ops.as_numpy(ops.edge_weighted_block_average(_dev(data.T, device), _dev(spacing.T, device), 2, "x"))
+    np.testing.assert_array_equal(res.T, np.array([[3.0, 3.0]]))
+    data = np.array([[2, 6], [6, 2], [2, 6]], dtype=np.float64)
+    spacing = np.array([[6, 2], [2, 6], [6, 2]], dtype=np.float64)
+    res = ops.as_numpy(ops.edge_weighted_block_average(_dev(data.T, device), _dev(spacing.T, device), 2, "y"))
+    np.testing.assert_array_equal(res.T, np.array([[3.0], [3.0]]))
+
+
+@pytest.mark.parametrize("method", ["sum", "mean", "min", "max", "median"])
+@pytest.mark.parametrize("dt", [np.float32, np.float64])
+def test_block_coarsen_float(device, method, dt):
+    from fv3net_amd import ops
+
+    rng = np.random.default_rng(4)
+    a = rng.integers(-20, 20, (3, 12, 8)).astype(dt)  # small integers: sums are exact
+    if method != "median":
+        a[0, 0, 0] = np.nan
+        a[1, :4, :4] = np.nan
+    else:
+        a[0, 0, 0] = np.nan
+    res = ops.as_numpy(ops.block_reduce(_dev(a, device), (4, 4), op=method))
+    ref = onp.block_coarsen(a, 4, method)
+    np.testing.assert_array_equal(res, ref)
+
+
+def test_block_reduce_matches_reference_regtest_hash_inputs(device):
+    # _xarray_block_reduce_dataarray regtest (test_cubedsphere.py:262-290): arange(32) as
+    # [x=4, y=4, z=2] float32, 2x2 blocks over (x, y), mean and median.
+    from fv3net_amd import ops
+
+    data = np.arange(32).reshape(4, 4, 2).astype(np.float32)
+    zxy = np.moveaxis(data, -1, 0)  # [z, x, y]: horizontal dims last
+    for method, fn in (("mean", np.mean), ("median", np.median)):
+        res = ops.as_numpy(ops.block_reduce(_dev(zxy, device), (2, 2), op=method))
+        ref = fn(data.reshape(2, 2, 2, 2, 2), axis=(1, 3))  # [X, Y, z]
+        np.testing.assert_array_equal(np.moveaxis(res, 0, -1), ref)
+
+
+@pytest.mark.parametrize("dt", [np.int32, np.int64])
+def test_block_coarsen_int_and_edge(device, dt):
+    from fv3net_amd import ops
+
+    # external/vcm/tests/test_cubedsphere.py:386-419 (arrays given as [x_dim, y_dim])
+    data = np.array([[2, 6, 2], [6, 2, 6]], dtype=dt).T.copy()  # -> [y, x]
+    res = ops.as_numpy(ops.block_reduce(_dev(data, device), (1, 2), (2, 2), op="sum"))
+    np.testing.assert_array_equal(res.T, np.array([[8, 8]]))
+    res = ops.as_numpy(ops.block_reduce(_dev(data, device), (1, 2), (2, 2), op="min"))
+    np.testing.assert_array_equal(res.T, np.array([[2, 2]]))
+    data = np.array([[2, 6], [6, 2], [2, 6]], dtype=dt).T.copy()
+    res = ops.as_numpy(ops.block_reduce(_dev(data, device), (2, 1), (2, 2), op="sum"))
+    np.testing.assert_array_equal(res.T, np.array([[8], [8]]))
+
+
+@pytest.mark.parametrize("policy", ["propagate", "omit"])
+def test_block_mode(device, policy):
+    from fv3net_amd import ops
+
+    # external/vcm/tests/test_cubedsphere.py:731-769
+    data = np.array(
+        [[0.0, 0.0, 1.0, 1.0], [0.0, 0.0, 1.0, 1.0], [1.0, 1.0, 0.0, 0.0], [1.0, 1.0, 0.0, np.nan]]
+    )
+    res = ops.as_numpy(ops.block_reduce(_dev(data, device), (2, 2), op="mode", nan_policy=policy))
+    np.testing.assert_array_equal(res, np.array([[0.0, 1.0], [1.0, 0.0]]))
+    rng = np.random.default_rng(5)
+    a = rng.integers(0, 4, (2, 16, 24)).astype(np.float32)  # categorical field, many ties
+    a[rng.random(a.shape) < 0.1] = np.nan
+    res = ops.as_numpy(ops.block_reduce(_dev(a, device), (4, 4), op="mode", nan_policy=policy))
+    np.testing.assert_array_equal(res, onp.block_mode(a, 4, policy))
+
+
+@pytest.mark.parametrize("shape", [(2, 2), (2, 3), (3, 3), (5, 4, 7)])
+@pytest.mark.parametrize("dt", [np.float32, np.float64, np.int32, np.int64])
+def test_block_upsample(device, shape, dt):
+    from fv3net_amd import ops
+
+    a = np.arange(np.prod(shape)).reshape(shape).astype(dt)
+    for f in (1, 2, 3):
+        res = ops.as_numpy(ops.block_upsample(_dev(a, device), f))
+        np.testing.assert_array_equal(res, onp.block_upsample(a, f))
+
+
+def test_full_size_c384_properties(device):
+    """C384 -> C48 at full size, checked through size-independent properties: a constant field
+    averages to itself, the operator is linear in the field, and sum(w * mean) over the coarse
+    grid equals sum(w * field) over the fine grid."""
+    from fv3net_amd import ops
+
+    g = torch.Generator(device=device).manual_seed(0)
+    obj = (torch.rand((6, 79, 384, 384), device=device, generator=g) * 2000 - 1000)
+    obj2 = (torch.rand((6, 79, 384, 384), device=device, generator=g) * 2000 - 1000)
+    area = torch.rand((6, 384, 384), device=device, generator=g) * 0.5 + 0.5
+    f = 8
+    const = ops.weighted_block_average(torch.full_like(obj, 3.25), area, f)
+    assert torch.allclose(const, torch.full_like(const, 3.25), rtol=1e-6, atol=0)
+    a, b = ops.weighted_block_average(obj, area, f), ops.weighted_block_average(obj2, area, f)
+    ab = ops.weighted_block_average(obj + 2 * obj2, area, f)
+    assert torch.allclose(ab, a + 2 * b, rtol=0, atol=2e-3)
+    wsum = ops.block_reduce(area, (f, f), op="sum")
+    lhs = (a.double() * wsum[:, None].double()).sum(dim=(-1, -2))
+    rhs = (obj.double() * area[:, None].double()).sum(dim=(-1, -2))
+    assert torch.allclose(lhs, rhs, rtol=1e-5, atol=1.0)

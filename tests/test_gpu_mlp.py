@@ -1,0 +1,210 @@
+"""Parity of the fused MFMA MLP kernel (through the C ABI) with the numpy oracle.
+
+The contraction is fp32 on the matrix cores (exact fp32 products, fp32 accumulation in k
+order).  Truth is the oracle evaluated in float64; the bar is the north star's 1e-5 relative:
+    max |gpu - truth| <= 1e-5 * max(|truth|)   per output variable
+and the GPU must be no less accurate than the reference-style float32 CPU evaluation by more
+than a small factor.  Zero-masked levels must be exactly 0.
+"""
+import numpy as np
+import pytest
+import torch
+
+from oracle import mlp_np
+
+pytestmark = pytest.mark.gpu
+
+
+def _random_spec(rng, in_feats, width, n_hidden, out_feats, log_inputs=(), residual=None, limits=None, masks=None):
+    from fv3net_amd.mlp import InputSpec, MlpSpec, OutputSpec, ResidualSpec
+
+    inputs = []
+    for name, (src, nf, start) in in_feats.items():
+        inputs.append(
+            InputSpec(
+                source=src, nfeat=nf, start=start, transform="log" if name in log_inputs else "none",
+                eps=1e-8 if name in log_inputs else 0.0,
+                center=rng.normal(0, 1, nf).astype(np.float32), scale=rng.uniform(0.5, 2, nf).astype(np.float32),
+            )
+        )
+    K = sum(i.nfeat for i in inputs)
+    hk, hb = [], []
+    fan = K
+    for _ in range(n_hidden):
+        hk.append((rng.normal(0, 1, (fan, width)) / np.sqrt(fan)).astype(np.float32))
+        hb.append(rng.normal(0, 0.1, width).astype(np.float32))
+        fan = width
+    outputs = []
+    for name, nf in out_feats.items():
+        lim = (limits or {}).get(name, (None, None))
+        outputs.append(
+            OutputSpec(name=name, nfeat=nf, scale=rng.uniform(0.5, 2, nf).astype(np.float32),
+                       center=rng.normal(0, 1, nf).astype(np.float32), min=lim[0], max=lim[1],
+                       mask=(masks or {}).get(name))
+        )
+    F = sum(o.nfeat for o in outputs)
+    residuals = [ResidualSpec(name=n, source=s, output=o) for n, (s, o) in (residual or {}).items()]
+    return MlpSpec(inputs=inputs, hidden_kernels=hk, hidden_biases=hb, outputs=outputs,
+                   out_kernel=(rng.normal(0, 1, (width, F)) / np.sqrt(width)).astype(np.float32),
+                   out_bias=rng.normal(0, 0.1, F).astype(np.float32), residuals=residuals)
+
+
+def _check(spec, sources_sf, device, layout, src_dtype=np.float32, out_dtype=torch.float32):
+    """sources_sf: name -> [sample, feature] numpy arrays."""
+    from fv3net_amd.mlp import MlpModel
+
+    model = MlpModel(spec, device=device)
+    dev_src = {}
+    for k, v in sources_sf.items():
+        a = v.astype(src_dtype)
+        a = a if layout == "sample_feature" else np.ascontiguousarray(a.T)
+        dev_src[k] = torch.from_numpy(np.ascontiguousarray(a)).to(device)
+    out = model.predict(dev_src, layout=layout, out_dtype=out_dtype)
+    truth = mlp_np.forward(spec, {k: v.astype(src_dtype) for k, v in sources_sf.items()}, dtype=np.float64)
+    cpu32 = mlp_np.forward(spec, {k: v.astype(src_dtype) for k, v in sources_sf.items()}, dtype=np.float32)
+    assert set(out) == set(truth)
+    for name in truth:
+        got = out[name].cpu().numpy()
+        got = got if layout == "sample_feature" else got.T
+        assert got.shape == truth[name].shape, (name, got.shape, truth[name].shape)
+        scale = np.max(np.abs(truth[name]))
+        err = np.max(np.abs(got - truth[name]))
+        err32 = np.max(np.abs(cpu32[name] - truth[name]))
+        assert err <= 1e-5 * scale, (name, err, scale)
+        assert err <= 4 * err32 + 1e-7 * scale, (name, err, err32)
+    return out, truth
+
+
+@pytest.mark.parametrize("layout", ["feature_sample", "sample_feature"])
+@pytest.mark.parametrize("width,n_hidden", [(8, 2), (12, 1), (40, 2), (100, 3), (256, 2)])
+def test_dense_model_shapes(device, layout, width, n_hidden):
+    """fv3fit DenseModel-like: T, q (79 levels) + cos_zenith (1) -> dQ1, dQ2 (79 each)."""
+    rng = np.random.default_rng(width)
+    n = 1000  # not a multiple of the 128-sample tile
+    spec = _random_spec(
+        rng, {"T": ("T", 79, 0), "q": ("q", 79, 0), "cosz": ("cosz", 1, 0)}, width, n_hidden,
+        {"dQ1": 79, "dQ2": 79},
+    )
+    src = {"T": rng.uniform(200, 300, (n, 79)) / 100, "q": rng.uniform(0, 0.02, (n, 79)) * 50,
+           "cosz": rng.uniform(0, 1, (n, 1))}
+    _check(spec, src, device, layout)
+
+
+def test_zhao_carr_emulator_shape(device):
+    """K = 711 (9 x 79, three of them log-transformed views of raw fields), 2 x 256 hidden,
+    396 outputs (1 + 5 x 79) and the five residual 'after = before + difference' outputs
+    (projects/microphysics/train/dense.yaml:62-89)."""
+    rng = np.random.default_rng(0)
+    n = 2000
+    raw = ["air_temperature_input", "specific_humidity_input", "cloud_water_mixing_ratio_input",
+           "pressure_thickness_of_atmospheric_layer", "air_temperature_after_last_gscond",
+           "specific_humidity_after_last_gscond"]
+    in_feats = {r: (r, 79, 0) for r in raw}
+    in_feats["log_cloud_input"] = ("cloud_water_mixing_ratio_input", 79, 0)
+    in_feats["log_humidity_input"] = ("specific_humidity_input", 79, 0)
+    in_feats["log_humidity_after_last_gscond"] = ("specific_humidity_after_last_gscond", 79, 0)
+    in_feats = dict(sorted(in_feats.items()))  # combine_inputs sorts by key
+    outs = {"total_precipitation": 1, "cloud_precpd_difference": 79, "temperature_precpd_difference": 79,
+            "humidity_precpd_difference": 79, "temperature_gscond_difference": 79, "humidity_gscond_difference": 79}
+    residual = {
+        "air_temperature_after_gscond": ("air_temperature_input", "temperature_gscond_difference"),
+        "specific_humidity_after_gscond": ("specific_humidity_input", "humidity_gscond_difference"),
+        "cloud_water_mixing_ratio_after_precpd": ("cloud_water_mixing_ratio_input", "cloud_precpd_difference"),
+        "air_temperature_after_precpd": ("air_temperature_input", "temperature_precpd_difference"),
+        "specific_humidity_after_precpd": ("specific_humidity_input", "humidity_precpd_difference"),
+    }
+    spec = _random_spec(rng, in_feats, 256, 2, outs,
+                        log_inputs=("log_cloud_input", "log_humidity_input", "log_humidity_after_last_gscond"),
+                        residual=residual)
+    src = {
+        "air_temperature_input": rng.uniform(1.8, 3.1, (n, 79)),
+        "specific_humidity_input": 10 ** rng.uniform(-8, -2, (n, 79)),
+        "cloud_water_mixing_ratio_input": np.where(rng.random((n, 79)) < 0.7, 0.0, 10 ** rng.uniform(-10, -3, (n, 79))),
+        "pressure_thickness_of_atmospheric_layer": rng.uniform(0.3, 1.5, (n, 79)),
+    }
+    src["air_temperature_after_last_gscond"] = src["air_temperature_input"] + rng.normal(0, 0.01, (n, 79))
+    src["specific_humidity_after_last_gscond"] = src["specific_humidity_input"] * rng.uniform(0.9, 1.1, (n, 79))
+    for layout in ("feature_sample", "sample_feature"):
+        _check(spec, src, device, layout)
+    # float64 sources (what the Fortran hook hands over) and float64 outputs
+    _check(spec, src, device, "feature_sample", src_dtype=np.float64, out_dtype=torch.float64)
+
+
+def test_limits_masks_and_clipped_inputs(device):
+    """OutputLimit (output_limit.py:29-48), zero mask of clipped output levels (clip.py:33-46),
+    input clip slices (clip.py:48-62): masked levels are exactly 0 (test_train.py:418-443)."""
+    rng = np.random.default_rng(5)
+    n = 513
+    mask = np.ones(79, np.float32)
+    mask[:10] = 0
+    spec = _random_spec(rng, {"T": ("T", 60, 19), "q": ("q", 79, 0)}, 32, 2, {"dQ1": 79, "dQ2": 79},
+                        limits={"dQ2": (-0.5, 0.75)}, masks={"dQ1": mask})
+    src = {"T": rng.normal(0, 1, (n, 79)), "q": rng.normal(0, 1, (n, 79))}
+    out, truth = _check(spec, src, device, "sample_feature")
+    got = out["dQ1"].cpu().numpy()
+    assert np.all(got[:, :10] == 0.0)
+    q2 = out["dQ2"].cpu().numpy()
+    assert q2.min() >= -0.5 and q2.max() <= 0.75
+    assert (q2 == -0.5).any() and (q2 == 0.75).any()
+
+
+def test_nan_input_propagates_only_to_its_sample(device):
+    rng = np.random.default_rng(6)
+    n = 300
+    spec = _random_spec(rng, {"a": ("a", 20, 0)}, 16, 2, {"y": 5})
+    from fv3net_amd.mlp import MlpModel
+
+    a = rng.normal(0, 1, (n, 20)).astype(np.float32)
+    a[17, 3] = np.nan
+    model = MlpModel(spec, device=device)
+    out = model.predict({"a": torch.from_numpy(a).to(device)}, layout="sample_feature")["y"].cpu().numpy()
+    assert np.all(np.isnan(out[17]))
+    assert not np.isnan(np.delete(out, 17, axis=0)).any()
+
+
+def test_predict_does_not_mutate_inputs_and_is_deterministic(device):
+    rng = np.random.default_rng(8)
+    spec = _random_spec(rng, {"a": ("a", 79, 0), "b": ("b", 1, 0)}, 8, 2, {"y": 79})
+    from fv3net_amd.mlp import MlpModel
+
+    model = MlpModel(spec, device=device)
+    a = torch.from_numpy(rng.normal(0, 1, (79, 700)).astype(np.float32)).to(device)
+    b = torch.from_numpy(rng.normal(0, 1, (700,)).astype(np.float32)).to(device)
+    a0, b0 = a.clone(), b.clone()
+    y1 = model.predict({"a": a, "b": b})["y"].clone()
+    y2 = model.predict({"a": a, "b": b})["y"]
+    assert torch.equal(a, a0) and torch.equal(b, b0)
+    assert torch.equal(y1, y2)
+
+
+def test_unsupported_configurations_fail_loudly(device):
+    from fv3net_amd._lib import Fv3HipError
+    from fv3net_amd.mlp import MlpModel
+
+    rng = np.random.default_rng(9)
+    spec = _random_spec(rng, {"a": ("a", 8, 0)}, 300, 1, {"y": 4})
+    with pytest.raises(Fv3HipError, match="width"):
+        MlpModel(spec, device=device)
+
+
+def test_full_size_c384_properties(device):
+    """All 884 736 C384 columns in one call: every column must equal the same column
+    evaluated in a small batch (the result may not depend on tile position), and a permutation
+    of the columns permutes the outputs."""
+    rng = np.random.default_rng(1)
+    from fv3net_amd.mlp import MlpModel
+
+    spec = _random_spec(rng, {"a": ("a", 79, 0), "b": ("b", 79, 0)}, 64, 2, {"y": 79, "z": 1})
+    model = MlpModel(spec, device=device)
+    n = 6 * 384 * 384
+    g = torch.Generator(device=device).manual_seed(0)
+    a = torch.randn((79, n), device=device, generator=g)
+    b = torch.randn((79, n), device=device, generator=g)
+    full = model.predict({"a": a, "b": b})
+    idx = torch.randint(0, n, (4096,), device=device, generator=g)
+    sub = model.predict({"a": a[:, idx].contiguous(), "b": b[:, idx].contiguous()})
+    for name in ("y", "z"):
+        assert torch.equal(full[name][:, idx], sub[name])
+    perm = torch.randperm(n, device=device, generator=g)
+    permuted = model.predict({"a": a[:, perm].contiguous(), "b": b[:, perm].contiguous()})
+    assert torch.equal(permuted["y"], full["y"][:, perm])

@@ -1,0 +1,196 @@
+"""Parity of the HIP vertical kernels with the oracle.
+
+mappm is single precision with the reference's exact operation order and no FMA contraction,
+so the HIP result must be BIT-IDENTICAL to the C restatement (which tests/test_oracle_mappm.py
+pins bit-for-bit to the reference's own Fortran).  pressure_at_interface is a sequential
+cumulative sum in the array dtype: bit-identical to numpy.cumsum.
+"""
+import json
+import os
+
+import numpy as np
+import pytest
+import torch
+
+from oracle import coarsen_np as onp
+from oracle import mappm_c
+
+pytestmark = pytest.mark.gpu
+GOLDEN = os.path.join(os.path.dirname(__file__), "golden")
+
+
+def _dev(a, device):
+    return torch.from_numpy(np.ascontiguousarray(a)).to(device)
+
+
+def _bits_equal(a, b):
+    """Bit-for-bit equality of float32 arrays; NaNs must sit in the same places but may differ
+    in sign/payload (x86 SSE and gfx950 generate different default NaNs)."""
+    a, b = np.ascontiguousarray(a), np.ascontiguousarray(b)
+    na, nb = np.isnan(a), np.isnan(b)
+    if not np.array_equal(na, nb):
+        return False
+    return np.array_equal(a.view(np.uint32)[~na], b.view(np.uint32)[~nb])
+
+
+def _columns(rng, ncol, km, kn, ptop2=None):
+    dp1 = rng.uniform(300, 1500, (ncol, km))
+    pe1 = np.concatenate([np.full((ncol, 1), 300.0), 300 + np.cumsum(dp1, 1)], 1)
+    dp2 = rng.uniform(300, 1500, (ncol, kn))
+    top = 300.0 if ptop2 is None else ptop2
+    pe2 = np.concatenate([np.full((ncol, 1), top), 300 + np.cumsum(dp2, 1)], 1)
+    q = rng.uniform(-1000, 1000, (ncol, km))
+    return pe1.astype(np.float32), q.astype(np.float32), pe2.astype(np.float32)
+
+
+def test_mappm_reference_known_answers(device):
+    # external/vcm/tests/test_mappm.py:5-44
+    from fv3net_amd import ops
+
+    p_in = np.asarray([0.0, 1.0, 2.0, 3.0, 4.0, 5.0])[None, :]
+    f_in = np.asarray([0.0, 1.0, 2.0, 3.0, 4.0])[None, :]
+    p_out = np.asarray([0.5, 1.2, 2.4, 2.8, 3.2, 4.5])[None, :]
+    res = ops.as_numpy(ops.mappm(_dev(p_in, device), _dev(f_in, device), _dev(p_out, device)))
+    assert res.dtype == np.float32
+    np.testing.assert_almost_equal(res, np.asarray([[0.35, 1.3, 2.1, 2.5, 3.35]], np.float32), decimal=5)
+
+    p_in = np.asarray([1.0, 2.0, 3.0, 4.0, 5.0])[None, :]
+    f_in = np.asarray([1.5, 2.5, 3.5, 4.5])[None, :]
+    p_out = np.asarray([0.0, 2.5, 3.5, 4.5, 50.0])[None, :]
+    res = ops.as_numpy(ops.mappm(_dev(p_in, device), _dev(f_in, device), _dev(p_out, device)))
+    np.testing.assert_almost_equal(res, np.asarray([[1.5, 3.0, 4.0, 4.502747]], np.float32), decimal=5)
+
+    p_in = np.asarray([1.0, 2.0, 3.0, 2.0, 5.0])[None, :]
+    f_in = np.full((1, 4), np.nan)
+    res = ops.as_numpy(ops.mappm(_dev(p_in, device), _dev(f_in, device), _dev(p_out, device)))
+    assert np.all(np.isnan(res))
+
+
+@pytest.mark.parametrize("km,kn,ncol", [(79, 79, 5000), (63, 63, 1000), (7, 7, 300), (4, 9, 100), (79, 40, 500), (20, 90, 333)])
+@pytest.mark.parametrize("iv,kord", [(1, 1), (0, 1), (-1, 4), (2, 6), (0, 7), (-2, 7), (1, 3)])
+def test_mappm_bit_exact_col_level(device, km, kn, ncol, iv, kord):
+    from fv3net_amd import ops
+
+    rng = np.random.default_rng(km * 100 + kn)
+    pe1, q, pe2 = _columns(rng, ncol, km, kn, ptop2=rng.choice([100.0, 300.0, 500.0]))
+    if iv == 0:
+        q = np.abs(q)
+    ref = mappm_c.mappm(pe1, q, pe2, iv, kord)
+    res = ops.as_numpy(ops.mappm(_dev(pe1, device), _dev(q, device), _dev(pe2, device), iv=iv, kord=kord))
+    assert _bits_equal(res, ref), np.nanmax(np.abs(res - ref))
+
+
+def test_mappm_level_col_layout_and_f64_inputs(device):
+    from fv3net_amd import ops
+
+    rng = np.random.default_rng(7)
+    nt, km, ny, nx = 2, 79, 12, 16
+    pe1, q, pe2 = _columns(rng, nt * ny * nx, km, km)
+    ref = mappm_c.mappm(pe1, q, pe2)
+
+    def native(a):  # [ncol, lev] -> [tile, lev, y, x]
+        return np.ascontiguousarray(np.moveaxis(a.reshape(nt, ny, nx, -1), -1, 1))
+
+    res = ops.as_numpy(ops.mappm(_dev(native(pe1), device), _dev(native(q), device), _dev(native(pe2), device), z_axis=1))
+    assert res.shape == (nt, km, ny, nx)
+    assert _bits_equal(np.moveaxis(res, 1, -1).reshape(-1, km), ref)
+    # float64 inputs are rounded to float32 on load, like f2py's argument conversion
+    res64 = ops.as_numpy(ops.mappm(_dev(native(pe1).astype(np.float64), device), _dev(native(q).astype(np.float64), device),
+                                   _dev(native(pe2).astype(np.float64), device), z_axis=1))
+    assert _bits_equal(res64, res)
+
+
+def test_mappm_edge_cases_bit_exact(device):
+    """Ties between interfaces, zero-thickness target layers, targets outside the source
+    column, NaNs in the field, flat fields (dm == 0 branch)."""
+    from fv3net_amd import ops
+
+    rng = np.random.default_rng(11)
+    ncol, km, kn = 2000, 30, 30
+    for trial in range(4):
+        dp1 = rng.integers(1, 4, (ncol, km)).astype(float)
+        pe1 = np.concatenate([np.full((ncol, 1), 3.0), 3 + np.cumsum(dp1, 1)], 1)
+        dp2 = rng.integers(0, 4, (ncol, kn)).astype(float)
+        pe2 = np.concatenate([np.full((ncol, 1), float(rng.integers(0, 6))), 3 + np.cumsum(dp2, 1)], 1)
+        q = rng.uniform(-10, 10, (ncol, km))
+        if trial >= 1:
+            q[rng.random((ncol, km)) < 0.05] = np.nan
+        if trial >= 2:
+            q = np.round(q)
+        for iv, kord in [(1, 1), (0, 7), (-1, 4)]:
+            ref = mappm_c.mappm(pe1, q, pe2, iv, kord)
+            res = ops.as_numpy(ops.mappm(_dev(pe1, device), _dev(q, device), _dev(pe2, device), iv=iv, kord=kord))
+            assert np.array_equal(np.isnan(res), np.isnan(ref))
+            assert _bits_equal(res, ref)
+
+
+def test_mappm_errors(device):
+    from fv3net_amd import ops
+    from fv3net_amd._lib import Fv3HipError
+
+    z = torch.zeros(4, 6, device=device)
+    with pytest.raises(ValueError, match="one shorter"):
+        ops.mappm(z, z, z)
+    with pytest.raises(ValueError, match="All dimensions except vertical"):
+        ops.mappm(torch.zeros(4, 7, device=device), torch.zeros(5, 6, device=device), torch.zeros(4, 7, device=device))
+    with pytest.raises(Fv3HipError, match="cs_profile"):
+        ops.mappm(torch.zeros(4, 7, device=device), z, torch.zeros(4, 7, device=device), kord=9)
+
+
+def test_mappm_empty(device):
+    from fv3net_amd import ops
+
+    res = ops.mappm(torch.zeros(0, 7, device=device), torch.zeros(0, 6, device=device), torch.zeros(0, 7, device=device))
+    assert tuple(res.shape) == (0, 6)
+
+
+@pytest.mark.parametrize("dt", [np.float32, np.float64])
+@pytest.mark.parametrize("z_axis", [0, 1, -1])
+def test_pressure_at_interface(device, dt, z_axis):
+    from fv3net_amd import ops
+
+    rng = np.random.default_rng(3)
+    delp = rng.uniform(300, 1500, (4, 9, 6)).astype(dt)
+    res = ops.as_numpy(ops.pressure_at_interface(_dev(delp, device), 300.0, z_axis))
+    ref = onp.pressure_at_interface(delp, 300.0, z_axis)
+    assert res.dtype == ref.dtype
+    np.testing.assert_array_equal(res, ref)
+
+
+def test_mask_weights(device):
+    from fv3net_amd import ops
+
+    # external/vcm/tests/test_regridz.py:113-147 (extrapolate=False case)
+    weights = np.array([[1.0, 1.0]])                                    # [y=1, x=2]
+    phalf_c = np.array([[[0.0, 0.0]], [[1.0, 1.0]], [[2.0, 2.0]], [[3.0, 3.0]]])  # [z+1, y, x]
+    phalf_f = np.array([[[0.0, 0.0]], [[1.0, 1.0]], [[2.0, 2.5]], [[2.75, 3.5]]])
+    res = ops.as_numpy(ops.mask_weights(_dev(weights, device), _dev(phalf_c, device), _dev(phalf_f, device), z_axis=0))
+    ref = onp.mask_weights(weights, phalf_c, phalf_f, 0)
+    np.testing.assert_array_equal(res, ref)
+    np.testing.assert_array_equal(res[:, 0, :], np.array([[1.0, 1.0], [1.0, 1.0], [0.0, 1.0]]))
+
+
+def test_full_size_c384_mappm_properties(device):
+    """C384 x 79 at full size through size-independent properties: remapping onto the same
+    interfaces returns the field, a constant field stays constant, and the remap conserves
+    the column integral when source and target span the same pressure range."""
+    from fv3net_amd import ops
+
+    g = torch.Generator(device=device).manual_seed(0)
+    nt, nz, n = 6, 79, 384
+    delp = torch.rand((nt, nz, n, n), device=device, generator=g) * 1200 + 300
+    q = torch.rand((nt, nz, n, n), device=device, generator=g) * 2000 - 1000
+    pe1 = ops.pressure_at_interface(delp, 300.0, 1)
+    same = ops.mappm(pe1, q, pe1, z_axis=1)
+    assert torch.allclose(same, q, rtol=1e-5, atol=1e-3)
+    const = ops.mappm(pe1, torch.full_like(q, 7.5), pe1, z_axis=1)
+    assert torch.allclose(const, torch.full_like(const, 7.5), rtol=1e-6, atol=0)
+    # a different target grid with the same top and bottom
+    w = torch.rand((nt, nz, n, n), device=device, generator=g) + 0.5
+    delp2 = w / w.sum(dim=1, keepdim=True) * delp.sum(dim=1, keepdim=True)
+    pe2 = ops.pressure_at_interface(delp2, 300.0, 1)
+    pe2[:, -1] = pe1[:, -1]
+    r = ops.mappm(pe1, q, pe2, z_axis=1)
+    lhs = (r.double() * (pe2[:, 1:] - pe2[:, :-1]).double()).sum(dim=1)
+    rhs = (q.double() * delp.double()).sum(dim=1)
+    assert torch.allclose(lhs, rhs, rtol=1e-4, atol=50.0)
