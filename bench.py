@@ -1,0 +1,323 @@
+#!/usr/bin/env python
+"""Benchmark of the hot path on MI355X.
+
+    python bench.py --gpus N --steps K --warmup W
+
+Headline (BASELINE.json configs[1]): columns/s of the Zhao-Carr microphysics MLP emulator
+(K = 711 inputs, 2 x 256 hidden, 396 outputs; projects/microphysics/train/dense.yaml:62-89 of
+the reference) over one C384 snapshot (6 x 384 x 384 = 884 736 columns, 79 levels) per GPU.
+A "step" is one pass of the fused kernel over the rank's snapshot, inputs resident in HBM.
+With N > 1 every rank owns its own snapshot (tile/snapshot sharding, no data-path collective):
+weak scaling; value = columns of all ranks / max-over-ranks time.
+
+The JSON line also carries
+  roofline     -- the MLP kernel against the fp32 MFMA peak, timed with HIP events on the launch stream
+  cpu_baseline -- the numpy oracle of the same network on a bounded sample, on this box's host cores
+  secondary    -- the HBM-bound coarsening kernels (C3072 -> C384 weighted_block_average, C384 mappm)
+                  against the HBM roofline
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+import numpy as np
+import torch
+import torch.distributed as dist
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+if ROOT not in sys.path:
+    sys.path.insert(0, ROOT)
+
+PEAK_FP32_MFMA_TFLOPS = 157.3  # MI355X dense fp32 matrix peak (MI355X_MICROARCH.md)
+PEAK_HBM_GBPS = 8000.0         # MI355X HBM3E peak
+
+RAW_FIELDS = [
+    "air_temperature_input",
+    "specific_humidity_input",
+    "cloud_water_mixing_ratio_input",
+    "pressure_thickness_of_atmospheric_layer",
+    "air_temperature_after_last_gscond",
+    "specific_humidity_after_last_gscond",
+]
+LOG_FIELDS = {
+    "log_cloud_input": ("cloud_water_mixing_ratio_input", 1e-10),
+    "log_humidity_input": ("specific_humidity_input", 1e-8),
+    "log_humidity_after_last_gscond": ("specific_humidity_after_last_gscond", 1e-8),
+}
+OUTPUTS = {
+    "total_precipitation": 1,
+    "cloud_precpd_difference": 79,
+    "temperature_precpd_difference": 79,
+    "humidity_precpd_difference": 79,
+    "temperature_gscond_difference": 79,
+    "humidity_gscond_difference": 79,
+}
+NZ = 79
+
+
+def zc_inputs_numpy(rng, n):
+    """SURVEY.md 8(d) config 2 distributions, [sample, feature] float32."""
+    t = rng.uniform(180, 310, (n, NZ))
+    q = 10 ** rng.uniform(-8, -2, (n, NZ))
+    c = np.where(rng.random((n, NZ)) < 0.7, 0.0, 10 ** rng.uniform(-10, -3, (n, NZ)))
+    dp = rng.uniform(300, 1500, (n, NZ))
+    src = {
+        "air_temperature_input": t,
+        "specific_humidity_input": q,
+        "cloud_water_mixing_ratio_input": c,
+        "pressure_thickness_of_atmospheric_layer": dp,
+        "air_temperature_after_last_gscond": t + rng.normal(0, 0.5, (n, NZ)),
+        "specific_humidity_after_last_gscond": q * rng.uniform(0.9, 1.1, (n, NZ)),
+    }
+    return {k: v.astype(np.float32) for k, v in src.items()}
+
+
+def zc_spec(seed=0):
+    """Random-init weights of the reference architecture; normalisation fitted on a sample the
+    way MicrophysicsConfig does (center per feature, one std over all features)."""
+    from fv3net_amd.mlp import InputSpec, MlpSpec, OutputSpec
+    from oracle import mlp_np
+
+    rng = np.random.default_rng(seed)
+    sample = zc_inputs_numpy(rng, 4096)
+    names = sorted(RAW_FIELDS + list(LOG_FIELDS))  # combine_inputs sorts by key
+    inputs = []
+    for name in names:
+        if name in LOG_FIELDS:
+            source, eps = LOG_FIELDS[name]
+            data = np.log(np.maximum(sample[source], np.float32(eps)))
+            inputs.append(InputSpec(source, NZ, transform="log", eps=eps,
+                                    center=mlp_np.fit_mean_per_feature(data), scale=mlp_np.fit_std_all(data)))
+        else:
+            data = sample[name]
+            inputs.append(InputSpec(name, NZ, center=mlp_np.fit_mean_per_feature(data),
+                                    scale=mlp_np.fit_std_all(data)))
+    k, w = NZ * len(inputs), 256
+    f = sum(OUTPUTS.values())
+    glorot = lambda a, b: rng.uniform(-1, 1, (a, b)).astype(np.float32) * np.float32(np.sqrt(6.0 / (a + b)))
+    return MlpSpec(
+        inputs=inputs,
+        hidden_kernels=[glorot(k, w), glorot(w, w)],
+        hidden_biases=[rng.normal(0, 0.01, w).astype(np.float32) for _ in range(2)],
+        outputs=[OutputSpec(n_, nf, scale=np.float32(rng.uniform(0.5, 2)), center=rng.normal(0, 1, nf).astype(np.float32))
+                 for n_, nf in OUTPUTS.items()],
+        out_kernel=glorot(w, f),
+        out_bias=rng.normal(0, 0.01, f).astype(np.float32),
+    )
+
+
+def zc_inputs_device(dev, n, seed):
+    """The same distributions generated on the device, [feature, sample] float32."""
+    g = torch.Generator(device=dev).manual_seed(seed)
+    u = lambda lo, hi: torch.rand((NZ, n), device=dev, generator=g) * (hi - lo) + lo
+    t = u(180, 310)
+    q = 10 ** u(-8, -2)
+    c = torch.where(torch.rand((NZ, n), device=dev, generator=g) < 0.7, torch.zeros((), device=dev), 10 ** u(-10, -3))
+    return {
+        "air_temperature_input": t,
+        "specific_humidity_input": q,
+        "cloud_water_mixing_ratio_input": c,
+        "pressure_thickness_of_atmospheric_layer": u(300, 1500),
+        "air_temperature_after_last_gscond": t + torch.randn((NZ, n), device=dev, generator=g) * 0.5,
+        "specific_humidity_after_last_gscond": q * u(0.9, 1.1),
+    }
+
+
+def cpu_baseline(spec, budget_s=15.0):
+    """The oracle (numpy float32, [sample, feature]) on a bounded sample of the same workload."""
+    from oracle import mlp_np
+
+    try:
+        from threadpoolctl import threadpool_info
+
+        threads = max([p.get("num_threads", 1) for p in threadpool_info()] or [1])
+    except Exception:
+        threads = os.cpu_count() or 1
+    n = 16384
+    src = zc_inputs_numpy(np.random.default_rng(1), n)
+    mlp_np.forward(spec, src)  # warm
+    t0, reps = time.perf_counter(), 0
+    while True:
+        mlp_np.forward(spec, src)
+        reps += 1
+        if time.perf_counter() - t0 > budget_s or reps >= 50:
+            break
+    dt = time.perf_counter() - t0
+    return {
+        "value": n * reps / dt,
+        "unit": "columns/s",
+        "cores": int(threads),
+        "kind": "port",
+        "sample": f"{reps} passes over {n} of the 884736 C384 columns, numpy float32 oracle (BLAS threads = {threads})",
+    }
+
+
+def time_kernel(fn, steps, dev):
+    from fv3net_amd.ops import HipTimer
+
+    timer = HipTimer()
+    timer.start(dev)
+    for _ in range(steps):
+        fn()
+    timer.stop(dev)
+    return timer.elapsed_ms() / steps
+
+
+def secondary_benchmarks(dev, steps):
+    """HBM-bound kernels of the coarse-graining path against the 8 TB/s roofline."""
+    from fv3net_amd import ops
+
+    out = []
+    g = torch.Generator(device=dev).manual_seed(0)
+    # C3072 -> C384 (f = 8) weighted_block_average of one 3-D float32 field, 2-D area weights
+    for label, n, tiles in (("C3072->C384", 3072, 6), ("C384->C48", 384, 6)):
+        try:
+            obj = torch.rand((tiles, NZ, n, n), device=dev, generator=g) * 2000 - 1000
+            area = torch.rand((tiles, n, n), device=dev, generator=g) * 0.5 + 0.5
+            fn = lambda: ops.weighted_block_average(obj, area, 8)
+            fn()
+            torch.cuda.synchronize(dev)
+            ms = time_kernel(fn, max(3, min(steps, 10)), dev)
+            nel = obj.numel()
+            alg_bytes = 4 * nel * (1 + 1 / 64) + 4 * nel / NZ
+            out.append({
+                "kernel": "weighted_block_average", "workload": f"{label} f=8, one [6,79,{n},{n}] f32 field, 2-D area weights",
+                "ms": ms, "roofline": {"bound": "hbm", "achieved": alg_bytes / ms / 1e6, "peak": PEAK_HBM_GBPS,
+                                       "unit": "GB/s", "frac": alg_bytes / ms / 1e6 / PEAK_HBM_GBPS, "traffic": None},
+            })
+            del obj, area
+        except torch.cuda.OutOfMemoryError:
+            out.append({"kernel": "weighted_block_average", "workload": label, "error": "out of memory"})
+        torch.cuda.empty_cache()
+    # mappm at C384: 884 736 columns, km = kn = 79, native [tile, z, y, x] layout
+    n = 384
+    delp = torch.rand((6, NZ, n, n), device=dev, generator=g) * 1200 + 300
+    delp2 = torch.rand((6, NZ, n, n), device=dev, generator=g) * 1200 + 300
+    q = torch.rand((6, NZ, n, n), device=dev, generator=g) * 2000 - 1000
+    pe1 = ops.pressure_at_interface(delp, 300.0, 1)
+    pe2 = ops.pressure_at_interface(delp2, 300.0, 1)
+    fn = lambda: ops.mappm(pe1, q, pe2, z_axis=1)
+    fn()
+    torch.cuda.synchronize(dev)
+    ms = time_kernel(fn, max(3, min(steps, 10)), dev)
+    ncol = 6 * n * n
+    alg_bytes = ncol * 1272.0
+    out.append({
+        "kernel": "mappm", "workload": "C384 884736 columns, km=kn=79, iv=1 kord=1, [tile,z,y,x] f32",
+        "ms": ms, "columns_per_s": ncol / ms * 1e3,
+        "roofline": {"bound": "hbm", "achieved": alg_bytes / ms / 1e6, "peak": PEAK_HBM_GBPS, "unit": "GB/s",
+                     "frac": alg_bytes / ms / 1e6 / PEAK_HBM_GBPS, "traffic": None},
+    })
+    return out
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=10)
+    ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--no-secondary", action="store_true")
+    ap.add_argument("--no-cpu", action="store_true")
+    args = ap.parse_args()
+
+    rank = int(os.environ.get("RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if world > 1:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device(f"cuda:{local_rank}"))
+    assert world == max(args.gpus, 1) or world == 1, f"--gpus {args.gpus} but WORLD_SIZE={world}"
+    dev = torch.device(f"cuda:{local_rank}")
+    torch.cuda.set_device(dev)
+
+    from fv3net_amd import _lib, ops
+    from fv3net_amd.mlp import MlpModel
+
+    _lib.load()
+    spec = zc_spec(0)
+    model = MlpModel(spec, device=dev)
+    ncol = 6 * 384 * 384
+    src = zc_inputs_device(dev, ncol, seed=1000 + rank)
+
+    def step():
+        return model.predict(src)
+
+    for _ in range(args.warmup):
+        step()
+
+    def fence():
+        torch.cuda.synchronize(dev)
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize(dev)
+
+    fence()
+    from fv3net_amd.ops import HipTimer
+
+    timer = HipTimer()
+    t0 = time.perf_counter()
+    timer.start(dev)
+    for _ in range(args.steps):
+        step()
+    timer.stop(dev)
+    fence()
+    elapsed = time.perf_counter() - t0
+    kernel_ms = timer.elapsed_ms() / args.steps
+    if world > 1:
+        t = torch.tensor([elapsed], device=dev, dtype=torch.float64)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        elapsed = float(t.item())
+
+    if rank == 0:
+        total_cols = ncol * world * args.steps
+        flops = model.flops_per_sample
+        achieved = flops * ncol / (kernel_ms * 1e-3) / 1e12
+        line = {
+            "metric": "columns/s ML-tendency inference at C384x79 (Zhao-Carr dense emulator)",
+            "value": total_cols / elapsed,
+            "unit": "columns/s",
+            "n_gpus": world,
+            "steps": args.steps,
+            "warmup": args.warmup,
+            "ms_per_step": elapsed / args.steps * 1e3,
+            "higher_is_better": True,
+            "scaling": "weak",
+            "vs_baseline": None,
+            "dtype": "f32",
+            "data": "synthetic (SURVEY 8d config 2 distributions, random-init weights of the dense.yaml architecture)",
+            "config": {
+                "workload": "C384 Zhao-Carr microphysics MLP emulator, one 6x384x384x79 snapshot per GPU "
+                            "(BASELINE configs[1]): K=711 -> 256 -> 256 -> 396, float32 [feature, sample] inputs in HBM",
+                "columns_per_gpu": ncol,
+                "flops_per_column": flops,
+                "parallelism": f"snapshot/tile sharding over {world} GPU(s), no collective on the data path",
+            },
+            "roofline": {
+                "bound": "mfma",
+                "achieved": achieved,
+                "peak": PEAK_FP32_MFMA_TFLOPS,
+                "unit": "TFLOP/s",
+                "frac": achieved / PEAK_FP32_MFMA_TFLOPS,
+                "traffic": None,
+                "kernel": "mlp_fused_kernel<8,13>",
+                "kernel_ms": kernel_ms,
+            },
+        }
+        if world == 1 and not args.no_cpu:
+            line["cpu_baseline"] = cpu_baseline(spec)
+        if world == 1 and not args.no_secondary:
+            del src
+            torch.cuda.empty_cache()
+            line["secondary"] = secondary_benchmarks(dev, args.steps)
+        info = ops.device_info()
+        line["device"] = {"name": info["name"], "arch": info["arch"], "compute_units": info["compute_units"]}
+        print(json.dumps(line), flush=True)
+    if world > 1:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

@@ -170,27 +170,30 @@ def test_mask_weights(device):
     np.testing.assert_array_equal(res[:, 0, :], np.array([[1.0, 1.0], [1.0, 1.0], [0.0, 1.0]]))
 
 
-def test_full_size_c384_mappm_properties(device):
-    """C384 x 79 at full size through size-independent properties: remapping onto the same
-    interfaces returns the field, a constant field stays constant, and the remap conserves
-    the column integral when source and target span the same pressure range."""
+def test_full_size_c384_mappm(device):
+    """C384 x 79 at full size (884 736 columns, native [tile, z, y, x] layout): remapping onto the
+    same interfaces returns the field, a constant field stays constant, and every 16th column
+    is bit-identical to the oracle.  (Column-integral conservation is NOT a property of the
+    reference: a target layer whose top edge is at or above the source top is assigned
+    q1(1) outright, mappm.f90:62-64.)"""
     from fv3net_amd import ops
 
     g = torch.Generator(device=device).manual_seed(0)
     nt, nz, n = 6, 79, 384
     delp = torch.rand((nt, nz, n, n), device=device, generator=g) * 1200 + 300
+    delp2 = torch.rand((nt, nz, n, n), device=device, generator=g) * 1200 + 300
     q = torch.rand((nt, nz, n, n), device=device, generator=g) * 2000 - 1000
     pe1 = ops.pressure_at_interface(delp, 300.0, 1)
+    pe2 = ops.pressure_at_interface(delp2, 300.0, 1)
     same = ops.mappm(pe1, q, pe1, z_axis=1)
     assert torch.allclose(same, q, rtol=1e-5, atol=1e-3)
-    const = ops.mappm(pe1, torch.full_like(q, 7.5), pe1, z_axis=1)
+    const = ops.mappm(pe1, torch.full_like(q, 7.5), pe2, z_axis=1)
     assert torch.allclose(const, torch.full_like(const, 7.5), rtol=1e-6, atol=0)
-    # a different target grid with the same top and bottom
-    w = torch.rand((nt, nz, n, n), device=device, generator=g) + 0.5
-    delp2 = w / w.sum(dim=1, keepdim=True) * delp.sum(dim=1, keepdim=True)
-    pe2 = ops.pressure_at_interface(delp2, 300.0, 1)
-    pe2[:, -1] = pe1[:, -1]
     r = ops.mappm(pe1, q, pe2, z_axis=1)
-    lhs = (r.double() * (pe2[:, 1:] - pe2[:, :-1]).double()).sum(dim=1)
-    rhs = (q.double() * delp.double()).sum(dim=1)
-    assert torch.allclose(lhs, rhs, rtol=1e-4, atol=50.0)
+
+    def cols(t):  # [tile, lev, y, x] -> every 16th column as [ncol, lev]
+        a = t.permute(0, 2, 3, 1).reshape(-1, t.shape[1])[::16]
+        return a.cpu().numpy()
+
+    ref = mappm_c.mappm(cols(pe1), cols(q), cols(pe2))
+    assert _bits_equal(cols(r), ref)
