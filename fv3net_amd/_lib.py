@@ -97,9 +97,14 @@ SIGNATURES = {
         c_int,
         [c_void_p, c_int, c_int64, c_int, c_int64, c_double, c_void_p, c_void_p],
     ),
+    "fv3hip_pressure_at_midpoint_log": (
+        c_int,
+        [c_void_p, c_int, c_int64, c_int, c_int64, c_double, c_void_p, c_void_p],
+    ),
     "fv3hip_mask_weights": (
         c_int,
-        [c_void_p, c_int, c_void_p, c_void_p, c_int, c_int64, c_int, c_int64, c_int64, c_void_p, c_void_p],
+        [c_void_p, c_int, c_void_p, c_int, c_int, c_void_p, c_int, c_int64, c_int, c_int64, c_int64, c_void_p,
+         c_void_p],
     ),
     "fv3hip_mappm_workspace_bytes": (c_size_t, [c_int64, c_int]),
     "fv3hip_mappm": (

@@ -324,7 +324,13 @@ __global__ void block_reduce_kernel(const T *__restrict__ in, T *__restrict__ ou
         const T *p = in + o * ny * (int64_t)nx + (int64_t)Y * sy * nx + (int64_t)X * sx;
         auto at = [&](int i) { return p[(int64_t)(i / bx) * nx + (i % bx)]; };
         T result;
-        if (op == FV3HIP_OP_SUM || op == FV3HIP_OP_MEAN) {
+        bool poisoned = false;  // NAN_PROPAGATE for sum/mean/min/max: numpy's plain reductions
+        if (nan_policy == FV3HIP_NAN_PROPAGATE && op <= FV3HIP_OP_MAX) {
+            for (int i = 0; i < n; ++i) poisoned |= nan_of(at(i));
+        }
+        if (poisoned) {
+            result = quiet_nan<T>();
+        } else if (op == FV3HIP_OP_SUM || op == FV3HIP_OP_MEAN) {
             T acc = 0;
             int cnt = 0;
             for (int i = 0; i < n; ++i) {

@@ -42,7 +42,8 @@ __global__ void pressure_at_interface_kernel(const T *__restrict__ delp, T *__re
 template <typename Tw, typename Tp>
 __global__ void mask_weights_kernel(const Tw *__restrict__ w, const Tp *__restrict__ pc,
                                     const Tp *__restrict__ pf, Tw *__restrict__ out,
-                                    int64_t n_batch, int nz, int64_t n_inner, int64_t w_repeat)
+                                    int64_t n_batch, int nz, int64_t n_inner, int64_t w_repeat,
+                                    int cmp_levels, int cmp_offset)
 {
     const int64_t total = n_batch * nz * n_inner;
     for (int64_t idx = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; idx < total;
@@ -51,9 +52,32 @@ __global__ void mask_weights_kernel(const Tw *__restrict__ w, const Tp *__restri
         const int64_t t = idx / n_inner;
         const int k = (int)(t % nz);
         const int64_t b = t / nz;
-        const Tp bottom = pc[(b * (nz + 1) + (k + 1)) * n_inner + c];
+        const Tp level = pc[(b * cmp_levels + (k + cmp_offset)) * n_inner + c];
         const Tp ps = pf[(b * (nz + 1) + nz) * n_inner + c];
-        out[idx] = (bottom < ps) ? w[(b / w_repeat) * n_inner + c] : (Tw)0;
+        out[idx] = (level < ps) ? w[(b / w_repeat) * n_inner + c] : (Tw)0;
+    }
+}
+
+// pressure_at_midpoint_log: delp / diff(log(p_interface)), sequential down the column
+template <typename T>
+__global__ void pressure_at_midpoint_log_kernel(const T *__restrict__ delp, T *__restrict__ out,
+                                                int64_t n_batch, int nz, int64_t n_inner, T toa)
+{
+    const int64_t ncol = n_batch * n_inner;
+    for (int64_t col = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; col < ncol;
+         col += (int64_t)gridDim.x * blockDim.x) {
+        const int64_t b = col / n_inner, c = col % n_inner;
+        const T *pd = delp + b * nz * n_inner + c;
+        T *po = out + b * nz * n_inner + c;
+        T p = toa;
+        T lp_prev = log(p);
+        for (int k = 0; k < nz; ++k) {
+            const T d = pd[(int64_t)k * n_inner];
+            p = p + d;
+            const T lp = log(p);
+            po[(int64_t)k * n_inner] = d / (lp - lp_prev);
+            lp_prev = lp;
+        }
     }
 }
 
@@ -368,24 +392,49 @@ extern "C" int fv3hip_pressure_at_interface(const void *delp, int dtype, int64_t
     return check_launch("pressure_at_interface_kernel");
 }
 
-extern "C" int fv3hip_mask_weights(const void *weights, int w_dtype, const void *p_coarse,
-                                   const void *p_fine, int p_dtype, int64_t n_batch, int nz,
-                                   int64_t n_inner, int64_t w_repeat, void *out, void *stream)
+extern "C" int fv3hip_pressure_at_midpoint_log(const void *delp, int dtype, int64_t n_batch, int nz,
+                                               int64_t n_inner, double toa_pressure, void *out,
+                                               void *stream)
+{
+    FV3HIP_REQUIRE(dtype == FV3HIP_F32 || dtype == FV3HIP_F64, "dtype must be F32 or F64, got %d", dtype);
+    FV3HIP_REQUIRE(n_batch >= 0 && nz >= 0 && n_inner >= 0, "negative extent");
+    const int64_t ncol = n_batch * n_inner;
+    if (ncol == 0 || nz == 0) return FV3HIP_OK;
+    FV3HIP_REQUIRE(delp && out, "null pointer");
+    int64_t blocks = ceil_div(ncol, 256);
+    if (blocks > 256 * 64) blocks = 256 * 64;
+    hipStream_t st = as_stream(stream);
+    if (dtype == FV3HIP_F32)
+        hipLaunchKernelGGL((pressure_at_midpoint_log_kernel<float>), dim3((unsigned)blocks), dim3(256),
+                           0, st, static_cast<const float *>(delp), static_cast<float *>(out), n_batch,
+                           nz, n_inner, (float)toa_pressure);
+    else
+        hipLaunchKernelGGL((pressure_at_midpoint_log_kernel<double>), dim3((unsigned)blocks), dim3(256),
+                           0, st, static_cast<const double *>(delp), static_cast<double *>(out),
+                           n_batch, nz, n_inner, toa_pressure);
+    return check_launch("pressure_at_midpoint_log_kernel");
+}
+
+extern "C" int fv3hip_mask_weights(const void *weights, int w_dtype, const void *p_cmp, int cmp_levels,
+                                   int cmp_offset, const void *p_fine, int p_dtype, int64_t n_batch,
+                                   int nz, int64_t n_inner, int64_t w_repeat, void *out, void *stream)
 {
     FV3HIP_REQUIRE(w_dtype == FV3HIP_F32 || w_dtype == FV3HIP_F64, "weights dtype must be F32 or F64");
     FV3HIP_REQUIRE(p_dtype == FV3HIP_F32 || p_dtype == FV3HIP_F64, "pressure dtype must be F32 or F64");
     FV3HIP_REQUIRE(w_repeat >= 1 && n_batch % w_repeat == 0, "bad w_repeat %lld", (long long)w_repeat);
+    FV3HIP_REQUIRE(cmp_offset >= 0 && cmp_levels >= nz + cmp_offset,
+                   "p_cmp has %d levels, need at least nz + cmp_offset = %d", cmp_levels, nz + cmp_offset);
     const int64_t total = n_batch * nz * n_inner;
     if (total <= 0) return FV3HIP_OK;
-    FV3HIP_REQUIRE(weights && p_coarse && p_fine && out, "null pointer");
+    FV3HIP_REQUIRE(weights && p_cmp && p_fine && out, "null pointer");
     int64_t blocks = ceil_div(total, 256);
     if (blocks > 256 * 64) blocks = 256 * 64;
     hipStream_t st = as_stream(stream);
 #define LAUNCH_(TW, TP)                                                                              \
     hipLaunchKernelGGL((mask_weights_kernel<TW, TP>), dim3((unsigned)blocks), dim3(256), 0, st,      \
-                       static_cast<const TW *>(weights), static_cast<const TP *>(p_coarse),          \
+                       static_cast<const TW *>(weights), static_cast<const TP *>(p_cmp),             \
                        static_cast<const TP *>(p_fine), static_cast<TW *>(out), n_batch, nz, n_inner, \
-                       w_repeat)
+                       w_repeat, cmp_levels, cmp_offset)
     if (w_dtype == FV3HIP_F32 && p_dtype == FV3HIP_F32) LAUNCH_(float, float);
     else if (w_dtype == FV3HIP_F32) LAUNCH_(float, double);
     else if (p_dtype == FV3HIP_F32) LAUNCH_(double, float);

@@ -1,0 +1,107 @@
+"""Vertical regridding to coarse pressure levels with the interface of
+``vcm.cubedsphere.regridz`` (external/vcm/vcm/cubedsphere/regridz.py), on the device.
+
+The reference moves the vertical dim last, flattens to [column, level], lets f2py copy to
+Fortran order and calls ``mappm`` per chunk.  Here the arrays stay in whatever layout they have
+(the native [tile, z, y, x] included) and the remap kernel walks the level axis in place.
+"""
+from typing import Hashable, Union
+
+from .. import ops
+from ..thermo import pressure_at_interface, pressure_at_midpoint_log
+from ..xr_compat import DataArray, Dataset, from_compat, to_compat
+from ._device import like_input, on_device
+from .coarsen import block_upsample_like, weighted_block_average
+from .constants import FV_CORE_X_CENTER, FV_CORE_Y_CENTER, RESTART_Z_CENTER, RESTART_Z_OUTER
+
+SURFACE_LEVEL = -1
+
+
+def regrid_vertical(p_in, f_in, p_out, iv: int = 1, kord: int = 1, z_dim_center: str = RESTART_Z_CENTER,
+                    z_dim_outer: str = RESTART_Z_OUTER):
+    """Vertical regridding with the PPM remap (regridz.py:223-301).  ``p_in``/``p_out`` hold
+    interface pressures along ``z_dim_outer``, ``f_in`` layer means along ``z_dim_center``; the
+    result has ``f_in``'s dim order and attrs, float32, with ``p_out``'s layers."""
+    if z_dim_center == z_dim_outer:
+        raise ValueError("'z_dim_center' and 'z_dim_outer' must not be equal.")
+    pi, fi, po = to_compat(p_in), to_compat(f_in), to_compat(p_out)
+    dims_except_z = [d for d in fi.dims if d != z_dim_center]
+    # same dim order for all three, the vertical dim where f_in has it
+    order_f = list(fi.dims)
+    order_p = [z_dim_outer if d == z_dim_center else d for d in order_f]
+    for name, arr in (("p_in", pi), ("p_out", po)):
+        if set(arr.dims) != set(order_p):
+            raise ValueError("All dimensions except vertical must be same size for p_in, f_in and p_out")
+    pi_t, po_t = pi.transpose(*order_p), po.transpose(*order_p)
+    n_columns = 1
+    for d in dims_except_z:
+        n_columns *= fi.sizes[d]
+        if pi_t.sizes[d] != fi.sizes[d] or po_t.sizes[d] != fi.sizes[d]:
+            raise ValueError("All dimensions except vertical must be same size for p_in, f_in and p_out")
+    if fi.sizes[z_dim_center] != pi_t.sizes[z_dim_outer] - 1:
+        raise ValueError("f_in must have a vertical dimension one shorter than p_in")
+    axis = fi.get_axis_num(z_dim_center)
+    res = ops.mappm(on_device(pi_t.data), on_device(fi.data), on_device(po_t.data), iv=iv, kord=kord, z_axis=axis)
+    coords = {k: v for k, v in fi.coords.items() if k != z_dim_center}
+    out = DataArray(like_input(res, fi.data), dims=fi.dims, coords=coords, name=fi.name, attrs=fi.attrs)
+    return from_compat(out, f_in)
+
+
+def _mask_weights(weights, pfull_coarse_on_fine, phalf_coarse_on_fine, phalf_fine, dim_center: str = RESTART_Z_CENTER,
+                  dim_outer: str = RESTART_Z_OUTER, extrapolate: bool = False):
+    """regridz.py:200-220: weights where the coarse level lies above the fine surface, else 0."""
+    w, pf = to_compat(weights), to_compat(phalf_fine)
+    pc = to_compat(pfull_coarse_on_fine if extrapolate else phalf_coarse_on_fine)
+    zc = dim_center if extrapolate else dim_outer
+    order = list(pf.dims)
+    axis = order.index(dim_outer)
+    pc_t = pc.transpose(*[zc if d == dim_outer else d for d in order])
+    w_order = [d for d in order if d != dim_outer]
+    if set(w.dims) != set(w_order):
+        # broadcast the weights over the missing non-vertical dims (e.g. area [tile, y, x] vs time)
+        import numpy as np  # noqa: F401  (host-side metadata only)
+
+        missing = [d for d in w_order if d not in w.dims]
+        data = on_device(w.data)
+        for _ in missing:
+            data = data.unsqueeze(0)
+        data = data.expand(*[pf.sizes[d] for d in missing], *w.shape).contiguous()
+        w = DataArray(data, dims=tuple(missing) + w.dims, coords=w.coords, attrs=w.attrs, name=w.name)
+    w_t = w.transpose(*w_order)
+    res = ops.mask_weights(on_device(w_t.data), on_device(pc_t.data), on_device(pf.data), axis, extrapolate=extrapolate)
+    dims = tuple(dim_center if d == dim_outer else d for d in order)
+    coords = {k: v for k, v in w.coords.items()}
+    out = DataArray(like_input(res, to_compat(weights).data), dims=dims, coords=coords, name=w.name, attrs=w.attrs)
+    return from_compat(out, weights)
+
+
+def _regrid_given_delp(ds, delp_fine, delp_coarse, weights, toa_pressure, x_dim: str = FV_CORE_X_CENTER,
+                       y_dim: str = FV_CORE_Y_CENTER, z_dim: str = RESTART_Z_CENTER, extrapolate: bool = False):
+    """regridz.py:149-197."""
+    delp_coarse_on_fine = block_upsample_like(delp_coarse, delp_fine, x_dim=x_dim, y_dim=y_dim)
+    phalf_coarse_on_fine = pressure_at_interface(delp_coarse_on_fine, dim_center=z_dim, dim_outer=RESTART_Z_OUTER,
+                                                 toa_pressure=toa_pressure)
+    phalf_fine = pressure_at_interface(delp_fine, dim_center=z_dim, dim_outer=RESTART_Z_OUTER, toa_pressure=toa_pressure)
+    d = to_compat(ds)
+    if isinstance(d, Dataset):
+        regridded = Dataset(attrs=d.attrs)
+        for var in d:
+            regridded[var] = regrid_vertical(phalf_fine, d[var], phalf_coarse_on_fine, z_dim_center=z_dim)
+    else:
+        regridded = regrid_vertical(phalf_fine, d, phalf_coarse_on_fine, z_dim_center=z_dim)
+    pfull_coarse_on_fine = (
+        pressure_at_midpoint_log(delp_coarse_on_fine, dim=z_dim, toa_pressure=toa_pressure) if extrapolate else None
+    )
+    masked_weights = _mask_weights(weights, pfull_coarse_on_fine, phalf_coarse_on_fine, phalf_fine, dim_center=z_dim,
+                                   extrapolate=extrapolate)
+    return from_compat(regridded, ds), masked_weights
+
+
+def regrid_to_area_weighted_pressure(ds, delp, area, toa_pressure: float, coarsening_factor: int,
+                                     x_dim: str = FV_CORE_X_CENTER, y_dim: str = FV_CORE_Y_CENTER,
+                                     z_dim: str = RESTART_Z_CENTER, extrapolate: bool = False):
+    """Vertically regrid cell-centred quantities to coarsened pressure levels (regridz.py:31-78).
+    Returns (regridded dataset, area masked wherever the coarse layer is below the fine surface)."""
+    delp_coarse = weighted_block_average(delp, area, coarsening_factor, x_dim=x_dim, y_dim=y_dim)
+    return _regrid_given_delp(ds, delp, delp_coarse, area, toa_pressure, x_dim=x_dim, y_dim=y_dim, z_dim=z_dim,
+                              extrapolate=extrapolate)

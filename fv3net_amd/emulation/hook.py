@@ -1,0 +1,44 @@
+"""``MicrophysicsHook``: applies the emulator to the Fortran state in place
+(external/emulation/emulation/_emulate/microphysics.py:19-100)."""
+import gc
+from typing import Callable, Mapping, MutableMapping
+
+import numpy as np
+
+FortranState = MutableMapping[str, np.ndarray]
+Mask = Callable[[FortranState, FortranState], FortranState]
+
+
+def always_emulator(state: FortranState, emulator: FortranState):
+    return emulator
+
+
+class MicrophysicsHook:
+    """Object that applies a ML model to the fortran state."""
+
+    def __init__(self, model: Callable[[FortranState], FortranState], mask: Mask = always_emulator,
+                 garbage_collection_interval: int = 10) -> None:
+        self.name = "microphysics emulator"
+        self.garbage_collection_interval = garbage_collection_interval
+        self.mask = mask
+        self._calls_since_last_collection = 0
+        self.model = model
+
+    def _maybe_garbage_collect(self):
+        if self._calls_since_last_collection % self.garbage_collection_interval:
+            gc.collect()
+            self._calls_since_last_collection = 0
+        else:
+            self._calls_since_last_collection += 1
+
+    def microphysics(self, state: FortranState) -> None:
+        """Hook called from Fortran through call_py_fort.  ``state`` holds ``[feature, sample]``
+        (or ``[sample]``) arrays plus scalar entries; it is updated in place with the
+        emulator's ``[feature, sample]`` outputs."""
+        inputs = {name: state[name].T for name in state if hasattr(state[name], "T")}
+        predictions = self.model(inputs)
+        # transpose back to FV3 conventions
+        model_outputs = {name: np.asarray(tensor).T for name, tensor in predictions.items()}
+        model_outputs.update(self.mask(state, model_outputs))
+        state.update(model_outputs)
+        self._maybe_garbage_collect()

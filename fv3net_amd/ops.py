@@ -223,19 +223,40 @@ def pressure_at_interface(delp: torch.Tensor, toa_pressure: float, z_axis: int) 
     return out
 
 
+def pressure_at_midpoint_log(delp: torch.Tensor, toa_pressure: float, z_axis: int) -> torch.Tensor:
+    """``delp / diff(log(p_interface))`` along ``z_axis`` (vertically_dependent.py:153-179)."""
+    dev = _require_device(delp)
+    delp = delp.contiguous()
+    z_axis = z_axis % delp.dim()
+    nz = int(delp.shape[z_axis])
+    n_batch, n_inner = _prod(delp.shape[:z_axis]), _prod(delp.shape[z_axis + 1:])
+    out = torch.empty_like(delp)
+    _lib.call(
+        "fv3hip_pressure_at_midpoint_log", _ptr(delp), _float_code(delp), n_batch, nz, n_inner,
+        float(toa_pressure), _ptr(out), _stream(dev),
+    )
+    return out
+
+
 def mask_weights(
-    weights: torch.Tensor, p_coarse: torch.Tensor, p_fine: torch.Tensor, z_axis: int
+    weights: torch.Tensor, p_coarse: torch.Tensor, p_fine: torch.Tensor, z_axis: int, extrapolate: bool = False
 ) -> torch.Tensor:
-    """``weights where p_coarse[k+1] < p_fine[surface] else 0`` (regridz.py:200-220,
-    extrapolate=False).  ``p_*`` have nz+1 levels along ``z_axis``; ``weights`` has p's shape
-    without the z axis, or without the z axis and any of the dims right before it
-    (e.g. p [tile, z+1, y, x] and weights [tile, y, x])."""
+    """``weights where p_level < p_fine[surface] else 0`` (regridz.py:200-220).
+    ``extrapolate=False``: ``p_coarse`` holds the nz+1 coarse interface pressures and level k is
+    compared through its bottom interface; ``extrapolate=True``: ``p_coarse`` holds the nz coarse
+    midpoint pressures.  ``p_fine`` has nz+1 levels along ``z_axis``; ``weights`` has the pressure
+    shape without the z axis."""
     dev = _require_device(weights, p_coarse, p_fine)
-    if p_coarse.shape != p_fine.shape or p_coarse.dtype != p_fine.dtype:
-        raise ValueError("p_coarse and p_fine must have the same shape and dtype")
+    if p_coarse.dtype != p_fine.dtype:
+        raise ValueError("p_coarse and p_fine must have the same dtype")
     p_coarse, p_fine, weights = p_coarse.contiguous(), p_fine.contiguous(), weights.contiguous()
     z_axis = z_axis % p_fine.dim()
     nz = int(p_fine.shape[z_axis]) - 1
+    cmp_levels, cmp_offset = (nz, 0) if extrapolate else (nz + 1, 1)
+    expect = list(p_fine.shape)
+    expect[z_axis] = cmp_levels
+    if list(p_coarse.shape) != expect:
+        raise ValueError(f"p_coarse has shape {tuple(p_coarse.shape)}, expected {tuple(expect)}")
     batch_shape, inner_shape = tuple(p_fine.shape[:z_axis]), tuple(p_fine.shape[z_axis + 1:])
     n_batch, n_inner = _prod(batch_shape), _prod(inner_shape)
     if tuple(weights.shape) != batch_shape + inner_shape:
@@ -243,11 +264,10 @@ def mask_weights(
             f"weights shape {tuple(weights.shape)} must be the pressure shape without its z axis "
             f"{batch_shape + inner_shape}"
         )
-    out_shape = batch_shape + (nz,) + inner_shape
-    out = torch.empty(out_shape, dtype=weights.dtype, device=dev)
+    out = torch.empty(batch_shape + (nz,) + inner_shape, dtype=weights.dtype, device=dev)
     _lib.call(
-        "fv3hip_mask_weights", _ptr(weights), _float_code(weights), _ptr(p_coarse), _ptr(p_fine),
-        _float_code(p_fine), n_batch, nz, n_inner, 1, _ptr(out), _stream(dev),
+        "fv3hip_mask_weights", _ptr(weights), _float_code(weights), _ptr(p_coarse), cmp_levels, cmp_offset,
+        _ptr(p_fine), _float_code(p_fine), n_batch, nz, n_inner, 1, _ptr(out), _stream(dev),
     )
     return out
 

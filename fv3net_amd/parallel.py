@@ -1,0 +1,85 @@
+"""One process per GPU: how the path shards and what (little) it exchanges.
+
+Every unit of work on this path is independent -- a column for the MLP and the remap, an
+f x f block for the horizontal coarsening -- so ranks never exchange data while computing
+(the reference's MPI ranks are equally independent,
+workflows/prognostic_c48_run/runtime/steppers/machine_learning.py:176-181).  What this module
+provides is the partition (cube tiles / row bands / column ranges over ranks) and the optional
+gather of results to one consumer, on ``torch.distributed`` (backend ``nccl`` = RCCL over xGMI
+on the GPU box, ``gloo`` in CPU tests).
+"""
+from typing import Dict, List, Sequence, Tuple
+
+import torch
+import torch.distributed as dist
+
+
+def world() -> Tuple[int, int]:
+    """(rank, world_size); (0, 1) when torch.distributed is not initialised."""
+    if dist.is_available() and dist.is_initialized():
+        return dist.get_rank(), dist.get_world_size()
+    return 0, 1
+
+
+def column_range(n_columns: int, world_size: int, rank: int) -> Tuple[int, int]:
+    """Contiguous, balanced [start, stop) of the columns owned by ``rank``."""
+    base, extra = divmod(n_columns, world_size)
+    start = rank * base + min(rank, extra)
+    return start, start + base + (1 if rank < extra else 0)
+
+
+def tile_bands(n_tiles: int, ny: int, factor: int, world_size: int) -> List[List[Tuple[int, int, int]]]:
+    """Partition ``n_tiles`` tiles of ``ny`` rows into (tile, row_start, row_stop) units, one list
+    per rank.  Rows are cut in multiples of the coarsening factor so that no f x f block
+    straddles two ranks (blocks never straddle tiles or sub-tiles in the reference either,
+    external/vcm/vcm/cubedsphere/coarsen.py:83-132).  Bands per tile is the smallest count that
+    makes tiles * bands a multiple of world_size (6 tiles on 8 GPUs -> 4 bands, 3 units each);
+    if the rows cannot be cut that finely, whole tiles are dealt round-robin."""
+    if ny % factor:
+        raise ValueError(f"{ny} rows are not a multiple of the coarsening factor {factor}")
+    blocks = ny // factor
+    bands = next((b for b in range(1, blocks + 1) if (n_tiles * b) % world_size == 0 and blocks % b == 0), None)
+    units: List[Tuple[int, int, int]] = []
+    if bands is None:
+        units = [(t, 0, ny) for t in range(n_tiles)]
+    else:
+        rows = (blocks // bands) * factor
+        units = [(t, b * rows, (b + 1) * rows) for t in range(n_tiles) for b in range(bands)]
+    out: List[List[Tuple[int, int, int]]] = [[] for _ in range(world_size)]
+    per = -(-len(units) // world_size)
+    for i, u in enumerate(units):
+        out[min(i // per, world_size - 1)].append(u)
+    return out
+
+
+def gather_columns(local: torch.Tensor, n_columns: int, dst: int = 0):
+    """Gather per-rank ``[features, n_local]`` blocks (split by :func:`column_range`) to rank
+    ``dst`` as ``[features, n_columns]``; returns None on the other ranks.  The only collective
+    on the path, and optional: needed only when a single consumer wants the whole cube."""
+    rank, size = world()
+    if size == 1:
+        return local
+    counts = [column_range(n_columns, size, r) for r in range(size)]
+    width = max(b - a for a, b in counts)
+    padded = torch.zeros((local.shape[0], width), dtype=local.dtype, device=local.device)
+    padded[:, : local.shape[1]] = local
+    if rank == dst:
+        bufs = [torch.empty_like(padded) for _ in range(size)]
+        dist.gather(padded, bufs, dst=dst)
+        return torch.cat([b[:, : (hi - lo)] for b, (lo, hi) in zip(bufs, counts)], dim=1)
+    dist.gather(padded, None, dst=dst)
+    return None
+
+
+def predict_sharded(model, sources: Dict[str, torch.Tensor], gather: bool = False, dst: int = 0):
+    """Run ``model.predict`` (an :class:`fv3net_amd.mlp.MlpModel` or anything with the same call)
+    on this rank's column range of ``[feature, sample]`` sources.  With ``gather`` the outputs are
+    collected on rank ``dst``."""
+    rank, size = world()
+    n = next(iter(sources.values())).shape[-1]
+    lo, hi = column_range(n, size, rank)
+    local = {k: v[..., lo:hi] for k, v in sources.items()}
+    outs = model.predict(local)
+    if not gather:
+        return outs
+    return {k: gather_columns(v, n, dst) for k, v in outs.items()}

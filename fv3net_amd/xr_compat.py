@@ -1,0 +1,407 @@
+"""A minimal labelled-array layer with the slice of xarray's interface that the hot path uses.
+
+The reference's public functions take and return ``xarray`` objects.  xarray is not installable
+in the build or GPU images, so the host layer works on these two small classes, which mirror the
+attributes the path touches (``dims``, ``sizes``, ``coords``, ``attrs``, ``name``, ``isel``,
+``transpose``, ``rename`` ...).  When real xarray IS importable, every public entry point accepts
+``xarray.DataArray`` / ``xarray.Dataset`` arguments and returns the same types (``to_compat`` /
+``from_compat`` below), so callers such as ``runtime.steppers.machine_learning`` keep working
+unchanged.
+
+``data`` may be a numpy array (host) or a torch tensor (device resident); the compute entry
+points move host data to the GPU and back, and leave device data where it is.
+"""
+from typing import Any, Dict, Hashable, Iterable, Mapping, Optional, Sequence, Tuple, Union
+
+import numpy as np
+
+try:  # pragma: no cover - not installable in this image
+    import xarray as _xr
+except ImportError:  # the normal case here
+    _xr = None
+
+try:
+    import torch
+except ImportError:  # pragma: no cover
+    torch = None
+
+
+def _is_torch(x) -> bool:
+    return torch is not None and isinstance(x, torch.Tensor)
+
+
+def _asarray(x):
+    if _is_torch(x) or isinstance(x, np.ndarray):
+        return x
+    return np.asarray(x)
+
+
+class DataArray:
+    """N-d array with named dimensions, 1-d dimension coordinates, a name and attributes."""
+
+    def __init__(self, data, dims: Optional[Sequence[Hashable]] = None, coords=None, name=None, attrs=None):
+        if isinstance(data, DataArray):
+            dims = data.dims if dims is None else dims
+            coords = data.coords if coords is None else coords
+            name = data.name if name is None else name
+            attrs = data.attrs if attrs is None else attrs
+            data = data.data
+        self.data = _asarray(data)
+        nd = self.data.ndim
+        if dims is None:
+            dims = tuple(f"dim_{i}" for i in range(nd))
+        if isinstance(dims, str):
+            dims = (dims,)
+        if len(dims) != nd:
+            raise ValueError(f"different number of dimensions on data and dims: {nd} vs {len(dims)}")
+        self.dims: Tuple[Hashable, ...] = tuple(dims)
+        self.name = name
+        self.attrs: Dict[str, Any] = dict(attrs) if attrs else {}
+        self.coords: Dict[Hashable, np.ndarray] = {}
+        for key, value in (coords or {}).items():
+            if isinstance(value, DataArray):
+                value = value.values
+            elif isinstance(value, tuple) and len(value) == 2:  # (dims, data)
+                value = value[1]
+            value = np.asarray(value)
+            if key in self.dims:
+                if value.shape != (self.sizes[key],):
+                    raise ValueError(f"coordinate {key!r} has shape {value.shape}, expected {(self.sizes[key],)}")
+                self.coords[key] = value
+            elif value.ndim == 0:
+                self.coords[key] = value  # scalar coordinate
+
+    # -- basic properties ---------------------------------------------------------------
+    @property
+    def shape(self):
+        return tuple(self.data.shape)
+
+    @property
+    def ndim(self):
+        return self.data.ndim
+
+    @property
+    def dtype(self):
+        return self.data.dtype
+
+    @property
+    def sizes(self) -> Dict[Hashable, int]:
+        return dict(zip(self.dims, self.shape))
+
+    @property
+    def values(self) -> np.ndarray:
+        if _is_torch(self.data):
+            return self.data.detach().cpu().numpy()
+        return np.asarray(self.data)
+
+    @property
+    def chunks(self):
+        return None
+
+    def get_axis_num(self, dim) -> int:
+        return self.dims.index(dim)
+
+    def __array__(self, dtype=None):
+        return self.values if dtype is None else self.values.astype(dtype)
+
+    def __repr__(self):
+        return f"<fv3net_amd DataArray {self.name!r} {self.sizes} {self.dtype}>"
+
+    # -- construction helpers -----------------------------------------------------------
+    def _replace(self, data=None, dims=None, coords=None, name="__keep__", attrs=None):
+        out = DataArray.__new__(DataArray)
+        out.data = self.data if data is None else data
+        out.dims = self.dims if dims is None else tuple(dims)
+        out.coords = dict(self.coords if coords is None else coords)
+        out.name = self.name if name == "__keep__" else name
+        out.attrs = dict(self.attrs if attrs is None else attrs)
+        return out
+
+    def copy(self, deep=True):
+        data = self.data
+        if deep:
+            data = data.clone() if _is_torch(data) else np.array(data, copy=True)
+        return self._replace(data=data)
+
+    def rename(self, new=None):
+        if isinstance(new, Mapping):
+            dims = tuple(new.get(d, d) for d in self.dims)
+            coords = {new.get(k, k): v for k, v in self.coords.items()}
+            return self._replace(dims=dims, coords=coords)
+        return self._replace(name=new)
+
+    def assign_attrs(self, *args, **kwargs):
+        attrs = dict(self.attrs)
+        for a in args:
+            attrs.update(a)
+        attrs.update(kwargs)
+        return self._replace(attrs=attrs)
+
+    def assign_coords(self, coords=None, **kwargs):
+        new = dict(self.coords)
+        items = dict(coords or {}, **kwargs)
+        for k, v in items.items():
+            v = v.values if isinstance(v, DataArray) else np.asarray(v)
+            if k in self.dims and v.shape != (self.sizes[k],):
+                raise ValueError(f"coordinate {k!r} has the wrong length")
+            new[k] = v
+        return self._replace(coords=new)
+
+    def drop(self, names):
+        names = [names] if isinstance(names, (str, bytes)) or not isinstance(names, Iterable) else list(names)
+        return self._replace(coords={k: v for k, v in self.coords.items() if k not in names})
+
+    drop_vars = drop
+
+    def astype(self, dtype):
+        if _is_torch(self.data):
+            tdt = dtype if isinstance(dtype, torch.dtype) else getattr(torch, np.dtype(dtype).name)
+            return self._replace(data=self.data.to(tdt))
+        return self._replace(data=self.data.astype(dtype))
+
+    def to_dataset(self, name=None):
+        name = self.name if name is None else name
+        if name is None:
+            raise ValueError("unable to convert unnamed DataArray to a Dataset without providing an explicit name")
+        return Dataset({name: self})
+
+    # -- indexing / reshaping -----------------------------------------------------------
+    def transpose(self, *dims):
+        if not dims:
+            dims = self.dims[::-1]
+        if Ellipsis in dims:
+            rest = [d for d in self.dims if d not in dims]
+            i = dims.index(Ellipsis)
+            dims = tuple(dims[:i]) + tuple(rest) + tuple(dims[i + 1:])
+        if set(dims) != set(self.dims) or len(dims) != len(self.dims):
+            raise ValueError(f"{dims} must be a permuted list of {self.dims}")
+        order = [self.dims.index(d) for d in dims]
+        data = self.data.permute(*order) if _is_torch(self.data) else np.transpose(self.data, order)
+        return self._replace(data=data, dims=dims)
+
+    def isel(self, indexers=None, **kwargs):
+        indexers = dict(indexers or {}, **kwargs)
+        key = []
+        dims = []
+        coords = dict(self.coords)
+        for d in self.dims:
+            idx = indexers.get(d, slice(None))
+            key.append(idx)
+            if isinstance(idx, (int, np.integer)):
+                if d in coords:
+                    coords[d] = np.asarray(coords[d][idx])
+            else:
+                dims.append(d)
+                if d in coords:
+                    coords[d] = coords[d][idx]
+        unknown = set(indexers) - set(self.dims)
+        if unknown:
+            raise ValueError(f"dimensions {unknown} do not exist")
+        return self._replace(data=self.data[tuple(key)], dims=dims, coords=coords)
+
+    def __getitem__(self, key):
+        if isinstance(key, (str, bytes)) or (isinstance(key, Hashable) and key in self.coords):
+            dims = (key,) if key in self.dims else ()
+            return DataArray(self.coords[key], dims=dims, coords={key: self.coords[key]} if dims else None, name=key)
+        raise KeyError(key)
+
+    def __setitem__(self, key, value):
+        if key in self.dims:
+            value = value.values if isinstance(value, DataArray) else np.asarray(value)
+            if value.shape != (self.sizes[key],):
+                raise ValueError(f"coordinate {key!r} has the wrong length")
+            self.coords[key] = value
+        else:
+            raise KeyError(key)
+
+
+class Dataset:
+    """Ordered mapping of names to DataArrays plus dataset-level attributes."""
+
+    def __init__(self, data_vars: Optional[Mapping[Hashable, Any]] = None, coords=None, attrs=None):
+        self._vars: Dict[Hashable, DataArray] = {}
+        self.attrs: Dict[str, Any] = dict(attrs) if attrs else {}
+        self._coords: Dict[Hashable, np.ndarray] = {}
+        for k, v in (coords or {}).items():
+            if isinstance(v, DataArray):
+                v = v.values
+            elif isinstance(v, tuple) and len(v) == 2:
+                v = v[1]
+            self._coords[k] = np.asarray(v)
+        for name, value in (data_vars or {}).items():
+            self[name] = value
+
+    # mapping protocol
+    def __iter__(self):
+        return iter(self._vars)
+
+    def __len__(self):
+        return len(self._vars)
+
+    def __contains__(self, key):
+        return key in self._vars or key in self.coords
+
+    def keys(self):
+        return self._vars.keys()
+
+    def items(self):
+        return self._vars.items()
+
+    def values(self):
+        return self._vars.values()
+
+    @property
+    def data_vars(self):
+        return self._vars
+
+    @property
+    def coords(self) -> Dict[Hashable, np.ndarray]:
+        out = dict(self._coords)
+        for v in self._vars.values():
+            for k, c in v.coords.items():
+                out.setdefault(k, c)
+        return out
+
+    @property
+    def dims(self) -> Dict[Hashable, int]:
+        out: Dict[Hashable, int] = {}
+        for v in self._vars.values():
+            for d, n in v.sizes.items():
+                if out.setdefault(d, n) != n:
+                    raise ValueError(f"conflicting sizes for dimension {d!r}")
+        return out
+
+    sizes = dims
+
+    def __getitem__(self, key):
+        if isinstance(key, (list, tuple)):
+            return Dataset({k: self._vars[k] for k in key}, coords=self._coords, attrs=self.attrs)
+        if key in self._vars:
+            return self._vars[key]
+        if key in self.coords:
+            c = self.coords[key]
+            return DataArray(c, dims=(key,) if c.ndim == 1 else (), name=key)
+        raise KeyError(key)
+
+    def __setitem__(self, name, value):
+        if isinstance(value, tuple) and len(value) in (2, 3):  # (dims, data[, attrs])
+            value = DataArray(value[1], dims=value[0], attrs=value[2] if len(value) == 3 else None)
+        if not isinstance(value, DataArray):
+            value = to_compat(value) if _xr is not None and isinstance(value, _xr.DataArray) else DataArray(value)
+        coords = dict(value.coords)
+        for d in value.dims:  # dataset-level dimension coordinates apply to every variable
+            if d in self._coords and d not in coords and self._coords[d].shape == (value.sizes[d],):
+                coords[d] = self._coords[d]
+        self._vars[name] = value._replace(name=name, coords=coords)
+
+    def __repr__(self):
+        return f"<fv3net_amd Dataset {list(self._vars)} {self.dims}>"
+
+    def assign(self, variables=None, **kwargs):
+        out = self.copy(deep=False)
+        for k, v in dict(variables or {}, **kwargs).items():
+            out[k] = v
+        return out
+
+    def assign_attrs(self, *args, **kwargs):
+        out = self.copy(deep=False)
+        for a in args:
+            out.attrs.update(a)
+        out.attrs.update(kwargs)
+        return out
+
+    def copy(self, deep=True):
+        return Dataset({k: (v.copy() if deep else v) for k, v in self._vars.items()}, coords=self._coords,
+                       attrs=self.attrs)
+
+    def map(self, func, args=(), **kwargs):
+        return Dataset({k: func(v, *args, **kwargs) for k, v in self._vars.items()}, coords=None, attrs=self.attrs)
+
+    apply = map
+
+    def rename(self, mapping):
+        out = Dataset(attrs=self.attrs)
+        for k, v in self._vars.items():
+            out[mapping.get(k, k)] = v.rename({d: mapping[d] for d in v.dims if d in mapping})
+        return out
+
+    def transpose(self, *dims):
+        out = Dataset(attrs=self.attrs)
+        for k, v in self._vars.items():
+            order = [d for d in dims if d in v.dims or d is Ellipsis]
+            out[k] = v.transpose(*order) if order else v
+        return out
+
+    def isel(self, indexers=None, **kwargs):
+        indexers = dict(indexers or {}, **kwargs)
+        return Dataset({k: v.isel({d: i for d, i in indexers.items() if d in v.dims}) for k, v in self._vars.items()},
+                       attrs=self.attrs)
+
+
+def merge(objects: Iterable[Union[Dataset, DataArray]]) -> Dataset:
+    out = Dataset()
+    for obj in objects:
+        if isinstance(obj, DataArray):
+            obj = obj.to_dataset()
+        for k, v in obj.items():
+            out[k] = v
+        out.attrs.update({})
+    return out
+
+
+def zeros_like(obj):
+    if isinstance(obj, Dataset):
+        return Dataset({k: zeros_like(v) for k, v in obj.items()}, attrs=obj.attrs)
+    data = torch.zeros_like(obj.data) if _is_torch(obj.data) else np.zeros_like(obj.data)
+    return obj._replace(data=data)
+
+
+# ---------------------------------------------------------------------------------------------
+# interop with real xarray, when it is installed
+# ---------------------------------------------------------------------------------------------
+def is_xarray(obj) -> bool:
+    return _xr is not None and isinstance(obj, (_xr.DataArray, _xr.Dataset))
+
+
+def to_compat(obj):
+    """xarray object -> compat object (compat objects and None pass through)."""
+    if obj is None or isinstance(obj, (DataArray, Dataset)):
+        return obj
+    if _xr is not None and isinstance(obj, _xr.DataArray):
+        coords = {k: np.asarray(v) for k, v in obj.coords.items() if k in obj.dims}
+        return DataArray(obj.data, dims=obj.dims, coords=coords, name=obj.name, attrs=obj.attrs)
+    if _xr is not None and isinstance(obj, _xr.Dataset):
+        coords = {k: np.asarray(v) for k, v in obj.coords.items() if k in obj.dims}
+        return Dataset({k: to_compat(obj[k]) for k in obj.data_vars}, coords=coords, attrs=obj.attrs)
+    raise TypeError(f"expected a DataArray or Dataset, got {type(obj)}")
+
+
+def from_compat(obj, like):
+    """Return ``obj`` as the kind of object ``like`` was (xarray in -> xarray out)."""
+    if not is_xarray(like):
+        return obj
+    if isinstance(obj, DataArray):  # pragma: no cover - needs xarray
+        return _xr.DataArray(obj.values, dims=obj.dims, coords={k: (k, v) for k, v in obj.coords.items() if k in obj.dims},
+                             name=obj.name, attrs=obj.attrs)
+    if isinstance(obj, Dataset):  # pragma: no cover - needs xarray
+        return _xr.Dataset({k: from_compat(v, like) for k, v in obj.items()}, attrs=obj.attrs)
+    return obj
+
+
+def assert_identical_including_dtype(a, b):
+    """Like vcm.xarray_utils.assert_identical_including_dtype, for compat objects."""
+    if isinstance(a, Dataset):
+        assert isinstance(b, Dataset) and list(a) == list(b), (list(a), list(b))
+        assert a.attrs == b.attrs, (a.attrs, b.attrs)
+        for k in a:
+            assert_identical_including_dtype(a[k], b[k])
+        return
+    assert a.dims == b.dims, (a.dims, b.dims)
+    assert a.name == b.name, (a.name, b.name)
+    assert a.attrs == b.attrs, (a.attrs, b.attrs)
+    assert a.values.dtype == b.values.dtype, (a.values.dtype, b.values.dtype)
+    np.testing.assert_array_equal(a.values, b.values)
+    assert set(a.coords) == set(b.coords), (set(a.coords), set(b.coords))
+    for k in a.coords:
+        np.testing.assert_array_equal(a.coords[k], b.coords[k])
+        assert np.asarray(a.coords[k]).dtype == np.asarray(b.coords[k]).dtype

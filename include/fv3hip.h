@@ -54,7 +54,8 @@ extern "C" {
 
 /* NaN handling for fv3hip_block_reduce */
 #define FV3HIP_NAN_SKIP 0      /* xarray coarsen().sum()/min()/max()/mean() default (skipna) */
-#define FV3HIP_NAN_PROPAGATE 1 /* numpy.median / scipy.stats.mode(nan_policy="propagate")    */
+#define FV3HIP_NAN_PROPAGATE 1 /* numpy.sum/mean/min/max/median (NaN if any NaN in the window);
+                                  scipy.stats.mode(nan_policy="propagate")                   */
 #define FV3HIP_NAN_OMIT 2      /* scipy.stats.mode(nan_policy="omit")                        */
 
 /* column layouts (fv3hip_mappm, fv3hip_pressure_at_interface) */
@@ -145,14 +146,24 @@ int fv3hip_pressure_at_interface(const void *delp, int dtype, int64_t n_batch, i
                                  int64_t n_inner, double toa_pressure, void *out, void *stream);
 
 /*
- * Replaces vcm.cubedsphere.regridz._mask_weights
- * (external/vcm/vcm/cubedsphere/regridz.py:200-220), extrapolate=False branch:
- *     out[b][k][c] = weights[b / w_repeat][c]  if p_coarse[b][k+1][c] < p_fine[b][nz][c] else 0
- * p_* are [n_batch][nz+1][n_inner] in p_dtype; weights [n_batch / w_repeat][n_inner] and out
- * [n_batch][nz][n_inner] in w_dtype.
+ * Replaces vcm.pressure_at_midpoint_log
+ * (external/vcm/vcm/calc/thermo/vertically_dependent.py:153-179): delp / diff(log(p_interface)).
+ * Same layout and dtype rules as fv3hip_pressure_at_interface; out has nz levels.
  */
-int fv3hip_mask_weights(const void *weights, int w_dtype, const void *p_coarse,
-                        const void *p_fine, int p_dtype, int64_t n_batch, int nz,
+int fv3hip_pressure_at_midpoint_log(const void *delp, int dtype, int64_t n_batch, int nz,
+                                    int64_t n_inner, double toa_pressure, void *out, void *stream);
+
+/*
+ * Replaces vcm.cubedsphere.regridz._mask_weights
+ * (external/vcm/vcm/cubedsphere/regridz.py:200-220):
+ *     out[b][k][c] = weights[b / w_repeat][c]  if p_cmp[b][k + cmp_offset][c] < p_fine[b][nz][c] else 0
+ * extrapolate=False: p_cmp = coarse interface pressures (nz+1 levels), cmp_offset = 1 (bottom
+ * interface of layer k); extrapolate=True: p_cmp = coarse midpoint pressures (nz levels),
+ * cmp_offset = 0.  p_cmp is [n_batch][cmp_levels][n_inner], p_fine [n_batch][nz+1][n_inner],
+ * both in p_dtype; weights [n_batch / w_repeat][n_inner] and out [n_batch][nz][n_inner] in w_dtype.
+ */
+int fv3hip_mask_weights(const void *weights, int w_dtype, const void *p_cmp, int cmp_levels,
+                        int cmp_offset, const void *p_fine, int p_dtype, int64_t n_batch, int nz,
                         int64_t n_inner, int64_t w_repeat, void *out, void *stream);
 
 /*

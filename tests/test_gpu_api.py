@@ -1,0 +1,412 @@
+"""The drop-in Python boundary on the GPU: the vcm.cubedsphere / mappm / fv3fit / emulation
+shaped entry points, written the way the reference's own tests are
+(external/vcm/tests/test_cubedsphere.py, test_regridz.py, test_coarsen_restarts.py,
+external/fv3fit/tests/training/test_train.py, external/emulation/tests/test_microphysics.py)."""
+import numpy as np
+import pytest
+import torch
+
+import coarsen_restarts_cases as cases
+from fv3net_amd.xr_compat import DataArray, Dataset, assert_identical_including_dtype, merge
+from oracle import coarsen_np as onp
+from oracle import mappm_c, mlp_np
+
+pytestmark = pytest.mark.gpu
+
+
+# ------------------------------------------------------------------------------------------------
+# vcm.cubedsphere
+# ------------------------------------------------------------------------------------------------
+@pytest.mark.parametrize("object_type", ["DataArray", "Dataset"])
+def test_weighted_block_average(object_type):
+    from fv3net_amd.cubedsphere import weighted_block_average
+
+    dims = ["x", "y"]
+    attrs, ds_attrs = {"units": "m"}, {"test": "a"}
+    data = DataArray(np.array([[2.0, 6.0], [6.0, 2.0]]), dims=dims, name="foo", attrs=attrs)
+    if object_type == "Dataset":
+        data = data.to_dataset()
+        data.attrs = ds_attrs
+    weights = DataArray(np.array([[6.0, 2.0], [2.0, 6.0]]), dims=dims)
+    expected = DataArray(np.array([[3.0]]), dims=dims, name="foo", attrs=attrs)
+    if object_type == "Dataset":
+        expected = expected.to_dataset()
+        expected.attrs = ds_attrs
+    result = weighted_block_average(data, weights, 2, x_dim="x", y_dim="y")
+    assert_identical_including_dtype(result, expected)
+
+
+@pytest.mark.parametrize(
+    ("data", "spacing", "factor", "edge", "expected_data"),
+    [([[2, 6, 2], [6, 2, 6]], [[6, 2, 6], [2, 6, 2]], 2, "x", [[3.0, 3.0]]),
+     ([[2, 6], [6, 2], [2, 6]], [[6, 2], [2, 6], [6, 2]], 2, "y", [[3.0], [3.0]])],
+)
+def test_edge_weighted_block_average(data, spacing, factor, edge, expected_data):
+    from fv3net_amd.cubedsphere import edge_weighted_block_average
+
+    dims = ["x_dim", "y_dim"]
+    attrs = {"units": "m"}
+    da = DataArray(np.array(data), dims=dims, attrs=attrs)
+    weights = DataArray(np.array(spacing), dims=dims)
+    expected = DataArray(np.array(expected_data), dims=dims, attrs=attrs)
+    result = edge_weighted_block_average(da, weights, factor, x_dim="x_dim", y_dim="y_dim", edge=edge)
+    assert_identical_including_dtype(result, expected)
+    with pytest.raises(ValueError, match="'edge' most be either"):
+        edge_weighted_block_average(da, weights, factor, x_dim="x_dim", y_dim="y_dim", edge="z")
+
+
+@pytest.fixture()
+def input_dataarray():
+    data = np.arange(32).reshape(4, 4, 2).astype(np.float32)
+    return DataArray(data, dims=["x", "y", "z"], name="foo", attrs={"units": "m"})
+
+
+def test_block_median_coarsen_and_coords(input_dataarray):
+    from fv3net_amd.cubedsphere import block_coarsen, block_median, horizontal_block_reduce
+
+    data = input_dataarray.values
+    med = np.median(data.reshape(2, 2, 2, 2, 2), axis=(1, 3))
+    for result in (block_median(input_dataarray, 2, "x", "y"),
+                   block_coarsen(input_dataarray, 2, "x", "y", method="median"),
+                   horizontal_block_reduce(input_dataarray, 2, np.median, "x", "y")):
+        assert result.dims == ("x", "y", "z") and result.name == "foo" and result.attrs == {"units": "m"}
+        np.testing.assert_array_equal(result.values, med)
+    mn = block_coarsen(input_dataarray, 2, "x", "y", "min")
+    np.testing.assert_array_equal(mn.values, data.reshape(2, 2, 2, 2, 2).min(axis=(1, 3)))
+    # coordinates follow coord_func like xarray's coarsen (test_cubedsphere.py:299-327)
+    with_coords = input_dataarray.assign_coords({d: np.arange(n, dtype=np.float64) for d, n in input_dataarray.sizes.items()})
+    r = block_median(with_coords, 2, "x", "y", coord_func="mean")
+    np.testing.assert_array_equal(r.coords["x"], [0.5, 2.5])
+    np.testing.assert_array_equal(r.coords["z"], [0.0, 1.0])
+    r = block_median(with_coords, 2, "x", "y", coord_func={"x": np.max, "y": "median"})
+    np.testing.assert_array_equal(r.coords["x"], [1.0, 3.0])
+    np.testing.assert_array_equal(r.coords["y"], [0.5, 2.5])
+
+
+@pytest.mark.parametrize(
+    ("data", "factor", "edge", "expected_sum", "expected_min"),
+    [([[2, 6, 2], [6, 2, 6]], 2, "x", [[8, 8]], [[2, 2]]), ([[2, 6], [6, 2], [2, 6]], 2, "y", [[8], [8]], [[2], [2]])],
+)
+def test_block_edge_sum_and_coarsen(data, factor, edge, expected_sum, expected_min):
+    from fv3net_amd.cubedsphere import block_edge_coarsen, block_edge_sum
+
+    dims = ["x_dim", "y_dim"]
+    da = DataArray(np.array(data), dims=dims, attrs={"units": "m"})
+    result = block_edge_sum(da, factor, x_dim="x_dim", y_dim="y_dim", edge=edge)
+    assert_identical_including_dtype(result, DataArray(np.array(expected_sum), dims=dims, attrs={"units": "m"}))
+    result = block_edge_coarsen(da, factor, x_dim="x_dim", y_dim="y_dim", edge=edge, method="min")
+    assert_identical_including_dtype(result, DataArray(np.array(expected_min), dims=dims, attrs={"units": "m"}))
+
+
+def test_block_mode():
+    from fv3net_amd.cubedsphere import _block_mode, block_coarsen
+
+    data = np.array([[0.0, 0.0, 1.0, 1.0], [0.0, 0.0, 1.0, 1.0], [1.0, 1.0, 0.0, 0.0], [1.0, 1.0, 0.0, np.nan]])
+    da = DataArray(data, dims=["x", "y"], attrs={"units": "m"})
+    expected = DataArray(np.array([[0.0, 1.0], [1.0, 0.0]]), dims=["x", "y"], attrs={"units": "m"})
+    assert_identical_including_dtype(_block_mode(da, 2, x_dim="x", y_dim="y", nan_policy="omit"), expected)
+    assert_identical_including_dtype(
+        block_coarsen(da, 2, x_dim="x", y_dim="y", method="mode", func_kwargs={"nan_policy": "omit"}), expected)
+
+
+def test_block_upsample():
+    from fv3net_amd.cubedsphere import block_upsample, block_upsample_like
+
+    foo = DataArray(np.array([[1, 2], [3, 4]]), dims=["xt", "yt"], name="foo")
+    u = DataArray(np.array([[1, 2, 3], [4, 5, 6]]), dims=["xt", "y"], name="u")
+    result = block_upsample(merge([foo, u]), 2, dims=["xt", "y", "yt"])
+    np.testing.assert_array_equal(result["foo"].values, [[1, 1, 2, 2], [1, 1, 2, 2], [3, 3, 4, 4], [3, 3, 4, 4]])
+    np.testing.assert_array_equal(result["u"].values, [[1, 1, 2, 2, 3], [1, 1, 2, 2, 3], [4, 4, 5, 5, 6], [4, 4, 5, 5, 6]])
+    assert result["u"].dims == ("xt", "y")
+    ref = DataArray(np.zeros((4, 4)), dims=["x", "y"], coords={"x": np.arange(4.0), "y": np.arange(4.0)})
+    like = block_upsample_like(DataArray(np.array([[1.0, 2], [3, 4]]), dims=["x", "y"]), ref, x_dim="x", y_dim="y")
+    assert like.shape == (4, 4) and list(like.coords["x"]) == [0, 1, 2, 3]
+
+
+# ------------------------------------------------------------------------------------------------
+# mappm module and regridz
+# ------------------------------------------------------------------------------------------------
+def test_mappm_module_f2py_signature():
+    from fv3net_amd import mappm
+
+    p_in = np.asarray([0.0, 1.0, 2.0, 3.0, 4.0, 5.0])[None, :]
+    f_in = np.asarray([0.0, 1.0, 2.0, 3.0, 4.0])[None, :]
+    p_out = np.asarray([0.5, 1.2, 2.4, 2.8, 3.2, 4.5])[None, :]
+    result = mappm.mappm(p_in, f_in, p_out, 1, 1.0, 1.0, 1.0, 0.0)
+    assert isinstance(result, np.ndarray) and result.dtype == np.float32
+    np.testing.assert_almost_equal(result, np.asarray([[0.35, 1.3, 2.1, 2.5, 3.35]], np.float32), decimal=5)
+    # Fortran-ordered inputs are accepted like f2py does
+    result_f = mappm.mappm(np.asfortranarray(p_in), np.asfortranarray(f_in), np.asfortranarray(p_out), 1, 1, 1, 1, 0.0)
+    np.testing.assert_array_equal(result, result_f)
+
+
+def test_regrid_vertical_and_errors():
+    from fv3net_amd.cubedsphere import regrid_vertical
+
+    rng = np.random.default_rng(0)
+    nt, nz, ny, nx = 2, 7, 4, 4
+    delp = rng.uniform(3, 5, (nt, nz, ny, nx))
+    p = onp.pressure_at_interface(delp, 300.0, 1)
+    p2 = onp.pressure_at_interface(rng.uniform(3, 5, (nt, nz, ny, nx)), 300.0, 1)
+    f = rng.uniform(-1000, 1000, (nt, nz, ny, nx))
+    dims_c, dims_o = ["tile", "zaxis_1", "y", "x"], ["tile", "zaxis_2", "y", "x"]
+    f_in = DataArray(f, dims=dims_c, attrs={"units": "K"}, name="T")
+    out = regrid_vertical(DataArray(p, dims=dims_o), f_in, DataArray(p2, dims=dims_o))
+    assert out.dims == tuple(dims_c) and out.attrs == {"units": "K"} and out.values.dtype == np.float32
+
+    def cols(a):
+        return np.moveaxis(a, 1, -1).reshape(-1, a.shape[1])
+
+    ref = mappm_c.mappm(cols(p), cols(f), cols(p2))
+    np.testing.assert_array_equal(cols(out.values), ref)
+    # a different dim order of the inputs gives the same answer (regridz.py:265-272)
+    out2 = regrid_vertical(DataArray(p, dims=dims_o).transpose("y", "x", "tile", "zaxis_2"), f_in,
+                           DataArray(p2, dims=dims_o).transpose("zaxis_2", "tile", "y", "x"))
+    np.testing.assert_array_equal(out2.values, out.values)
+    with pytest.raises(ValueError, match="must not be equal"):
+        regrid_vertical(DataArray(p, dims=dims_o), f_in, DataArray(p2, dims=dims_o), z_dim_center="z", z_dim_outer="z")
+    with pytest.raises(ValueError, match="one shorter"):
+        regrid_vertical(DataArray(p[:, :-1], dims=dims_o), f_in, DataArray(p2, dims=dims_o))
+    with pytest.raises(ValueError, match="All dimensions except vertical"):
+        regrid_vertical(DataArray(p[:1], dims=dims_o), f_in, DataArray(p2, dims=dims_o))
+
+
+def _squeeze_time(dims, arr):
+    return (np.squeeze(arr, axis=dims.index("Time")), [d for d in dims if d != "Time"]) if "Time" in dims else (arr, list(dims))
+
+
+@pytest.mark.parametrize("tag", ["area-weighted-model-level-without-agrid-winds", "mass-weighted-model-level-with-agrid-winds",
+                                 "pressure-level-with-agrid-winds", "pressure-level-extrapolate-with-agrid-winds"])
+def test_coarsen_restarts_regression_fixtures(tag):
+    """The reference's end-to-end regression of the coarsening path
+    (external/vcm/tests/test_coarsen_restarts.py:108-127), driven through the drop-in API: inputs
+    regenerated by the reference's seed rule, outputs compared with the reference's own fixture
+    values at xr.testing.assert_allclose's defaults."""
+    from fv3net_amd.cubedsphere import edge_weighted_block_average, regrid_to_area_weighted_pressure, weighted_block_average
+
+    meta, expected = cases.load()
+    inp = cases.inputs(meta)
+    f = meta["factor"]
+    plan = cases.plan(tag)
+
+    def da(category, var):
+        dims, arr = inp[category][var]
+        arr, dims = _squeeze_time(dims, arr)
+        return DataArray(arr, dims=dims, name=var)
+
+    def grid(var, ydim, xdim):
+        dims, arr = inp["grid"][var]
+        return DataArray(arr, dims=["tile", ydim, xdim])
+
+    got = {}
+    for category, variables in plan.get("area", {}).items():
+        ydim = "yaxis_2" if category == "fv_core.res" else "yaxis_1"
+        ds = Dataset({v: da(category, v) for v in variables})
+        res = weighted_block_average(ds, grid("area", ydim, "xaxis_1"), f, x_dim="xaxis_1", y_dim=ydim)
+        got.update({(category, v): res[v] for v in variables})
+    delp_core = da("fv_core.res", "delp")
+    for category, variables in plan.get("mass", {}).items():
+        ydim = "yaxis_2" if category == "fv_core.res" else "yaxis_1"
+        delp = delp_core if category == "fv_core.res" else delp_core.rename({"yaxis_2": "yaxis_1"})
+        area = grid("area", ydim, "xaxis_1")
+        mass = DataArray(delp.values * area.values[:, None], dims=delp.dims)  # host-side product of two inputs
+        res = weighted_block_average(Dataset({v: da(category, v) for v in variables}), mass, f, x_dim="xaxis_1", y_dim=ydim)
+        got.update({(category, v): res[v] for v in variables})
+    for category, variables in plan.get("edge_x", {}).items():
+        for v in variables:
+            got[(category, v)] = edge_weighted_block_average(da(category, v), grid("dx", "yaxis_1", "xaxis_1"), f,
+                                                             x_dim="xaxis_1", y_dim="yaxis_1", edge="x")
+    for category, variables in plan.get("edge_y", {}).items():
+        for v in variables:
+            got[(category, v)] = edge_weighted_block_average(da(category, v), grid("dy", "yaxis_2", "xaxis_2"), f,
+                                                             x_dim="xaxis_2", y_dim="yaxis_2", edge="y")
+    for category, variables in plan.get("pressure", {}).items():
+        ydim = "yaxis_2" if category == "fv_core.res" else "yaxis_1"
+        delp = delp_core if category == "fv_core.res" else delp_core.rename({"yaxis_2": "yaxis_1"})
+        area = grid("area", ydim, "xaxis_1")
+        ds = Dataset({v: da(category, v) for v in variables})
+        regridded, masked_area = regrid_to_area_weighted_pressure(ds, delp, area, meta["toa_pressure"], f, x_dim="xaxis_1",
+                                                                  y_dim=ydim, extrapolate=plan["extrapolate"])
+        res = weighted_block_average(regridded, masked_area, f, x_dim="xaxis_1", y_dim=ydim)
+        got.update({(category, v): res[v] for v in variables})
+
+    checked = 0
+    for key, (entry, want) in expected.items():
+        if entry["tag"] != tag:
+            continue
+        want, dims = _squeeze_time(entry["dims"], want)
+        res = got[(entry["category"], entry["variable"])].transpose(*dims).values
+        assert res.shape == want.shape, key
+        assert np.array_equal(np.isnan(res), np.isnan(want)), key
+        if "pressure" in plan and (entry["category"], entry["variable"]) in got and any(
+                entry["variable"] in v for v in plan["pressure"].values()):
+            # Remapped fields: the interface pressures are rounded to float32 inside mappm, and one
+            # float32 ulp of a layer edge moves a layer mean by ~1e-5 x (field contrast / layer
+            # thickness in ulps).  The reference itself notes mappm is not reproducible across
+            # platforms (test_coarsen_restarts.py:119-123); with identical float32 pressures the HIP
+            # remap is bit-identical to the oracle (tests/test_gpu_vertical.py).  Here the coarse
+            # delp differs from numpy's in the last float32 bit of sum(area) (summation order), so
+            # the bar is 1e-5 relative to the field's magnitude.
+            np.testing.assert_allclose(res, want, rtol=1e-5, atol=2e-5 * np.nanmax(np.abs(want)), err_msg=key)
+        else:
+            np.testing.assert_allclose(res, want, rtol=1e-5, atol=1e-8, err_msg=key)
+        checked += 1
+    assert checked >= 6
+
+
+# ------------------------------------------------------------------------------------------------
+# fv3fit predictor
+# ------------------------------------------------------------------------------------------------
+def _dense_model(rng, nz=79, width=12, depth=3, clip=None, limits=None):
+    from fv3net_amd import fit
+
+    names_in, names_out = ["air_temperature", "specific_humidity", "cos_zenith_angle"], ["dQ1", "dQ2"]
+    feats = [nz - ((clip or {}).get(n, slice(0, None)).start or 0) if n in (clip or {}) else (1 if n == "cos_zenith_angle" else nz)
+             for n in names_in]
+    k = sum(feats)
+    hk, hb, fan = [], [], k
+    for _ in range(depth - 1):
+        hk.append((rng.normal(0, 1, (fan, width)) / np.sqrt(fan)).astype(np.float32))
+        hb.append(rng.normal(0, 0.1, width).astype(np.float32))
+        fan = width
+    spec = fit.spec_from_arrays(
+        names_in, [rng.normal(0, 1, n) for n in feats], [rng.uniform(0.5, 2, n) for n in feats], hk, hb, names_out,
+        [(rng.normal(0, 1, (width, nz)) / np.sqrt(width)).astype(np.float32) for _ in names_out],
+        [rng.normal(0, 0.1, nz).astype(np.float32) for _ in names_out],
+        [rng.normal(0, 1, nz) for _ in names_out], [rng.uniform(0.5, 2, nz) for _ in names_out], clip=clip, limits=limits)
+    return fit.HipDenseModel(names_in, names_out, spec, unstacked_dims=("z",))
+
+
+def _state(rng, nz=79, ny=12, nx=12, dtype=np.float64):
+    return Dataset({
+        "air_temperature": DataArray(rng.normal(0, 1, (nz, ny, nx)).astype(dtype), dims=["z", "y", "x"]),
+        "specific_humidity": DataArray(rng.normal(0, 1, (nz, ny, nx)).astype(dtype), dims=["z", "y", "x"]),
+        "cos_zenith_angle": DataArray(rng.uniform(0, 1, (ny, nx)).astype(dtype), dims=["y", "x"]),
+        "unused": DataArray(np.zeros(3), dims=["t"]),
+    })
+
+
+def _oracle_predict(model, X):
+    src = {}
+    for name in model.spec.sources:
+        da = X[name]
+        a = da.transpose(*[d for d in da.dims if d != "z"], *[d for d in da.dims if d == "z"]).values
+        src[name] = a.reshape(-1, a.shape[-1]) if "z" in da.dims else a.reshape(-1, 1)
+    return mlp_np.forward(model.spec, src, dtype=np.float64)
+
+
+def test_predictor_predict_matches_oracle_and_keeps_dims(tmp_path):
+    from fv3net_amd import fit
+
+    rng = np.random.default_rng(0)
+    model = _dense_model(rng)
+    X = _state(rng)
+    before = {k: v.values.copy() for k, v in X.items()}
+    out = model.predict(X)
+    for k in before:  # predict does not mutate its input (test_train.py:332-342)
+        np.testing.assert_array_equal(X[k].values, before[k])
+    assert list(out) == ["dQ1", "dQ2"]
+    truth = _oracle_predict(model, X)
+    for name in out:
+        assert out[name].dims == ("z", "y", "x") and out[name].values.dtype == np.float32
+        got = out[name].values.reshape(79, -1).T
+        assert np.max(np.abs(got - truth[name])) <= 1e-5 * np.max(np.abs(truth[name]))
+    # other dim orders give the same numbers, in the input's order (stacking.py:40-52)
+    Xt = Dataset({k: (v.transpose("y", "x", "z") if "z" in v.dims else v) for k, v in X.items()})
+    out_t = model.predict(Xt)
+    assert out_t["dQ1"].dims == ("y", "x", "z")
+    np.testing.assert_array_equal(out_t["dQ1"].transpose("z", "y", "x").values, out["dQ1"].values)
+    # dump / load preserves the prediction exactly (test_train.py:386-415 asks rtol 1e-3)
+    fit.dump(model, str(tmp_path / "model"))
+    loaded = fit.load(str(tmp_path / "model"))
+    np.testing.assert_array_equal(loaded.predict(X)["dQ2"].values, out["dQ2"].values)
+    with pytest.raises(KeyError):
+        model.predict(Dataset({"air_temperature": X["air_temperature"]}))
+
+
+def test_predictor_with_tile_dim_and_device_resident_inputs():
+    rng = np.random.default_rng(1)
+    model = _dense_model(rng, nz=20, width=8, depth=2)
+    nz, nt, ny, nx = 20, 6, 8, 8
+    host = Dataset({
+        "air_temperature": DataArray(rng.normal(0, 1, (nt, nz, ny, nx)), dims=["tile", "z", "y", "x"]),
+        "specific_humidity": DataArray(rng.normal(0, 1, (nt, nz, ny, nx)), dims=["tile", "z", "y", "x"]),
+        "cos_zenith_angle": DataArray(rng.uniform(0, 1, (nt, ny, nx)), dims=["tile", "y", "x"]),
+    })
+    out = model.predict(host)
+    assert out["dQ1"].dims == ("tile", "z", "y", "x")
+    dev = Dataset({k: DataArray(torch.from_numpy(v.values).cuda(), dims=v.dims) for k, v in host.items()})
+    out_dev = model.predict(dev)
+    assert isinstance(out_dev["dQ1"].data, torch.Tensor) and out_dev["dQ1"].data.is_cuda
+    np.testing.assert_array_equal(out_dev["dQ1"].values, out["dQ1"].values)
+
+
+def test_clipped_levels_are_exactly_zero_and_limits_hold():
+    # test_train.py:418-443: clip config zero-fills clipped output levels
+    rng = np.random.default_rng(2)
+    model = _dense_model(rng, nz=30, clip={"air_temperature": slice(5, None), "dQ1": slice(8, 25)},
+                         limits={"dQ2": (-0.25, None)})
+    X = _state(rng, nz=30)
+    out = model.predict(X)
+    assert np.all(out["dQ1"].values[:8] == 0.0) and np.all(out["dQ1"].values[25:] == 0.0)
+    assert np.any(out["dQ1"].values[8:25] != 0.0)
+    assert out["dQ2"].values.min() >= -0.25 and (out["dQ2"].values == -0.25).any()
+    truth = _oracle_predict(model, X)
+    got = out["dQ1"].values.reshape(30, -1).T
+    assert np.max(np.abs(got - truth["dQ1"])) <= 1e-5 * np.max(np.abs(truth["dQ1"]))
+
+
+def test_offline_training_produces_a_working_predictor():
+    """Train on y = 2*x (an identity-like target, test_train.py:203-249 style) in PyTorch and
+    predict with the HIP kernel; the two must agree and the fit must be reasonable."""
+    from fv3net_amd import fit
+
+    rng = np.random.default_rng(3)
+    nz = 10
+    batches = []
+    for _ in range(4):
+        a = rng.normal(0, 1, (nz, 16, 16)).astype(np.float32)
+        batches.append(Dataset({"a": DataArray(a, dims=["z", "y", "x"]), "b": DataArray(2 * a, dims=["z", "y", "x"])}))
+    hp = fit.DenseHyperparameters(["a"], ["b"], width=32, depth=2, epochs=60, batch_size=256, learning_rate=3e-3)
+    model = fit.train_dense_model(hp, batches)
+    out = model.predict(batches[0])
+    target = batches[0]["b"].values
+    rmse = np.sqrt(np.mean((out["b"].values - target) ** 2))
+    assert rmse < 0.25 * target.std(), rmse
+    model2 = fit.train_dense_model(hp, batches)  # same seed -> same model (test_train.py:316-329)
+    np.testing.assert_array_equal(model2.predict(batches[0])["b"].values, out["b"].values)
+
+
+# ------------------------------------------------------------------------------------------------
+# emulation hook
+# ------------------------------------------------------------------------------------------------
+def test_microphysics_hook_with_hip_emulator(tmp_path):
+    import bench
+    from fv3net_amd.emulation import HipEmulator, MicrophysicsHook
+    from fv3net_amd.mlp import ResidualSpec
+
+    spec = bench.zc_spec(0)
+    spec.residuals = [
+        ResidualSpec("air_temperature_after_gscond", "air_temperature_input", "temperature_gscond_difference"),
+        ResidualSpec("specific_humidity_after_precpd", "specific_humidity_input", "humidity_precpd_difference"),
+    ]
+    emulator = HipEmulator(spec)
+    emulator.dump(str(tmp_path / "emu"))
+    emulator = HipEmulator.load(str(tmp_path / "emu"))
+    n = 2304  # one C384 rank with a 48 x 48 subdomain
+    src_sf = bench.zc_inputs_numpy(np.random.default_rng(5), n)
+    # the Fortran state: [feature, sample] float64 arrays plus scalars
+    state = {k: np.ascontiguousarray(v.T.astype(np.float64)) for k, v in src_sf.items()}
+    state["model_time"] = [2016, 8, 1, 0, 15, 0]
+    state["rank"] = 3
+    inputs_before = {k: v.copy() for k, v in state.items() if isinstance(v, np.ndarray)}
+    hook = MicrophysicsHook(emulator)
+    assert hook.microphysics(state) is None
+    for k, v in inputs_before.items():
+        np.testing.assert_array_equal(state[k], v)
+    truth = mlp_np.forward(spec, {k: v.astype(np.float64) for k, v in src_sf.items()}, dtype=np.float64)
+    for name, want in truth.items():
+        got = state[name]
+        assert got.shape == (want.shape[1], n) and got.flags.c_contiguous  # [feature, sample]
+        assert np.max(np.abs(got.T - want)) <= 1e-5 * np.max(np.abs(want)), name
+    assert state["rank"] == 3

@@ -1,0 +1,189 @@
+"""Host-side logic that needs no GPU: the C ABI exports what the header declares, the labelled
+array layer, coordinate coarsening, the model io registry, spec (de)serialisation, the hook's
+in-place contract, the partitioning helpers, and that the product path refuses to run without a
+GPU instead of falling back."""
+import os
+import re
+
+import numpy as np
+import pytest
+import torch
+
+import fv3net_amd
+from fv3net_amd import _lib
+from fv3net_amd.xr_compat import DataArray, Dataset, assert_identical_including_dtype
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def test_library_exports_every_symbol_in_the_header():
+    header = open(os.path.join(ROOT, "include", "fv3hip.h")).read()
+    declared = set(re.findall(r"\b(fv3hip_[a-z_0-9]+)\s*\(", header))
+    assert declared == set(_lib.SIGNATURES), declared ^ set(_lib.SIGNATURES)
+    lib = _lib.load()
+    for name in declared:
+        assert hasattr(lib, name), name
+    assert lib.fv3hip_abi_version() == 1
+    assert lib.fv3hip_mappm_workspace_bytes(10, 79) == 5 * 79 * 10 * 4
+
+
+def test_library_reports_errors_without_touching_the_gpu():
+    lib = _lib.load()
+    rc = lib.fv3hip_weighted_block_average(None, 7, None, 0, 1, 4, 4, 1, 2, None, None)
+    assert rc == _lib.EINVAL
+    assert b"dtype" in lib.fv3hip_last_error()
+    rc = lib.fv3hip_mappm(None, None, None, 0, None, 1, 1, 79, 79, 1, 9, 0, None, 0, None)
+    assert rc == _lib.EUNSUPPORTED and b"cs_profile" in lib.fv3hip_last_error()
+
+
+@pytest.mark.skipif(torch.cuda.is_available(), reason="checks the no-GPU behaviour")
+def test_no_cpu_fallback():
+    from fv3net_amd import mappm, ops
+    from fv3net_amd.cubedsphere import weighted_block_average
+
+    with pytest.raises(RuntimeError, match="no CPU fallback"):
+        ops.weighted_block_average(torch.zeros(4, 4), torch.zeros(4, 4), 2)
+    da = DataArray(np.zeros((4, 4)), dims=["y", "x"])
+    with pytest.raises(RuntimeError, match="no CPU fallback"):
+        weighted_block_average(da, da, 2, x_dim="x", y_dim="y")
+    with pytest.raises(RuntimeError, match="no CPU fallback"):
+        mappm.mappm(np.zeros((1, 6)), np.zeros((1, 5)), np.zeros((1, 6)), 1, 1, 1, 1, 0.0)
+
+
+def test_dataarray_basics():
+    da = DataArray(np.arange(24.0).reshape(2, 3, 4), dims=["t", "y", "x"], coords={"x": [1.0, 2, 3, 4]}, name="foo",
+                   attrs={"units": "m"})
+    assert da.sizes == {"t": 2, "y": 3, "x": 4}
+    tr = da.transpose("x", "t", "y")
+    assert tr.dims == ("x", "t", "y") and tr.shape == (4, 2, 3) and tr.attrs == {"units": "m"}
+    assert da.transpose("x", ...).dims == ("x", "t", "y")
+    sel = da.isel(t=0, x=slice(1, 3))
+    assert sel.dims == ("y", "x") and list(sel.coords["x"]) == [2.0, 3.0]
+    ds = da.to_dataset()
+    assert list(ds) == ["foo"] and ds.dims == {"t": 2, "y": 3, "x": 4}
+    assert da.rename("bar").name == "bar" and da.rename({"x": "lon"}).dims == ("t", "y", "lon")
+    with pytest.raises(ValueError):
+        DataArray(np.zeros((2, 2)), dims=["a"])
+    assert_identical_including_dtype(da, da.copy())
+
+
+def test_coordinate_coarsening():
+    from fv3net_amd.cubedsphere import add_coordinates, coarsen_coords, coarsen_coords_coord_func
+
+    # external/vcm/tests/test_cubedsphere.py:422-616: subtile coordinates, float32 and float64
+    for dtype in (np.float32, np.float64):
+        for start in (1, 49, 97):
+            c = np.arange(start, start + 48, dtype=dtype)
+            ref = DataArray(np.zeros(48), dims=["x"], coords={"x": c})
+            out = coarsen_coords(2, ref, ["x"])["x"]
+            assert out.dtype == np.float32
+            np.testing.assert_array_equal(out, np.arange((start - 1) // 2 + 1, (start - 1) // 2 + 25))
+            np.testing.assert_array_equal(coarsen_coords_coord_func(c.reshape(-1, 2)), out)
+    coarse = DataArray(np.zeros(24), dims=["x"], name="a")
+    ref = DataArray(np.zeros(48), dims=["x"], coords={"x": np.arange(1, 49, dtype=np.float32)})
+    assert add_coordinates(ref, coarse, 2, ["x"]).coords["x"][-1] == 24.0
+
+
+def test_io_registry_and_constant_predictor(tmp_path):
+    from fv3net_amd import fit
+
+    model = fit.ConstantOutputPredictor(["air_temperature"], ["dQ1", "rain"])
+    model.set_outputs(dQ1=np.arange(5.0), rain=2.5)
+    fit.dump(model, str(tmp_path / "m"))
+    assert (tmp_path / "m" / "name").read_text() == "constant-output"
+    loaded = fit.load(str(tmp_path / "m"))
+    X = Dataset({"air_temperature": DataArray(np.zeros((5, 3, 4)), dims=["z", "y", "x"])})
+    out = loaded.predict(X)
+    assert out["dQ1"].dims == ("z", "y", "x") and out["rain"].dims == ("y", "x")
+    np.testing.assert_array_equal(out["dQ1"].values[:, 1, 2], np.arange(5.0))
+    assert float(out["rain"].values[0, 0]) == 2.5
+    with pytest.raises(ValueError, match="already registered"):
+        fit.io.register("constant-output")
+    (tmp_path / "tf").mkdir()
+    (tmp_path / "tf" / "name").write_text("all-keras")
+    with pytest.raises(ValueError, match="TensorFlow"):
+        fit.load(str(tmp_path / "tf"))
+
+
+def _spec(rng):
+    from fv3net_amd.mlp import InputSpec, MlpSpec, OutputSpec, ResidualSpec
+
+    return MlpSpec(
+        inputs=[InputSpec("T", 5, center=rng.normal(size=5), scale=rng.uniform(1, 2, 5)),
+                InputSpec("q", 3, start=2, transform="log", eps=1e-8)],
+        hidden_kernels=[rng.normal(size=(8, 4)).astype(np.float32)], hidden_biases=[np.zeros(4, np.float32)],
+        outputs=[OutputSpec("dQ1", 5, scale=np.ones(5), center=np.zeros(5), min=-1.0, mask=np.array([0, 1, 1, 1, 1.0]))],
+        out_kernel=rng.normal(size=(4, 5)).astype(np.float32), out_bias=np.zeros(5, np.float32),
+        residuals=[ResidualSpec("T_after", "T", "dQ1")],
+    )
+
+
+def test_spec_roundtrip_and_validation(tmp_path):
+    from fv3net_amd import fit
+    from fv3net_amd.mlp import MlpSpec
+
+    spec = _spec(np.random.default_rng(0))
+    spec.validate()
+    assert spec.sources == ["T", "q"] and spec.source_nfeat() == {"T": 5, "q": 5}
+    assert spec.output_names == ["dQ1", "T_after"]
+    model = fit.HipDenseModel(["T", "q"], ["dQ1"], spec)
+    fit.dump(model, str(tmp_path / "m"))
+    assert (tmp_path / "m" / "name").read_text() == "hip-dense"
+    back = fit.load(str(tmp_path / "m"))
+    assert back.input_variables == ["T", "q"] and back.output_variables == ["dQ1"]
+    m1, a1 = spec.to_arrays()
+    m2, a2 = back.spec.to_arrays()
+    assert m1 == m2 and set(a1) == set(a2)
+    for k in a1:
+        np.testing.assert_array_equal(a1[k], a2[k])
+    bad = _spec(np.random.default_rng(0))
+    bad.out_kernel = bad.out_kernel[:, :3]
+    with pytest.raises(ValueError):
+        bad.validate()
+    with pytest.raises(ValueError, match="not produced"):
+        fit.HipDenseModel(["T"], ["nope"], spec)
+
+
+def test_hook_updates_state_in_place():
+    # external/emulation/tests/test_microphysics.py:21-44: an "x + 1" model, [feature, sample] arrays
+    from fv3net_amd.emulation import MicrophysicsHook
+
+    def model(x):
+        return {"air_temperature_output": x["air_temperature_input"] + 1}
+
+    state = {"air_temperature_input": np.arange(6.0).reshape(3, 2), "model_time": [2016, 8, 1, 0, 0, 0], "rank": 0}
+    hook = MicrophysicsHook(model)
+    assert hook.microphysics(state) is None
+    assert state["air_temperature_output"].shape == (3, 2)
+    np.testing.assert_array_equal(state["air_temperature_output"], np.arange(6.0).reshape(3, 2) + 1)
+    assert state["model_time"] == [2016, 8, 1, 0, 0, 0]
+
+
+def test_emulation_config(tmp_path):
+    from fv3net_amd.emulation.config import EmulationConfig, get_hooks
+
+    gscond, micro, store = get_hooks(str(tmp_path / "missing.yml"))
+    state = {"a": np.zeros(3)}
+    assert micro(state) is None and gscond(state) is None and store(state) is None and list(state) == ["a"]
+    with pytest.raises(NotImplementedError, match="cloud_squash"):
+        EmulationConfig.from_dict({"model": {"path": "x", "cloud_squash": 1e-6}})
+    with pytest.raises(ValueError, match="unknown"):
+        EmulationConfig.from_dict({"model": {"pth": "x"}})
+
+
+def test_partitioning():
+    from fv3net_amd import parallel
+
+    for n, w in [(884736, 8), (10, 3), (5, 8)]:
+        ranges = [parallel.column_range(n, w, r) for r in range(w)]
+        assert ranges[0][0] == 0 and ranges[-1][1] == n
+        assert all(a[1] == b[0] for a, b in zip(ranges, ranges[1:]))
+        sizes = [b - a for a, b in ranges]
+        assert max(sizes) - min(sizes) <= 1
+    units = parallel.tile_bands(6, 3072, 8, 8)
+    assert [len(u) for u in units] == [3] * 8
+    flat = sorted(u for r in units for u in r)
+    assert flat[0] == (0, 0, 768) and all((hi - lo) % 8 == 0 for _, lo, hi in flat)
+    assert sum(hi - lo for _, lo, hi in flat) == 6 * 3072
+    assert [len(u) for u in parallel.tile_bands(6, 384, 8, 6)] == [1] * 6
+    assert parallel.world() == (0, 1)
