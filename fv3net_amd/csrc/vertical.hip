@@ -141,33 +141,39 @@ __device__ __forceinline__ void ppm_limiters1(float dm, float a1, float &a2, flo
     }
 }
 
-template <typename Tin>
-__global__ __launch_bounds__(256) void mappm_simple_kernel(
-    const Tin *__restrict__ pe1_, const Tin *__restrict__ q1_, const Tin *__restrict__ pe2_,
-    float *__restrict__ q2_, int64_t col0, int64_t col_end, int64_t n_inner, int km, int kn, int iv,
-    int kord, int layout, float *__restrict__ ws, int64_t ws_cols)
-{
-    const int64_t lc = blockIdx.x * (int64_t)blockDim.x + threadIdx.x;  // column inside the chunk
-    const int64_t col = col0 + lc;
-    if (col >= col_end) return;
+// element (column, level k) of an array with `nlev` levels lives at base + (k-1)*ks
+struct ColumnAddr {
+    int64_t ks, o_pe1, o_q1, o_pe2, o_q2;
+};
 
-    // element (column, level k) of an array with `nlev` levels lives at base + (k-1)*ks
-    int64_t ks;
-    int64_t o_pe1, o_q1, o_pe2, o_q2;
+__device__ __forceinline__ ColumnAddr column_addr(int64_t col, int64_t n_inner, int km, int kn, int layout)
+{
+    ColumnAddr a;
     if (layout == FV3HIP_LAYOUT_COL_LEVEL) {
-        ks = 1;
-        o_pe1 = col * (km + 1);
-        o_q1 = col * km;
-        o_pe2 = col * (kn + 1);
-        o_q2 = col * kn;
+        a.ks = 1;
+        a.o_pe1 = col * (km + 1);
+        a.o_q1 = col * km;
+        a.o_pe2 = col * (kn + 1);
+        a.o_q2 = col * kn;
     } else {
-        ks = n_inner;
+        a.ks = n_inner;
         const int64_t b = col / n_inner, c = col % n_inner;
-        o_pe1 = b * (km + 1) * n_inner + c;
-        o_q1 = b * km * n_inner + c;
-        o_pe2 = b * (kn + 1) * n_inner + c;
-        o_q2 = b * kn * n_inner + c;
+        a.o_pe1 = b * (km + 1) * n_inner + c;
+        a.o_q1 = b * km * n_inner + c;
+        a.o_pe2 = b * (kn + 1) * n_inner + c;
+        a.o_q2 = b * kn * n_inner + c;
     }
+    return a;
+}
+
+// One column, the Fortran control flow verbatim (all iv, kord <= 7, any input whatsoever).
+template <typename Tin>
+__device__ __noinline__ void mappm_column_exact(const Tin *__restrict__ pe1_, const Tin *__restrict__ q1_,
+                                                const Tin *__restrict__ pe2_, float *__restrict__ q2_,
+                                                const ColumnAddr addr, int km, int kn, int iv, int kord,
+                                                float *__restrict__ ws, int64_t lc, int64_t ws_cols)
+{
+    const int64_t ks = addr.ks, o_pe1 = addr.o_pe1, o_q1 = addr.o_q1, o_pe2 = addr.o_pe2, o_q2 = addr.o_q2;
     auto PE1 = [&](int k) { return (float)pe1_[o_pe1 + (int64_t)(k - 1) * ks]; };
     auto Q = [&](int k) { return (float)q1_[o_q1 + (int64_t)(k - 1) * ks]; };
     auto PE2 = [&](int k) { return (float)pe2_[o_pe2 + (int64_t)(k - 1) * ks]; };
@@ -361,8 +367,276 @@ __global__ __launch_bounds__(256) void mappm_simple_kernel(
 #undef W_
 }
 
+template <typename Tin>
+__global__ __launch_bounds__(256) void mappm_simple_kernel(
+    const Tin *__restrict__ pe1_, const Tin *__restrict__ q1_, const Tin *__restrict__ pe2_,
+    float *__restrict__ q2_, int64_t col0, int64_t col_end, int64_t n_inner, int km, int kn, int iv,
+    int kord, int layout, float *__restrict__ ws, int64_t ws_cols)
+{
+    const int64_t lc = blockIdx.x * (int64_t)blockDim.x + threadIdx.x;  // column inside the chunk
+    const int64_t col = col0 + lc;
+    if (col >= col_end) return;
+    mappm_column_exact<Tin>(pe1_, q1_, pe2_, q2_, column_addr(col, n_inner, km, kn, layout), km, kn, iv, kord,
+                            ws, lc, ws_cols);
+}
+
+// ---------------------------------------------------------------------------------------
+// mappm, fast path (kord <= 6, km >= 8): one thread per column, no workspace traffic.
+//
+// The Fortran walks TARGET layers and, for each, searches and integrates over source layers,
+// reading a4(2:4, L) at a data-dependent L.  Here the sweep is SOURCE-layer major: the wave
+// marches L = 1..km together, the PPM reconstruction of layer L lives in a register sliding
+// window (every pe1/q1 load is a coalesced row, each value loaded once), and each lane emits
+// the target layers that end inside layer L (a two-pointer merge; only the pe2 loads and q2
+// stores are at a per-lane level).  For every (target k, source L) pair the same tests are made
+// in the same order with the same single-precision expressions as mappm.f90:58-124, so for
+// columns whose pe1 and pe2 are finite and non-decreasing the result is bit-identical to the
+// sequential routine.  A lane that meets anything else (NaN or non-monotone pressures, a
+// top-edge search that finds no layer) reruns its column through mappm_column_exact.
+// ---------------------------------------------------------------------------------------
+template <typename Tin>
+__global__ __launch_bounds__(256) void mappm_merge_kernel(
+    const Tin *__restrict__ pe1_, const Tin *__restrict__ q1_, const Tin *__restrict__ pe2_,
+    float *__restrict__ q2_, int64_t col0, int64_t col_end, int64_t n_inner, int km, int kn, int iv,
+    int kord, int layout, unsigned int *__restrict__ n_bad, unsigned int *__restrict__ bad_cols)
+{
+    const int64_t lc = blockIdx.x * (int64_t)blockDim.x + threadIdx.x;
+    const int64_t col = col0 + lc;
+    if (col >= col_end) return;
+    const ColumnAddr addr = column_addr(col, n_inner, km, kn, layout);
+    const int64_t ks = addr.ks;
+    const Tin *pp1 = pe1_ + addr.o_pe1, *pq1 = q1_ + addr.o_q1, *pp2 = pe2_ + addr.o_pe2;
+    float *pq2 = q2_ + addr.o_q2;
+    auto PE1 = [&](int k) { return (float)pp1[(int64_t)(k - 1) * ks]; };
+    auto Q = [&](int k) { return (float)pq1[(int64_t)(k - 1) * ks]; };
+    auto PE2 = [&](int k) { return (float)pp2[(int64_t)(k - 1) * ks]; };
+    auto OUT = [&](int k, float v) { pq2[(int64_t)(k - 1) * ks] = v; };
+
+    const int km1 = km - 1;
+    int lmt_int = kord - 3;
+    lmt_int = (lmt_int > 0) ? lmt_int : 0;
+    if (iv == 0) lmt_int = (lmt_int < 2) ? lmt_int : 2;
+    const bool int_recompute_a6 = (kord != 4), int_limit = (kord != 6);
+    const float r3 = 1.f / 3.f, r23 = 2.f / 3.f;
+
+    // ---- head of the column: pe1(1..5), q1(1..4), and the two values the pre-checks need ----
+    float pe_a = PE1(1), pe_b = PE1(2), pe_c = PE1(3), pe_d = PE1(4), pe_e = PE1(5);
+    float q0 = Q(1), qp1 = Q(2), qp2 = Q(3), qp3 = Q(4);
+    const float pe1_top = pe_a, pe1_bot = PE1(km + 1), q_top = q0, q_bot = Q(km);
+    bool bad = !(pe_b >= pe_a) | !(pe_c >= pe_b) | !(pe_d >= pe_c) | !(pe_e >= pe_d);
+    float d0 = pe_b - pe_a, dp1 = pe_c - pe_b, dp2 = pe_d - pe_c, dp3 = pe_e - pe_d;  // dp(L..L+3)
+    float dm1 = 0.f, qm1 = 0.f;                                                       // dp(L-1), q(L-1)
+
+    // dc(k) for 2 <= k <= km-1 (mappm.f90:658-668) from the values around level k
+    auto DCI = [&](float dpa, float dpb, float dpc, float qa, float qb, float qc) {
+        const float d4b = dpa + dpb, d4c = dpb + dpc;  // d4(k), d4(k+1)
+        const float c1 = (dpa + 0.5f * dpb) / d4c;
+        const float c2 = (dpc + 0.5f * dpb) / d4b;
+        const float df2 = dpb * (c1 * (qc - qb) + c2 * (qb - qa)) / (d4b + dpc);
+        return f_sign(f_min3(fabsf(df2), f_max3(qa, qb, qc) - qb, qb - f_min3(qa, qb, qc)), df2);
+    };
+    // a4(2,k) for 3 <= k <= km-1 (mappm.f90:674-683): dpz..dpc = dp(k-2..k+1), qa = q(k-1), qb = q(k)
+    auto INT = [&](float dpz, float dpa, float dpb, float dpc, float qa, float qb, float dca, float dcb) {
+        const float d4a = dpz + dpa, d4b = dpa + dpb, d4c = dpb + dpc;  // d4(k-1), d4(k), d4(k+1)
+        const float c1 = (qb - qa) * dpa / d4b;
+        const float a1 = d4a / (d4b + dpa);
+        const float a2 = d4c / (d4b + dpb);
+        return qa + c1 + 2.f / (d4a + d4c) * (dpb * (c1 * (a1 - a2) + a2 * dca) - dpa * a1 * dcb);
+    };
+
+    // ---- prologue: dc(2), dc(3), al(3), then the top boundary (mappm.f90:689-725) ----
+    float dc1 = DCI(d0, dp1, dp2, q0, qp1, qp2);                 // dc(2)
+    const float dc_3 = DCI(dp1, dp2, dp3, qp1, qp2, qp3);        // dc(3)
+    const float al_3 = INT(d0, dp1, dp2, dp3, qp1, qp2, dc1, dc_3);
+    float al0, al1, dc0, ar_km = 0.f;
+    {
+        const float d1 = d0, d2 = dp1;
+        const float qm = (d2 * q0 + d1 * qp1) / (d1 + d2);
+        const float dq = 2.f * (qp1 - q0) / (d1 + d2);
+        const float c1 = 4.f * (al_3 - qm - d2 * dq) / (d2 * (2.f * d2 * d2 + d1 * (d2 + 3.f * d1)));
+        const float c3 = dq - 0.5f * c1 * (d2 * (5.f * d1 + d2) - 3.f * d1 * d1);
+        float a2 = qm - 0.25f * c1 * d1 * d2 * (d2 + 3.f * d1);
+        float a1 = d1 * (2.f * c1 * (d1 * d1) - c3) + a2;
+        a2 = f_max2(a2, f_min2(q0, qp1));
+        a2 = f_min2(a2, f_max2(q0, qp1));
+        dc0 = 0.5f * (a2 - q0);
+        if (iv == 0) {
+            a1 = f_max2(0.f, a1);
+            a2 = f_max2(0.f, a2);
+        } else if (iv == -1) {
+            if (a1 * q0 <= 0.f) a1 = 0.f;
+        } else if (iv == 2 || iv == -2) {
+            a1 = q0;
+        }
+        al0 = a1;
+        al1 = a2;
+    }
+
+    // ---- per-lane target cursor ----
+    int k = 1;
+    float p2k = PE2(1), p2k1 = PE2(2), p2k2 = PE2(kn >= 2 ? 3 : 2);  // pe2(k), pe2(k+1), pe2(k+2)
+    bool accum = false;
+    float qsum = 0.f, dpsum = 0.f;
+    auto advance = [&]() {  // the load for two targets ahead is issued here, used two advances later
+        ++k;
+        p2k = p2k1;
+        p2k1 = p2k2;
+        if (k + 2 <= kn + 1) p2k2 = PE2(k + 2);
+    };
+    // consume the targets the pre-checks decide (above the old top / below the old surface)
+    auto settle = [&]() {
+        while (k <= kn) {
+            if (!(p2k1 >= p2k)) bad = true;
+            if (bad) {
+                k = kn + 1;
+                break;
+            }
+            if (p2k <= pe1_top)
+                OUT(k, q_top);
+            else if (p2k >= pe1_bot)
+                OUT(k, q_bot);
+            else
+                break;
+            advance();
+        }
+    };
+    settle();
+
+    for (int L = 1; L <= km; ++L) {
+        const bool edge = (L <= 2) | (L >= km1);
+        // ---- finalise layer L: A6 and the limiter (mappm.f90:773-849) ----
+        float al = al0, ar = (L == km) ? ar_km : al1, a6 = 0.f;
+        if (edge | int_recompute_a6) a6 = 3.f * (2.f * q0 - (al + ar));
+        if (edge | int_limit) ppm_limiters1(dc0, q0, al, ar, a6, edge ? 0 : lmt_int);
+        const float pL = pe_a, pL1 = pe_b;
+
+        // ---- emit the target layers that can be decided inside layer L ----
+        while (k <= kn) {
+            if (!accum) {
+                if (p2k >= pL && p2k <= pL1) {
+                    const float PL = (p2k - pL) / d0;
+                    if (p2k1 <= pL1) {
+                        const float PR = (p2k1 - pL) / d0;
+                        const float TT = r3 * (PR * (PR + PL) + PL * PL);
+                        OUT(k, al + 0.5f * (a6 + ar - al) * (PR + PL) - a6 * TT);
+                        advance();
+                        settle();
+                    } else {
+                        const float delp = pL1 - p2k;
+                        const float TT = r3 * (1.f + PL * (1.f + PL));
+                        qsum = delp * (al + 0.5f * (a6 + ar - al) * (1.f + PL) - a6 * TT);
+                        dpsum = delp;
+                        accum = true;
+                        break;
+                    }
+                } else {
+                    break;
+                }
+            } else {
+                if (p2k1 > pL1) {
+                    qsum = qsum + d0 * q0;
+                    dpsum = dpsum + d0;
+                    break;
+                } else {
+                    const float delp = p2k1 - pL;
+                    const float esl = delp / d0;
+                    qsum = qsum + delp * (al + 0.5f * esl * (ar - al + a6 * (1.f - r23 * esl)));
+                    dpsum = dpsum + delp;
+                    OUT(k, qsum / dpsum);
+                    accum = false;
+                    advance();
+                    settle();
+                }
+            }
+        }
+
+        // ---- slide the window: reconstruction of level L+2 ----
+        float al2 = 0.f, dc2 = 0.f, q_new = 0.f, pe_new = pe_e;
+        const int kk = L + 2;
+        if (L + 4 <= km) {  // the values that enter the window after the shift: q(L+4), pe1(L+5)
+            q_new = Q(L + 4);
+            pe_new = PE1(L + 5);
+            if (!(pe_new >= pe_e)) bad = true;
+        }
+        if (kk >= 3 && kk <= km1) {
+            // window now: dm1,d0,dp1,dp2,dp3 = dp(L-1..L+3); q0,qp1,qp2,qp3 = q(L..L+3)
+            dc2 = DCI(dp1, dp2, dp3, qp1, qp2, qp3);                       // dc(L+2)
+            // dc(L+1): dc1 is dc(L+1) for L >= 1 (set below / by the prologue)
+            al2 = INT(d0, dp1, dp2, dp3, qp1, qp2, dc1, dc2);              // al(L+2)
+        } else if (kk == km) {
+            // bottom boundary (mappm.f90:729-761): al(km), ar(km), dc(km) from al(km-1) = al1
+            const float d1 = dp2, d2 = dp1;            // dp(km), dp(km-1)
+            const float qk = qp2, qk1 = qp1;           // q(km), q(km-1)
+            const float qm = (d2 * qk + d1 * qk1) / (d1 + d2);
+            const float dq = 2.f * (qk1 - qk) / (d1 + d2);
+            const float c1 = (al1 - qm - d2 * dq) / (d2 * (2.f * d2 * d2 + d1 * (d2 + 3.f * d1)));
+            const float c3 = dq - 2.0f * c1 * (d2 * (5.f * d1 + d2) - 3.f * d1 * d1);
+            float alk = qm - c1 * d1 * d2 * (d2 + 3.f * d1);
+            float ark = d1 * (8.f * c1 * (d1 * d1) - c3) + alk;
+            alk = f_max2(alk, f_min2(qk, qk1));
+            alk = f_min2(alk, f_max2(qk, qk1));
+            dc2 = 0.5f * (qk - alk);
+            if (iv == 0) {
+                alk = f_max2(0.f, alk);
+                ark = f_max2(0.f, ark);
+            } else if (iv < 0) {
+                if (qk * ark <= 0.f) ark = 0.f;
+            }
+            al2 = alk;
+            ar_km = ark;
+        }
+        // shift: level L+1 becomes the current one
+        qm1 = q0; q0 = qp1; qp1 = qp2; qp2 = qp3; qp3 = q_new;
+        dm1 = d0; d0 = dp1; dp1 = dp2; dp2 = dp3; dp3 = pe_new - pe_e;
+        pe_a = pe_b; pe_b = pe_c; pe_c = pe_d; pe_d = pe_e; pe_e = pe_new;
+        al0 = al1; al1 = al2;
+        dc0 = dc1; dc1 = dc2;
+    }
+    (void)qm1;
+    (void)dm1;
+
+    // ---- past the old surface (mappm.f90:115-121) ----
+    if (k <= kn && accum) {
+        const float delp = p2k1 - pe1_bot;
+        if (delp > 0.f) {
+            qsum = qsum + delp * q_bot;
+            dpsum = dpsum + delp;
+        }
+        OUT(k, qsum / dpsum);
+        accum = false;
+        advance();
+        settle();
+    }
+    if (k <= kn) bad = true;  // a top-edge search that no source layer satisfied
+    if (bad) bad_cols[atomicAdd(n_bad, 1u)] = (unsigned int)lc;  // redone by mappm_fallback_kernel
+}
+
+// The columns the merge sweep gave up on (listed by their index inside the chunk), through the
+// sequential routine.  Launched after every merge launch; exits at once when the list is empty.
+template <typename Tin>
+__global__ __launch_bounds__(256) void mappm_fallback_kernel(
+    const Tin *__restrict__ pe1_, const Tin *__restrict__ q1_, const Tin *__restrict__ pe2_,
+    float *__restrict__ q2_, int64_t col0, int64_t n_inner, int km, int kn, int iv, int kord, int layout,
+    const unsigned int *__restrict__ n_bad, const unsigned int *__restrict__ bad_cols,
+    float *__restrict__ ws, int64_t ws_cols)
+{
+    const unsigned int count = *n_bad;
+    const int64_t slot = blockIdx.x * (int64_t)blockDim.x + threadIdx.x;
+    for (int64_t i = slot; i < count; i += (int64_t)gridDim.x * blockDim.x) {
+        const int64_t col = col0 + bad_cols[i];
+        mappm_column_exact<Tin>(pe1_, q1_, pe2_, q2_, column_addr(col, n_inner, km, kn, layout), km, kn, iv,
+                                kord, ws, slot, ws_cols);
+    }
+}
+
 constexpr int64_t kMappmChunk = 1 << 20;  // columns per launch; bounds the workspace
 constexpr int kMappmPlanes = 5;           // AL, AR, A6, DC, H2
+constexpr int64_t kFallbackSlots = 256 * 256;  // threads (= reconstruction slots) of the fallback pass
+constexpr size_t kCounterBytes = 256;
+
+// workspace: [counter][bad-column list: chunk x u32][5 planes x km x slots floats]
+inline int64_t ws_slots(int64_t ncol) { return ncol < kMappmChunk ? ncol : kMappmChunk; }
+inline size_t ws_list_bytes(int64_t ncol) { return ((size_t)ws_slots(ncol) * 4 + 255) & ~(size_t)255; }
 
 }  // namespace
 }  // namespace fv3hip
@@ -446,8 +720,7 @@ extern "C" int fv3hip_mask_weights(const void *weights, int w_dtype, const void 
 extern "C" size_t fv3hip_mappm_workspace_bytes(int64_t ncol, int km)
 {
     if (ncol <= 0 || km <= 0) return 0;
-    const int64_t cols = ncol < kMappmChunk ? ncol : kMappmChunk;
-    return (size_t)kMappmPlanes * (size_t)km * (size_t)cols * sizeof(float);
+    return kCounterBytes + ws_list_bytes(ncol) + (size_t)kMappmPlanes * (size_t)km * (size_t)ws_slots(ncol) * sizeof(float);
 }
 
 extern "C" int fv3hip_mappm(const void *pe1, const void *q1, const void *pe2, int in_dtype, float *q2,
@@ -469,21 +742,39 @@ extern "C" int fv3hip_mappm(const void *pe1, const void *q1, const void *pe2, in
     FV3HIP_REQUIRE(workspace && workspace_bytes >= fv3hip_mappm_workspace_bytes(ncol, km),
                    "workspace too small: need %zu bytes, got %zu", fv3hip_mappm_workspace_bytes(ncol, km), workspace_bytes);
     hipStream_t st = as_stream(stream);
-    const int64_t ws_cols = ncol < kMappmChunk ? ncol : kMappmChunk;
+    const int64_t ws_cols = ws_slots(ncol);
+    unsigned int *n_bad = static_cast<unsigned int *>(workspace);
+    unsigned int *bad_cols = reinterpret_cast<unsigned int *>(static_cast<char *>(workspace) + kCounterBytes);
+    float *planes = reinterpret_cast<float *>(static_cast<char *>(workspace) + kCounterBytes + ws_list_bytes(ncol));
+    // kord <= 6: the register-window merge sweep, then the (normally empty) list of columns it gave
+    // up on through the sequential routine; kord == 7 (Huynh's constraint needs a wider stencil)
+    // goes through the sequential routine directly
+    const bool fast = (kord <= 6);
     for (int64_t col0 = 0; col0 < ncol; col0 += kMappmChunk) {
         const int64_t col_end = (col0 + kMappmChunk < ncol) ? col0 + kMappmChunk : ncol;
         const int64_t blocks = ceil_div(col_end - col0, 256);
-        if (in_dtype == FV3HIP_F32)
-            hipLaunchKernelGGL((mappm_simple_kernel<float>), dim3((unsigned)blocks), dim3(256), 0, st,
-                               static_cast<const float *>(pe1), static_cast<const float *>(q1),
-                               static_cast<const float *>(pe2), q2, col0, col_end, n_inner, km, kn, iv,
-                               kord, layout, static_cast<float *>(workspace), ws_cols);
-        else
-            hipLaunchKernelGGL((mappm_simple_kernel<double>), dim3((unsigned)blocks), dim3(256), 0, st,
-                               static_cast<const double *>(pe1), static_cast<const double *>(q1),
-                               static_cast<const double *>(pe2), q2, col0, col_end, n_inner, km, kn,
-                               iv, kord, layout, static_cast<float *>(workspace), ws_cols);
-        int rc = check_launch("mappm_simple_kernel");
+        if (fast) {
+            FV3HIP_CHECK_HIP(hipMemsetAsync(n_bad, 0, 16, st));
+            const int64_t fb_threads = (col_end - col0 < kFallbackSlots) ? (col_end - col0) : kFallbackSlots;
+            const int64_t fb_blocks = ceil_div(fb_threads, 256);
+#define LAUNCH_(T)                                                                                       \
+    hipLaunchKernelGGL((mappm_merge_kernel<T>), dim3((unsigned)blocks), dim3(256), 0, st,                \
+                       static_cast<const T *>(pe1), static_cast<const T *>(q1), static_cast<const T *>(pe2), \
+                       q2, col0, col_end, n_inner, km, kn, iv, kord, layout, n_bad, bad_cols);           \
+    hipLaunchKernelGGL((mappm_fallback_kernel<T>), dim3((unsigned)fb_blocks), dim3(256), 0, st,          \
+                       static_cast<const T *>(pe1), static_cast<const T *>(q1), static_cast<const T *>(pe2), \
+                       q2, col0, n_inner, km, kn, iv, kord, layout, n_bad, bad_cols, planes, ws_cols)
+            if (in_dtype == FV3HIP_F32) { LAUNCH_(float); } else { LAUNCH_(double); }
+#undef LAUNCH_
+        } else {
+#define LAUNCH_(T)                                                                                       \
+    hipLaunchKernelGGL((mappm_simple_kernel<T>), dim3((unsigned)blocks), dim3(256), 0, st,               \
+                       static_cast<const T *>(pe1), static_cast<const T *>(q1), static_cast<const T *>(pe2), \
+                       q2, col0, col_end, n_inner, km, kn, iv, kord, layout, planes, ws_cols)
+            if (in_dtype == FV3HIP_F32) { LAUNCH_(float); } else { LAUNCH_(double); }
+#undef LAUNCH_
+        }
+        int rc = check_launch("mappm kernel");
         if (rc) return rc;
     }
     return FV3HIP_OK;

@@ -197,3 +197,41 @@ def test_full_size_c384_mappm(device):
 
     ref = mappm_c.mappm(cols(pe1), cols(q), cols(pe2))
     assert _bits_equal(cols(r), ref)
+
+
+def test_mappm_ill_formed_columns_take_the_sequential_path(device):
+    """Columns with non-monotone or NaN pressures leave the merge sweep and are redone by the
+    sequential routine; the rest of the batch is unaffected.  Everything stays bit-identical to
+    the oracle (whose semantics for such columns are the Fortran's, with per-column state)."""
+    from fv3net_amd import ops
+
+    rng = np.random.default_rng(21)
+    ncol, km, kn = 3000, 40, 40
+    pe1, q, pe2 = _columns(rng, ncol, km, kn)
+    bad = rng.choice(ncol, 300, replace=False)
+    for i, c in enumerate(bad):
+        kind = i % 5
+        if kind == 0:      # a source interface out of order
+            j = rng.integers(1, km)
+            pe1[c, j], pe1[c, j + 1] = pe1[c, j + 1], pe1[c, j]
+        elif kind == 1:    # a target interface out of order
+            j = rng.integers(1, kn)
+            pe2[c, j], pe2[c, j + 1] = pe2[c, j + 1], pe2[c, j]
+        elif kind == 2:    # NaN source pressure
+            pe1[c, rng.integers(0, km + 1)] = np.nan
+        elif kind == 3:    # NaN target pressure
+            pe2[c, rng.integers(0, kn + 1)] = np.nan
+        else:              # decreasing target column
+            pe2[c] = pe2[c, ::-1].copy()
+    for iv, kord in [(1, 1), (0, 4), (-1, 6)]:
+        qq = np.abs(q) if iv == 0 else q
+        ref = mappm_c.mappm(pe1, qq, pe2, iv, kord)
+        res = ops.as_numpy(ops.mappm(_dev(pe1, device), _dev(qq, device), _dev(pe2, device), iv=iv, kord=kord))
+        good = np.setdiff1d(np.arange(ncol), bad)
+        assert _bits_equal(res[good], ref[good])
+        assert _bits_equal(res[bad], ref[bad])
+    # every column ill-formed: more work-list entries than fallback threads in a launch is fine
+    pe1_all = pe1[:, ::-1].copy()
+    ref = mappm_c.mappm(pe1_all, q, pe2, 1, 1)
+    res = ops.as_numpy(ops.mappm(_dev(pe1_all, device), _dev(q, device), _dev(pe2, device)))
+    assert _bits_equal(res, ref)

@@ -24,7 +24,7 @@ def test_library_exports_every_symbol_in_the_header():
     for name in declared:
         assert hasattr(lib, name), name
     assert lib.fv3hip_abi_version() == 1
-    assert lib.fv3hip_mappm_workspace_bytes(10, 79) == 5 * 79 * 10 * 4
+    assert lib.fv3hip_mappm_workspace_bytes(10, 79) >= 5 * 79 * 10 * 4
 
 
 def test_library_reports_errors_without_touching_the_gpu():
