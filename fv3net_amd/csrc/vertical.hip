@@ -409,8 +409,9 @@ __global__ __launch_bounds__(256) void mappm_merge_kernel(
     float *pq2 = q2_ + addr.o_q2;
     auto PE1 = [&](int k) { return (float)pp1[(int64_t)(k - 1) * ks]; };
     auto Q = [&](int k) { return (float)pq1[(int64_t)(k - 1) * ks]; };
-    auto PE2 = [&](int k) { return (float)pp2[(int64_t)(k - 1) * ks]; };
+    auto PE2g = [&](int k) { return (float)pp2[(int64_t)(k - 1) * ks]; };
     auto OUT = [&](int k, float v) { pq2[(int64_t)(k - 1) * ks] = v; };
+    __shared__ float ring_lds[16 * 256];
 
     const int km1 = km - 1;
     int lmt_int = kord - 3;
@@ -473,100 +474,76 @@ __global__ __launch_bounds__(256) void mappm_merge_kernel(
     }
 
     // ---- per-lane target cursor ----
+    // For finite, non-decreasing pressures the targets of a column come in three runs: those
+    // whose top edge is at or above the old top (copy q1(1), mappm.f90:62-64), those that
+    // start inside the column (the merge below), those that start at or below the old surface
+    // (copy q1(km), mappm.f90:65-67).  `live` = this lane still has a target of the middle run.
+    //
+    // The target interfaces are consumed at a per-lane level.  Reading them from HBM where they
+    // are needed would cost a memory round trip per emitted target, so each lane keeps a private
+    // ring of the next kRing interfaces of its column in LDS ([slot][thread], conflict-free):
+    // rows are requested at the top of a source-layer iteration and written to the ring at the
+    // top of the next one, so the emit loop touches LDS only and every global load of the kernel
+    // has a whole iteration to land.
+    constexpr int kRing = 16;
+    float *ring = ring_lds + threadIdx.x;
+    auto RING = [&](int j) -> float & { return ring[(j & (kRing - 1)) * 256]; };
+    int jw = 1;  // interfaces < jw are in the ring (those >= jw - kRing are still there)
+    {
+        float tmp[kRing];
+#pragma unroll
+        for (int i = 0; i < kRing; ++i) tmp[i] = PE2g((i + 1 <= kn + 1) ? i + 1 : kn + 1);
+#pragma unroll
+        for (int i = 0; i < kRing; ++i) RING(i + 1) = tmp[i];
+        jw = (kRing < kn + 1 ? kRing : kn + 1) + 1;
+    }
+    int jp = jw;            // interfaces in [jw, jp) have been requested (at most two)
+    float pv0 = 0.f, pv1 = 0.f;
+    auto PE2 = [&](int j) { return (j < jw) ? RING(j) : PE2g(j); };  // (j >= jw - kRing by construction)
+
     int k = 1;
-    float p2k = PE2(1), p2k1 = PE2(2), p2k2 = PE2(kn >= 2 ? 3 : 2);  // pe2(k), pe2(k+1), pe2(k+2)
+    float p2k = PE2(1), p2k1 = PE2(2);  // pe2(k), pe2(k+1)
     bool accum = false;
     float qsum = 0.f, dpsum = 0.f;
-    auto advance = [&]() {  // the load for two targets ahead is issued here, used two advances later
+    auto advance = [&]() {
         ++k;
+        if (!(p2k1 >= p2k)) bad = true;  // also catches NaN
         p2k = p2k1;
-        p2k1 = p2k2;
-        if (k + 2 <= kn + 1) p2k2 = PE2(k + 2);
+        p2k1 = PE2(k + 1 <= kn + 1 ? k + 1 : kn + 1);
     };
-    // consume the targets the pre-checks decide (above the old top / below the old surface)
-    auto settle = [&]() {
-        while (k <= kn) {
-            if (!(p2k1 >= p2k)) bad = true;
-            if (bad) {
-                k = kn + 1;
-                break;
-            }
-            if (p2k <= pe1_top)
-                OUT(k, q_top);
-            else if (p2k >= pe1_bot)
-                OUT(k, q_bot);
-            else
-                break;
-            advance();
-        }
-    };
-    settle();
+    if (!(p2k1 >= p2k)) bad = true;
+    while (k <= kn && !bad && p2k <= pe1_top) {
+        OUT(k, q_top);
+        advance();
+    }
+    bool live = (k <= kn) && !bad && !(p2k >= pe1_bot);
 
+    float q_in = 0.f, pe_in = pe_e;  // q(L+3), pe1(L+4) for the NEXT iteration's window, in flight
+    float al2 = 0.f, dc2 = 0.f;
     for (int L = 1; L <= km; ++L) {
-        const bool edge = (L <= 2) | (L >= km1);
-        // ---- finalise layer L: A6 and the limiter (mappm.f90:773-849) ----
-        float al = al0, ar = (L == km) ? ar_km : al1, a6 = 0.f;
-        if (edge | int_recompute_a6) a6 = 3.f * (2.f * q0 - (al + ar));
-        if (edge | int_limit) ppm_limiters1(dc0, q0, al, ar, a6, edge ? 0 : lmt_int);
-        const float pL = pe_a, pL1 = pe_b;
-
-        // ---- emit the target layers that can be decided inside layer L ----
-        while (k <= kn) {
-            if (!accum) {
-                if (p2k >= pL && p2k <= pL1) {
-                    const float PL = (p2k - pL) / d0;
-                    if (p2k1 <= pL1) {
-                        const float PR = (p2k1 - pL) / d0;
-                        const float TT = r3 * (PR * (PR + PL) + PL * PL);
-                        OUT(k, al + 0.5f * (a6 + ar - al) * (PR + PL) - a6 * TT);
-                        advance();
-                        settle();
-                    } else {
-                        const float delp = pL1 - p2k;
-                        const float TT = r3 * (1.f + PL * (1.f + PL));
-                        qsum = delp * (al + 0.5f * (a6 + ar - al) * (1.f + PL) - a6 * TT);
-                        dpsum = delp;
-                        accum = true;
-                        break;
-                    }
-                } else {
-                    break;
-                }
-            } else {
-                if (p2k1 > pL1) {
-                    qsum = qsum + d0 * q0;
-                    dpsum = dpsum + d0;
-                    break;
-                } else {
-                    const float delp = p2k1 - pL;
-                    const float esl = delp / d0;
-                    qsum = qsum + delp * (al + 0.5f * esl * (ar - al + a6 * (1.f - r23 * esl)));
-                    dpsum = dpsum + delp;
-                    OUT(k, qsum / dpsum);
-                    accum = false;
-                    advance();
-                    settle();
-                }
-            }
+        // ---- (1) everything requested during the previous iteration lands here ----
+        if (jp > jw) RING(jw) = pv0;
+        if (jp > jw + 1) RING(jw + 1) = pv1;
+        jw = jp;
+        if (L > 1) {  // level L becomes the current one
+            if (!(pe_in >= pe_e)) bad = true;
+            qm1 = q0; q0 = qp1; qp1 = qp2; qp2 = qp3; qp3 = q_in;
+            dm1 = d0; d0 = dp1; dp1 = dp2; dp2 = dp3; dp3 = pe_in - pe_e;
+            pe_a = pe_b; pe_b = pe_c; pe_c = pe_d; pe_d = pe_e; pe_e = pe_in;
+            al0 = al1; al1 = al2;
+            dc0 = dc1; dc1 = dc2;
         }
-
-        // ---- slide the window: reconstruction of level L+2 ----
-        float al2 = 0.f, dc2 = 0.f, q_new = 0.f, pe_new = pe_e;
+        // ---- (2) reconstruction of level L+2 from the window dp(L-1..L+3), q(L..L+3) ----
         const int kk = L + 2;
-        if (L + 4 <= km) {  // the values that enter the window after the shift: q(L+4), pe1(L+5)
-            q_new = Q(L + 4);
-            pe_new = PE1(L + 5);
-            if (!(pe_new >= pe_e)) bad = true;
-        }
-        if (kk >= 3 && kk <= km1) {
-            // window now: dm1,d0,dp1,dp2,dp3 = dp(L-1..L+3); q0,qp1,qp2,qp3 = q(L..L+3)
-            dc2 = DCI(dp1, dp2, dp3, qp1, qp2, qp3);                       // dc(L+2)
-            // dc(L+1): dc1 is dc(L+1) for L >= 1 (set below / by the prologue)
-            al2 = INT(d0, dp1, dp2, dp3, qp1, qp2, dc1, dc2);              // al(L+2)
+        al2 = 0.f;
+        dc2 = 0.f;
+        if (kk <= km1) {
+            dc2 = DCI(dp1, dp2, dp3, qp1, qp2, qp3);           // dc(L+2)
+            al2 = INT(d0, dp1, dp2, dp3, qp1, qp2, dc1, dc2);  // al(L+2)
         } else if (kk == km) {
             // bottom boundary (mappm.f90:729-761): al(km), ar(km), dc(km) from al(km-1) = al1
-            const float d1 = dp2, d2 = dp1;            // dp(km), dp(km-1)
-            const float qk = qp2, qk1 = qp1;           // q(km), q(km-1)
+            const float d1 = dp2, d2 = dp1;   // dp(km), dp(km-1)
+            const float qk = qp2, qk1 = qp1;  // q(km), q(km-1)
             const float qm = (d2 * qk + d1 * qk1) / (d1 + d2);
             const float dq = 2.f * (qk1 - qk) / (d1 + d2);
             const float c1 = (al1 - qm - d2 * dq) / (d2 * (2.f * d2 * d2 + d1 * (d2 + 3.f * d1)));
@@ -585,29 +562,88 @@ __global__ __launch_bounds__(256) void mappm_merge_kernel(
             al2 = alk;
             ar_km = ark;
         }
-        // shift: level L+1 becomes the current one
-        qm1 = q0; q0 = qp1; qp1 = qp2; qp2 = qp3; qp3 = q_new;
-        dm1 = d0; d0 = dp1; dp1 = dp2; dp2 = dp3; dp3 = pe_new - pe_e;
-        pe_a = pe_b; pe_b = pe_c; pe_c = pe_d; pe_d = pe_e; pe_e = pe_new;
-        al0 = al1; al1 = al2;
-        dc0 = dc1; dc1 = dc2;
+        // ---- (3) requests for the next iteration: q(L+4), pe1(L+5), up to two target interfaces ----
+        if (L + 4 <= km) {
+            q_in = Q(L + 4);
+            pe_in = PE1(L + 5);
+        }
+        if (jp <= kn + 1 && jp < k + kRing) {
+            pv0 = PE2g(jp);
+            ++jp;
+            if (jp <= kn + 1 && jp < k + kRing) {
+                pv1 = PE2g(jp);
+                ++jp;
+            }
+        }
+
+        const bool edge = (L <= 2) | (L >= km1);
+        // ---- (4) finalise layer L: A6 and the limiter (mappm.f90:773-849) ----
+        float al = al0, ar = (L == km) ? ar_km : al1, a6 = 0.f;
+        if (edge | int_recompute_a6) a6 = 3.f * (2.f * q0 - (al + ar));
+        if (edge | int_limit) ppm_limiters1(dc0, q0, al, ar, a6, edge ? 0 : lmt_int);
+        const float pL = pe_a, pL1 = pe_b;
+
+        // ---- (5) emit the target layers that end inside layer L ----
+        // Per layer a lane goes through zero or more emitting events (the bottom part of an
+        // accumulating target; targets lying entirely inside the layer) and then exactly one
+        // non-emitting one (start a target that leaves the layer / add the whole layer / nothing).
+        for (;;) {
+            const bool part = live && accum && !(p2k1 > pL1);
+            const bool inside = live && !accum && (p2k >= pL && p2k <= pL1) && (p2k1 <= pL1);
+            if (!(part || inside)) break;
+            float val;
+            if (part) {
+                const float delp = p2k1 - pL;
+                const float esl = delp / d0;
+                qsum = qsum + delp * (al + 0.5f * esl * (ar - al + a6 * (1.f - r23 * esl)));
+                dpsum = dpsum + delp;
+                val = qsum / dpsum;
+                accum = false;
+            } else {
+                const float PL = (p2k - pL) / d0;
+                const float PR = (p2k1 - pL) / d0;
+                const float TT = r3 * (PR * (PR + PL) + PL * PL);
+                val = al + 0.5f * (a6 + ar - al) * (PR + PL) - a6 * TT;
+            }
+            OUT(k, val);
+            advance();
+            live = (k <= kn) && !bad && !(p2k >= pe1_bot);
+        }
+        if (live) {
+            if (accum) {  // whole layer (mappm.f90:99-104)
+                qsum = qsum + d0 * q0;
+                dpsum = dpsum + d0;
+            } else if (p2k >= pL && p2k <= pL1) {  // fractional area (mappm.f90:85-92)
+                const float PL = (p2k - pL) / d0;
+                const float delp = pL1 - p2k;
+                const float TT = r3 * (1.f + PL * (1.f + PL));
+                qsum = delp * (al + 0.5f * (a6 + ar - al) * (1.f + PL) - a6 * TT);
+                dpsum = delp;
+                accum = true;
+            }
+        }
     }
     (void)qm1;
     (void)dm1;
 
-    // ---- past the old surface (mappm.f90:115-121) ----
-    if (k <= kn && accum) {
+    // ---- past the old surface (mappm.f90:115-121), then the run that copies q1(km) ----
+    if (k <= kn && !bad && accum) {
         const float delp = p2k1 - pe1_bot;
         if (delp > 0.f) {
             qsum = qsum + delp * q_bot;
             dpsum = dpsum + delp;
         }
         OUT(k, qsum / dpsum);
-        accum = false;
         advance();
-        settle();
     }
-    if (k <= kn) bad = true;  // a top-edge search that no source layer satisfied
+    while (k <= kn && !bad) {
+        if (p2k >= pe1_bot) {
+            OUT(k, q_bot);
+            advance();
+        } else {
+            bad = true;  // a top-edge search that no source layer satisfied
+        }
+    }
     if (bad) bad_cols[atomicAdd(n_bad, 1u)] = (unsigned int)lc;  // redone by mappm_fallback_kernel
 }
 
