@@ -38,6 +38,18 @@
 namespace fv3hip {
 namespace {
 
+// Scheduling of one k-pair slot: the matrix pipe takes a 32x32x2 f32 MFMA every 64 cycles and the
+// wave issues in order, so the slot's other work (LDS reads of the next A fragments, the input
+// prefetch / normalisation, the LDS commits) only overlaps if it sits BETWEEN the MFMAs.  Ask the
+// scheduler for (1 MFMA, up to Q others) x NT, then fence the slot.
+#define MLP_SLOT_SCHED(NT, Q)                                                          \
+    _Pragma("unroll") for (int _i = 0; _i < (NT); ++_i)                                \
+    {                                                                                  \
+        __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);                             \
+        __builtin_amdgcn_sched_group_barrier(0x002 | 0x004 | 0x010 | 0x080 | 0x400, (Q), 0); \
+    }                                                                                  \
+    __builtin_amdgcn_sched_barrier(0)
+
 typedef float f32x16 __attribute__((ext_vector_type(16)));
 typedef float f32x4 __attribute__((ext_vector_type(4)));
 
@@ -55,6 +67,16 @@ struct KEntry {  // one network input feature (32 bytes)
     int transform;
     float eps;
     int pad0, pad1;
+};
+
+struct XAddr {  // per call: where network input k is read from (16 bytes)
+    int64_t row;  // byte address of (feature, sample 0)
+    int64_t ss;   // byte stride between samples
+};
+
+struct XNorm {  // per model: what is done to it (16 bytes)
+    float center, scale, eps;
+    int flags;  // bit 0: log transform, bit 1: a real input (0 = padding -> 0)
 };
 
 struct OEntry {  // one network output feature (32 bytes)
@@ -107,8 +129,9 @@ __global__ __launch_bounds__(kThreads, 1) void mlp_fused_kernel(const MlpLaunch 
 
     extern __shared__ __attribute__((aligned(16))) char smem[];
     f32x4 *wbuf = reinterpret_cast<f32x4 *>(smem);                       // [2][CH_MAX]
-    KEntry *ktab = reinterpret_cast<KEntry *>(wbuf + 2 * CH_MAX);        // [n_ktab]
-    OEntry *otab = reinterpret_cast<OEntry *>(ktab + p.n_ktab);          // [n_otab]
+    XAddr *xa_tab = reinterpret_cast<XAddr *>(wbuf + 2 * CH_MAX);        // [n_ktab] where input k lives
+    XNorm *xn_tab = reinterpret_cast<XNorm *>(xa_tab + p.n_ktab);        // [n_ktab] how it is normalised
+    OEntry *otab = reinterpret_cast<OEntry *>(xn_tab + p.n_ktab);        // [n_otab]
     float *biasl = reinterpret_cast<float *>(otab + p.n_otab);           // [n_bias]
     int64_t *src_base = reinterpret_cast<int64_t *>(biasl + ((p.n_bias + 3) & ~3));  // [16]
     int64_t *src_fs = src_base + kMaxSources;
@@ -124,9 +147,27 @@ __global__ __launch_bounds__(kThreads, 1) void mlp_fused_kernel(const MlpLaunch 
 
     // ---- one-time prologue: tables to LDS ----
     {
-        const f32x4 *gk = reinterpret_cast<const f32x4 *>(p.ktab);
-        f32x4 *lk = reinterpret_cast<f32x4 *>(ktab);
-        for (int i = tid; i < p.n_ktab * 2; i += kThreads) lk[i] = gk[i];
+        // Per-feature input tables: the byte address of every network input's row for sample 0
+        // (per call) and its normalisation constants, so that a k-pair slot needs one 16-byte LDS
+        // read to issue an input load and one to finish it -- no dependent LDS chain in a slot.
+        typedef const int64_t __attribute__((address_space(4))) *KargPtr64;
+        typedef const char __attribute__((address_space(4))) *KargBytes64;
+        KargPtr64 ksrc = (KargPtr64)((KargBytes64)__builtin_amdgcn_kernarg_segment_ptr() + offsetof(MlpLaunch, src));
+        for (int i = tid; i < p.n_ktab; i += kThreads) {
+            const KEntry e = p.ktab[i];
+            const int sidx = e.src < 0 ? 0 : e.src;
+            const int64_t esz = SRC64 ? 8 : 4;
+            XAddr a;
+            a.row = ksrc[sidx] + (e.src < 0 ? 0 : (int64_t)e.feat * ksrc[kMaxSources + sidx] * esz);
+            a.ss = e.src < 0 ? 0 : ksrc[2 * kMaxSources + sidx] * esz;
+            xa_tab[i] = a;
+            XNorm nrm;
+            nrm.center = e.center;
+            nrm.scale = e.scale;
+            nrm.eps = e.eps;
+            nrm.flags = (e.transform == FV3HIP_TRANSFORM_LOG ? 1 : 0) | (e.src < 0 ? 0 : 2);
+            xn_tab[i] = nrm;
+        }
         const f32x4 *go = reinterpret_cast<const f32x4 *>(p.otab);
         f32x4 *lo = reinterpret_cast<f32x4 *>(otab);
         for (int i = tid; i < p.n_otab * 2; i += kThreads) lo[i] = go[i];
@@ -176,25 +217,28 @@ __global__ __launch_bounds__(kThreads, 1) void mlp_fused_kernel(const MlpLaunch 
     typedef double __attribute__((address_space(1))) *GF64Ptr;
     Raw xraw[KC_H];
     float xcur[KC_H];
-    auto issue_x = [&](int c, int64_t nc) {  // raw loads for layer-1 chunk c, sample nc
-#pragma unroll
-        for (int s = 0; s < KC_H; ++s) {
-            const KEntry e = ktab[2 * (c * KC_H + s) + half];
-            const int sidx = e.src < 0 ? 0 : e.src;
-            GRawPtr base = (GRawPtr)src_base[sidx];
-            const int64_t off = (int64_t)e.feat * src_fs[sidx] + nc * src_ss[sidx];
-            xraw[s] = base[e.src < 0 ? 0 : off];
-        }
+    // one element (k-pair s of a layer-1 chunk): raw load / transform + normalise, both branch-free
+    // so that they can be scheduled between MFMAs
+    auto issue_x1 = [&](const XAddr a, int s, int64_t nc) { xraw[s] = *(GRawPtr)(a.row + nc * a.ss); };
+    auto finish_x1 = [&](const XNorm e, int s) {
+        const float raw = (float)xraw[s];
+        const float lg = logf(raw < e.eps ? e.eps : raw);
+        float v = (e.flags & 1) ? lg : raw;
+        v = (v - e.center) / e.scale;
+        xcur[s] = (e.flags & 2) ? v : 0.f;
     };
-    auto finish_x = [&](int c) {  // transform + normalise the chunk loaded by issue_x
+    auto issue_x = [&](int c, int64_t nc) {  // a whole chunk at once (tile boundaries only)
 #pragma unroll
-        for (int s = 0; s < KC_H; ++s) {
-            const KEntry e = ktab[2 * (c * KC_H + s) + half];
-            float v = (float)xraw[s];
-            if (e.transform == FV3HIP_TRANSFORM_LOG) v = logf(v < e.eps ? e.eps : v);
-            v = (v - e.center) / e.scale;
-            xcur[s] = e.src < 0 ? 0.f : v;
-        }
+        for (int s = 0; s < KC_H; ++s) issue_x1(xa_tab[2 * (c * KC_H + s) + half], s, nc);
+    };
+    auto finish_x = [&](int c) {
+#pragma unroll
+        for (int s = 0; s < KC_H; ++s) finish_x1(xn_tab[2 * (c * KC_H + s) + half], s);
+    };
+    // one staged float4 of the next chunk -> the other LDS buffer
+    // (unconditional: a chunk type with fewer float4s just leaves the tail of the buffer unused)
+    auto commit_w1 = [&](int buf, int i) {
+        if (i < NV_MAX) wbuf[buf * CH_MAX + tid + i * kThreads] = stage[i];
     };
 
     int par = 0;  // LDS buffer holding the chunk about to be consumed
@@ -227,23 +271,55 @@ __global__ __launch_bounds__(kThreads, 1) void mlp_fused_kernel(const MlpLaunch 
             for (int t = 0; t < HT; ++t)
 #pragma unroll
                 for (int r = 0; r < 16; ++r) h[t][r] = biasl[(t * 16 + r) * 2 + half];
+            // Software pipeline, one k-pair (HT MFMAs = HT x 64 cycles of matrix pipe) per slot:
+            //   * the A fragments of k-pair s+1 are read from LDS before the MFMAs of k-pair s;
+            //   * slot s issues the raw input load of element s of the NEXT chunk and finishes
+            //     (transform, normalise) the element issued 8 slots earlier, so every global load
+            //     has 8 slots (>= 4096 cycles) to land and the VALU work rides under the MFMAs;
+            //   * the staged weights of the next chunk go to the other LDS buffer one float4 per
+            //     slot in the second half of the chunk.
             for (int c = 0; c < p.n_chunks1; ++c) {
-                issue_w(g + 1 < G ? g + 1 : 0);
-                const bool more = c + 1 < p.n_chunks1;
-                if (more) issue_x(c + 1, nc);
+                const int gnext = (g + 1 < G) ? g + 1 : 0;
+                issue_w(gnext);
+                const int cn = (c + 1 < p.n_chunks1) ? c + 1 : c;
                 const f32x4 *lw = wbuf + par * CH_MAX + lane;
+                f32x4 a_cur[HG], a_nxt[HG];
+#pragma unroll
+                for (int j = 0; j < HG; ++j) a_cur[j] = lw[j * 64];
+                // table entries are read one slot ahead of their use
+                const XAddr *xa_n = xa_tab + 2 * cn * KC_H + half;    // issue: element s of chunk cn
+                const XNorm *xn_c = xn_tab + 2 * c * KC_H + half;     // finish, first half: chunk c, s+8
+                const XNorm *xn_n = xn_tab + 2 * cn * KC_H + half;    // finish, second half: chunk cn, s-8
+                XAddr xa_cur = xa_n[0], xa_nxt = xa_cur;
+                XNorm xn_cur = xn_c[2 * (KC_H / 2)], xn_nxt = xn_cur;
 #pragma unroll
                 for (int s = 0; s < KC_H; ++s) {
-                    f32x4 a[HG];
+                    if (s + 1 < KC_H) {
 #pragma unroll
-                    for (int j = 0; j < HG; ++j) a[j] = lw[(s * HG + j) * 64];
+                        for (int j = 0; j < HG; ++j) a_nxt[j] = lw[((s + 1) * HG + j) * 64];
+                        xa_nxt = xa_n[2 * (s + 1)];
+                        xn_nxt = (s + 1 < KC_H / 2) ? xn_c[2 * (s + 1 + KC_H / 2)] : xn_n[2 * (s + 1 - KC_H / 2)];
+                    }
                     const float b = xcur[s];
 #pragma unroll
                     for (int t = 0; t < HT; ++t)
-                        h[t] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[t / 4][t % 4], b, h[t], 0, 0, 0);
+                        h[t] = __builtin_amdgcn_mfma_f32_32x32x2f32(a_cur[t / 4][t % 4], b, h[t], 0, 0, 0);
+                    // No branches in a slot (the scheduler only interleaves inside a basic block): on
+                    // the last chunk the "next chunk" is the chunk itself, which re-derives values
+                    // that are already there; re-finishing elements 8..15 of chunk 0 is idempotent.
+                    issue_x1(xa_cur, s, nc);
+                    if (s < KC_H / 2) {
+                        finish_x1(xn_cur, s + KC_H / 2);
+                    } else {
+                        finish_x1(xn_cur, s - KC_H / 2);
+                        commit_w1(par ^ 1, s - KC_H / 2);
+                    }
+#pragma unroll
+                    for (int j = 0; j < HG; ++j) a_cur[j] = a_nxt[j];
+                    xa_cur = xa_nxt;
+                    xn_cur = xn_nxt;
+                    MLP_SLOT_SCHED(HT, 10);
                 }
-                commit_w(g + 1 < G ? g + 1 : 0, par ^ 1);
-                if (more) finish_x(c + 1);
                 __syncthreads();
                 par ^= 1;
                 ++g;
@@ -263,19 +339,27 @@ __global__ __launch_bounds__(kThreads, 1) void mlp_fused_kernel(const MlpLaunch 
                 for (int r = 0; r < 16; ++r) h2[t][r] = bl[(t * 16 + r) * 2 + half];
 #pragma unroll
             for (int kt = 0; kt < HT; ++kt) {
-                issue_w(g + 1 < G ? g + 1 : 0);
+                const int gnext = (g + 1 < G) ? g + 1 : 0;
+                issue_w(gnext);
                 const f32x4 *lw = wbuf + par * CH_MAX + lane;
+                f32x4 a_cur[HG], a_nxt[HG];
+#pragma unroll
+                for (int j = 0; j < HG; ++j) a_cur[j] = lw[j * 64];
 #pragma unroll
                 for (int s = 0; s < KC_H; ++s) {
-                    f32x4 a[HG];
+                    if (s + 1 < KC_H) {
 #pragma unroll
-                    for (int j = 0; j < HG; ++j) a[j] = lw[(s * HG + j) * 64];
+                        for (int j = 0; j < HG; ++j) a_nxt[j] = lw[((s + 1) * HG + j) * 64];
+                    }
                     const float b = h[kt][s];
 #pragma unroll
                     for (int t = 0; t < HT; ++t)
-                        h2[t] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[t / 4][t % 4], b, h2[t], 0, 0, 0);
+                        h2[t] = __builtin_amdgcn_mfma_f32_32x32x2f32(a_cur[t / 4][t % 4], b, h2[t], 0, 0, 0);
+                    if (s >= KC_H / 2) commit_w1(par ^ 1, s - KC_H / 2);
+#pragma unroll
+                    for (int j = 0; j < HG; ++j) a_cur[j] = a_nxt[j];
+                    MLP_SLOT_SCHED(HT, 3);
                 }
-                commit_w(g + 1 < G ? g + 1 : 0, par ^ 1);
                 __syncthreads();
                 par ^= 1;
                 ++g;
@@ -300,20 +384,32 @@ __global__ __launch_bounds__(kThreads, 1) void mlp_fused_kernel(const MlpLaunch 
             for (int kt = 0; kt < HT; ++kt) {
 #pragma unroll
                 for (int hf = 0; hf < OHALVES; ++hf) {
-                    const bool last_chunk = (g + 1 == G);
-                    issue_w(last_chunk ? 0 : g + 1);
+                    const int gnext = (g + 1 == G) ? 0 : g + 1;
+                    issue_w(gnext);
                     const f32x4 *lw = wbuf + par * CH_MAX + lane;
+                    f32x4 a_cur[OG], a_nxt[OG];
+#pragma unroll
+                    for (int j = 0; j < OG; ++j) a_cur[j] = lw[j * 64];
 #pragma unroll
                     for (int s = 0; s < KC_O; ++s) {
-                        f32x4 a[OG];
+                        if (s + 1 < KC_O) {
 #pragma unroll
-                        for (int j = 0; j < OG; ++j) a[j] = lw[(s * OG + j) * 64];
+                            for (int j = 0; j < OG; ++j) a_nxt[j] = lw[((s + 1) * OG + j) * 64];
+                        }
                         const float b = h[kt][hf * KC_O + s];
 #pragma unroll
                         for (int t = 0; t < OC; ++t)
-                            y[t] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[t / 4][t % 4], b, y[t], 0, 0, 0);
+                            y[t] = __builtin_amdgcn_mfma_f32_32x32x2f32(a_cur[t / 4][t % 4], b, y[t], 0, 0, 0);
+                        // NV_MAX float4 per thread to commit, over the second half of the chunk's slots
+                        constexpr int per_slot = (NV_MAX + KC_O / 2 - 1) / (KC_O / 2);
+                        if (s >= KC_O / 2) {
+#pragma unroll
+                            for (int i = 0; i < per_slot; ++i) commit_w1(par ^ 1, (s - KC_O / 2) * per_slot + i);
+                        }
+#pragma unroll
+                        for (int j = 0; j < OG; ++j) a_cur[j] = a_nxt[j];
+                        MLP_SLOT_SCHED(OC, 3);
                     }
-                    commit_w(last_chunk ? 0 : g + 1, par ^ 1);
                     __syncthreads();
                     par ^= 1;
                     ++g;
