@@ -9,7 +9,8 @@ import os
 from ctypes import POINTER, c_char_p, c_double, c_float, c_int, c_int64, c_size_t, c_void_p
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "libfv3hip.so")
+# FV3HIP_LIBRARY points at an alternative build of the same ABI (diagnostic builds with stamps)
+LIB_PATH = os.environ.get("FV3HIP_LIBRARY") or os.path.join(_HERE, "libfv3hip.so")
 
 F32, F64, I32, I64 = 0, 1, 2, 3
 OP_SUM, OP_MEAN, OP_MIN, OP_MAX, OP_MEDIAN, OP_MODE = range(6)

@@ -30,6 +30,7 @@
 //     outputs are applied in registers in the epilogue.
 #include <cmath>
 #include <cstddef>
+#include <cstdlib>
 #include <type_traits>
 #include <vector>
 
@@ -42,6 +43,11 @@ namespace {
 // wave issues in order, so the slot's other work (LDS reads of the next A fragments, the input
 // prefetch / normalisation, the LDS commits) only overlaps if it sits BETWEEN the MFMAs.  Ask the
 // scheduler for (1 MFMA, up to Q others) x NT, then fence the slot.
+// End-of-chunk barrier: the other waves only need this wave's LDS writes (the committed weights),
+// so wait for LDS traffic only; __syncthreads() would also drain vmcnt, i.e. the loads just issued
+// for the NEXT chunk.
+#define MLP_CHUNK_BARRIER() asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory")
+
 #define MLP_SLOT_SCHED(NT, Q)                                                          \
     _Pragma("unroll") for (int _i = 0; _i < (NT); ++_i)                                \
     {                                                                                  \
@@ -70,16 +76,32 @@ struct KEntry {  // one network input feature (32 bytes)
 };
 
 struct XAddr {  // per call: where network input k is read from (16 bytes)
-    int64_t row;  // byte address of (feature, sample 0)
-    int64_t ss;   // byte stride between samples
+    int64_t row;       // byte address of (feature, sample 0)
+    unsigned int ss;   // byte stride between samples (< 4 GiB)
+    unsigned int pad;
 };
 
 struct XNorm {  // per model: what is done to it (16 bytes)
-    float center, scale, eps;
+    float center, rscale, eps;  // rscale = 1 / (std + epsilon), rounded once
     int flags;  // bit 0: log transform, bit 1: a real input (0 = padding -> 0)
 };
 
-struct OEntry {  // one network output feature (32 bytes)
+// per-call output tables (LDS), one entry per network output feature
+struct OFast {      // 16 bytes
+    int64_t row;    // byte address of (feature, sample 0) in its output array; 0 = padding, no store
+    float scale, center;
+};
+struct OSlow {      // 16 bytes
+    float lo, hi, mask;
+    unsigned int ss;  // byte stride between samples
+};
+struct ORes {       // 32 bytes; residual output  after = before + value
+    int64_t src_row;  // 0 = none
+    int64_t out_row;
+    unsigned int src_ss, out_ss, pad0, pad1;
+};
+
+struct OEntry {  // one network output feature as the host describes it (32 bytes, global memory)
     float scale, center, lo, hi;
     float mask;
     int out_feat;  // (output slot << 20) | feature inside the slot; -1 for padding
@@ -99,8 +121,13 @@ struct MlpLaunch {
     int n_otab;
     int n_bias;
     int out64;
+    unsigned long long chunk_log_mask;  // bit c: layer-1 chunk c holds a log-transformed input
+    int epi_fast;      // outputs are float32, sample-contiguous and 16-byte aligned: row-wise dwordx4 stores
+    int has_limits;    // any output limit or zero mask
+    int n_residual;
     int64_t n_samples;
     int64_t n_tiles;
+    unsigned long long *stamps;  // diagnostic builds only (-DMLP_STAMPS): [wave][8] cycle sums
     const void *src[kMaxSources];
     int64_t src_fs[kMaxSources];
     int64_t src_ss[kMaxSources];
@@ -131,14 +158,10 @@ __global__ __launch_bounds__(kThreads, 1) void mlp_fused_kernel(const MlpLaunch 
     f32x4 *wbuf = reinterpret_cast<f32x4 *>(smem);                       // [2][CH_MAX]
     XAddr *xa_tab = reinterpret_cast<XAddr *>(wbuf + 2 * CH_MAX);        // [n_ktab] where input k lives
     XNorm *xn_tab = reinterpret_cast<XNorm *>(xa_tab + p.n_ktab);        // [n_ktab] how it is normalised
-    OEntry *otab = reinterpret_cast<OEntry *>(xn_tab + p.n_ktab);        // [n_otab]
-    float *biasl = reinterpret_cast<float *>(otab + p.n_otab);           // [n_bias]
-    int64_t *src_base = reinterpret_cast<int64_t *>(biasl + ((p.n_bias + 3) & ~3));  // [16]
-    int64_t *src_fs = src_base + kMaxSources;
-    int64_t *src_ss = src_fs + kMaxSources;
-    int64_t *out_base = src_ss + kMaxSources;                            // [32]
-    int64_t *out_fs = out_base + kMaxOutputs;
-    int64_t *out_ss = out_fs + kMaxOutputs;
+    OFast *ofast = reinterpret_cast<OFast *>(xn_tab + p.n_ktab);         // [n_otab]
+    OSlow *oslow = reinterpret_cast<OSlow *>(ofast + p.n_otab);          // [n_otab]
+    ORes *ores = reinterpret_cast<ORes *>(oslow + p.n_otab);             // [n_otab] if the model has residual outputs
+    float *biasl = reinterpret_cast<float *>(ores + (p.n_residual ? p.n_otab : 0));  // [n_bias]
 
     const int tid = threadIdx.x;
     const int lane = tid & 63;
@@ -158,29 +181,60 @@ __global__ __launch_bounds__(kThreads, 1) void mlp_fused_kernel(const MlpLaunch 
             const int sidx = e.src < 0 ? 0 : e.src;
             const int64_t esz = SRC64 ? 8 : 4;
             XAddr a;
-            a.row = ksrc[sidx] + (e.src < 0 ? 0 : (int64_t)e.feat * ksrc[kMaxSources + sidx] * esz);
-            a.ss = e.src < 0 ? 0 : ksrc[2 * kMaxSources + sidx] * esz;
+            // padding reads a finite constant (the first bias) and is multiplied by rscale = 0
+            a.row = e.src < 0 ? reinterpret_cast<int64_t>(p.bias)
+                              : ksrc[sidx] + (int64_t)e.feat * ksrc[kMaxSources + sidx] * esz;
+            a.ss = e.src < 0 ? 0u : (unsigned int)(ksrc[2 * kMaxSources + sidx] * esz);
+            a.pad = 0;
             xa_tab[i] = a;
             XNorm nrm;
-            nrm.center = e.center;
-            nrm.scale = e.scale;
+            nrm.center = e.src < 0 ? 0.f : e.center;
+            nrm.rscale = e.src < 0 ? 0.f : e.scale;  // the host stores the reciprocal in KEntry.scale
             nrm.eps = e.eps;
             nrm.flags = (e.transform == FV3HIP_TRANSFORM_LOG ? 1 : 0) | (e.src < 0 ? 0 : 2);
             xn_tab[i] = nrm;
         }
-        const f32x4 *go = reinterpret_cast<const f32x4 *>(p.otab);
-        f32x4 *lo = reinterpret_cast<f32x4 *>(otab);
-        for (int i = tid; i < p.n_otab * 2; i += kThreads) lo[i] = go[i];
+        // Per-feature output tables: absolute row addresses for this call, so that the epilogue is
+        // one LDS read, a multiply-add, one address computation and a store per value.
+        KargPtr64 kout = (KargPtr64)((KargBytes64)__builtin_amdgcn_kernarg_segment_ptr() + offsetof(MlpLaunch, out));
+        const int64_t osz = p.out64 ? 8 : 4;
+        for (int i = tid; i < p.n_otab; i += kThreads) {
+            const OEntry e = p.otab[i];
+            OFast f;
+            OSlow sl;
+            f.scale = e.scale;
+            f.center = e.center;
+            sl.lo = e.lo;
+            sl.hi = e.hi;
+            sl.mask = e.mask;
+            sl.ss = 0;
+            f.row = 0;
+            int slot = 0, feat = 0;
+            if (e.out_feat >= 0) {
+                slot = e.out_feat >> 20;
+                feat = e.out_feat & 0xFFFFF;
+                f.row = kout[slot] + (int64_t)feat * kout[kMaxOutputs + slot] * osz;
+                sl.ss = (unsigned int)(kout[2 * kMaxOutputs + slot] * osz);
+            }
+            ofast[i] = f;
+            oslow[i] = sl;
+            if (p.n_residual) {
+                ORes r;
+                r.src_row = 0;
+                r.out_row = 0;
+                r.src_ss = r.out_ss = r.pad0 = r.pad1 = 0;
+                if (e.out_feat >= 0 && e.res >= 0) {
+                    const int rslot = e.res >> 8, rs = e.res & 0xFF;
+                    const int64_t esz = SRC64 ? 8 : 4;
+                    r.src_row = ksrc[rs] + (int64_t)feat * ksrc[kMaxSources + rs] * esz;
+                    r.src_ss = (unsigned int)(ksrc[2 * kMaxSources + rs] * esz);
+                    r.out_row = kout[rslot] + (int64_t)feat * kout[kMaxOutputs + rslot] * osz;
+                    r.out_ss = (unsigned int)(kout[2 * kMaxOutputs + rslot] * osz);
+                }
+                ores[i] = r;
+            }
+        }
         for (int i = tid; i < p.n_bias; i += kThreads) biasl[i] = p.bias[i];
-        // The pointer/stride tables are indexed per lane later on, so they go to LDS too.  They
-        // are read straight from the kernarg segment with vector loads (p is the only kernel
-        // argument, at offset 0): indexing p.src[] by thread would pull the whole struct into
-        // SGPRs.
-        typedef const int64_t __attribute__((address_space(4))) *KargPtr;
-        typedef const char __attribute__((address_space(4))) *KargBytes;
-        KargPtr ka = (KargPtr)((KargBytes)__builtin_amdgcn_kernarg_segment_ptr() + offsetof(MlpLaunch, src));
-        constexpr int kTableWords = 3 * kMaxSources + 3 * kMaxOutputs;  // src, src_fs, src_ss, out, out_fs, out_ss
-        if (tid < kTableWords) src_base[tid] = ka[tid];
     }
     __syncthreads();
 
@@ -188,26 +242,38 @@ __global__ __launch_bounds__(kThreads, 1) void mlp_fused_kernel(const MlpLaunch 
     const int n_hid_chunks = p.n_chunks1 + (p.n_hidden - 1) * HT;  // hidden-type chunks per tile
     const int n_out_chunks = p.n_pass * HT * OHALVES;              // output-type chunks per tile
     const int G = n_hid_chunks + n_out_chunks;
-    f32x4 stage[NV_MAX];
-    auto issue_w = [&](int g) {  // global -> registers for chunk g of the stream
-        if (g < n_hid_chunks) {
-            const f32x4 *gp = p.w + (int64_t)g * CH_H + tid;
-#pragma unroll
-            for (int i = 0; i < NV_MAX; ++i)
-                if (i < NV_H) stage[i] = gp[i * kThreads];
-        } else {
-            const f32x4 *gp = p.w + (int64_t)n_hid_chunks * CH_H + (int64_t)(g - n_hid_chunks) * CH_O + tid;
-#pragma unroll
-            for (int i = 0; i < NV_MAX; ++i)
-                if (i < NV_O) stage[i] = gp[i * kThreads];
-        }
+    // The next chunk is staged through registers in two halves (first half requested at the start
+    // of a chunk and committed to the other LDS buffer in its second quarter, second half requested
+    // at mid-chunk and committed in the last quarter): half the staging registers.
+    constexpr int NVH = (NV_MAX + 1) / 2;
+    f32x4 stage[NVH];
+    auto chunk_src = [&](int g) -> const f32x4 * {
+        return (g < n_hid_chunks) ? p.w + (int64_t)g * CH_H + tid
+                                  : p.w + (int64_t)n_hid_chunks * CH_H + (int64_t)(g - n_hid_chunks) * CH_O + tid;
     };
-    auto commit_w = [&](int g, int buf) {  // registers -> LDS buffer
-        f32x4 *lp = wbuf + buf * CH_MAX + tid;
-        const int nv = (g < n_hid_chunks) ? NV_H : NV_O;
+    // (for a chunk type with fewer than 2*NVH float4s per thread the second half reads on into the
+    // stream -- the host pads it by one maximal chunk -- and lands in LDS words nobody reads)
+    auto issue_w = [&](int g, int part) {  // global -> registers
+        const f32x4 *gp = chunk_src(g) + part * NVH * kThreads;
 #pragma unroll
-        for (int i = 0; i < NV_MAX; ++i)
-            if (i < nv) lp[i * kThreads] = stage[i];
+        for (int i = 0; i < NVH; ++i) stage[i] = gp[i * kThreads];
+    };
+    auto commit_w1 = [&](int buf, int part, int i) {  // one staged float4 -> the other LDS buffer
+        if (i < NVH) wbuf[buf * CH_MAX + tid + (part * NVH + i) * kThreads] = stage[i];
+    };
+    // slot s of a chunk of KC slots: its share of staging chunk `gnext` into buffer `buf`
+    auto stage_step = [&](int s, int KC, int gnext, int buf) {
+        const int Q = KC / 4, per = (NVH + Q - 1) / Q;
+        if (s == 0) issue_w(gnext, 0);
+        if (s >= Q && s < 2 * Q) {
+#pragma unroll
+            for (int i = 0; i < per; ++i) commit_w1(buf, 0, (s - Q) * per + i);
+        }
+        if (s == 2 * Q) issue_w(gnext, 1);
+        if (s >= 3 * Q) {
+#pragma unroll
+            for (int i = 0; i < per; ++i) commit_w1(buf, 1, (s - 3 * Q) * per + i);
+        }
     };
 
     // ---- layer-1 B operand helpers ----
@@ -219,14 +285,19 @@ __global__ __launch_bounds__(kThreads, 1) void mlp_fused_kernel(const MlpLaunch 
     float xcur[KC_H];
     // one element (k-pair s of a layer-1 chunk): raw load / transform + normalise, both branch-free
     // so that they can be scheduled between MFMAs
-    auto issue_x1 = [&](const XAddr a, int s, int64_t nc) { xraw[s] = *(GRawPtr)(a.row + nc * a.ss); };
-    auto finish_x1 = [&](const XNorm e, int s) {
+    auto issue_x1 = [&](const XAddr a, int s, int64_t nc) {
+        // one v_mad_u64_u32: samples and strides are below 2^32
+        xraw[s] = *(GRawPtr)(a.row + (int64_t)((uint64_t)(unsigned int)nc * (uint64_t)a.ss));
+    };
+    // padding entries need no special case: their row points at a finite constant, center = rscale = 0
+    auto finish_x1 = [&](const XNorm e, int s) {  // generic: log transform where flagged
         const float raw = (float)xraw[s];
         const float lg = logf(raw < e.eps ? e.eps : raw);
-        float v = (e.flags & 1) ? lg : raw;
-        v = (v - e.center) / e.scale;
-        xcur[s] = (e.flags & 2) ? v : 0.f;
+        const float v = (e.flags & 1) ? lg : raw;
+        // (x - mean) * (1 / (std + eps)) instead of the reference's division: <= 1 ulp apart
+        xcur[s] = (v - e.center) * e.rscale;
     };
+    auto finish_x1_plain = [&](const XNorm e, int s) { xcur[s] = ((float)xraw[s] - e.center) * e.rscale; };
     auto issue_x = [&](int c, int64_t nc) {  // a whole chunk at once (tile boundaries only)
 #pragma unroll
         for (int s = 0; s < KC_H; ++s) issue_x1(xa_tab[2 * (c * KC_H + s) + half], s, nc);
@@ -235,22 +306,33 @@ __global__ __launch_bounds__(kThreads, 1) void mlp_fused_kernel(const MlpLaunch 
 #pragma unroll
         for (int s = 0; s < KC_H; ++s) finish_x1(xn_tab[2 * (c * KC_H + s) + half], s);
     };
-    // one staged float4 of the next chunk -> the other LDS buffer
-    // (unconditional: a chunk type with fewer float4s just leaves the tail of the buffer unused)
-    auto commit_w1 = [&](int buf, int i) {
-        if (i < NV_MAX) wbuf[buf * CH_MAX + tid + i * kThreads] = stage[i];
-    };
-
+#ifdef MLP_STAMPS
+    unsigned long long st_acc[6] = {0, 0, 0, 0, 0, 0}, st_t0 = 0;
+#define STAMP_BEGIN() st_t0 = __builtin_readcyclecounter()
+#define STAMP_END(i)                                         \
+    {                                                        \
+        const unsigned long long _t = __builtin_readcyclecounter(); \
+        st_acc[i] += _t - st_t0;                             \
+        st_t0 = _t;                                          \
+    }
+#else
+#define STAMP_BEGIN() ((void)0)
+#define STAMP_END(i) ((void)0)
+#endif
     int par = 0;  // LDS buffer holding the chunk about to be consumed
     int64_t tile = blockIdx.x;
     if (tile >= p.n_tiles) return;
 
     // prime the pipeline: chunk 0 of the stream and the first tile's first inputs
     {
-        issue_w(0);
         int64_t n = tile * kTileSamples + wave * 32 + (lane & 31);
         issue_x(0, n < p.n_samples ? n : p.n_samples - 1);
-        commit_w(0, 0);
+#pragma unroll
+        for (int part = 0; part < 2; ++part) {
+            issue_w(0, part);
+#pragma unroll
+            for (int i = 0; i < NVH; ++i) commit_w1(0, part, i);
+        }
         finish_x(0);
         __syncthreads();
     }
@@ -265,6 +347,7 @@ __global__ __launch_bounds__(kThreads, 1) void mlp_fused_kernel(const MlpLaunch 
         int g = 0;
 
         f32x16 h[HT];
+        STAMP_BEGIN();
         // ================= layer 1: inputs -> hidden =================
         {
 #pragma unroll
@@ -280,9 +363,12 @@ __global__ __launch_bounds__(kThreads, 1) void mlp_fused_kernel(const MlpLaunch 
             //     slot in the second half of the chunk.
             for (int c = 0; c < p.n_chunks1; ++c) {
                 const int gnext = (g + 1 < G) ? g + 1 : 0;
-                issue_w(gnext);
                 const int cn = (c + 1 < p.n_chunks1) ? c + 1 : c;
                 const f32x4 *lw = wbuf + par * CH_MAX + lane;
+                // The slot loop exists in four flavours: whether this chunk (elements 8..15, finished in
+                // the first half) and the next one (elements 0..7, second half) hold log-transformed
+                // inputs.  Chunks without them finish an element with a subtract and a multiply.
+                auto run_slots = [&](auto log_c, auto log_n) {
                 f32x4 a_cur[HG], a_nxt[HG];
 #pragma unroll
                 for (int j = 0; j < HG; ++j) a_cur[j] = lw[j * 64];
@@ -297,8 +383,10 @@ __global__ __launch_bounds__(kThreads, 1) void mlp_fused_kernel(const MlpLaunch 
                     if (s + 1 < KC_H) {
 #pragma unroll
                         for (int j = 0; j < HG; ++j) a_nxt[j] = lw[((s + 1) * HG + j) * 64];
+#ifndef MLP_ABLATE_TABLES
                         xa_nxt = xa_n[2 * (s + 1)];
                         xn_nxt = (s + 1 < KC_H / 2) ? xn_c[2 * (s + 1 + KC_H / 2)] : xn_n[2 * (s + 1 - KC_H / 2)];
+#endif
                     }
                     const float b = xcur[s];
 #pragma unroll
@@ -307,20 +395,30 @@ __global__ __launch_bounds__(kThreads, 1) void mlp_fused_kernel(const MlpLaunch 
                     // No branches in a slot (the scheduler only interleaves inside a basic block): on
                     // the last chunk the "next chunk" is the chunk itself, which re-derives values
                     // that are already there; re-finishing elements 8..15 of chunk 0 is idempotent.
+#ifndef MLP_ABLATE_ISSUE
                     issue_x1(xa_cur, s, nc);
+#endif
+#ifndef MLP_ABLATE_FINISH
                     if (s < KC_H / 2) {
-                        finish_x1(xn_cur, s + KC_H / 2);
+                        if (decltype(log_c)::value) finish_x1(xn_cur, s + KC_H / 2); else finish_x1_plain(xn_cur, s + KC_H / 2);
                     } else {
-                        finish_x1(xn_cur, s - KC_H / 2);
-                        commit_w1(par ^ 1, s - KC_H / 2);
+                        if (decltype(log_n)::value) finish_x1(xn_cur, s - KC_H / 2); else finish_x1_plain(xn_cur, s - KC_H / 2);
                     }
+#endif
+                    stage_step(s, KC_H, gnext, par ^ 1);
 #pragma unroll
                     for (int j = 0; j < HG; ++j) a_cur[j] = a_nxt[j];
                     xa_cur = xa_nxt;
                     xn_cur = xn_nxt;
-                    MLP_SLOT_SCHED(HT, 10);
+                    MLP_SLOT_SCHED(HT, 5);
                 }
-                __syncthreads();
+                };
+                const bool lc = (p.chunk_log_mask >> c) & 1, ln = (p.chunk_log_mask >> cn) & 1;
+                using T_ = std::true_type;
+                using F_ = std::false_type;
+                if (lc) { if (ln) run_slots(T_{}, T_{}); else run_slots(T_{}, F_{}); }
+                else { if (ln) run_slots(F_{}, T_{}); else run_slots(F_{}, F_{}); }
+                MLP_CHUNK_BARRIER();
                 par ^= 1;
                 ++g;
             }
@@ -329,6 +427,7 @@ __global__ __launch_bounds__(kThreads, 1) void mlp_fused_kernel(const MlpLaunch 
 #pragma unroll
                 for (int r = 0; r < 16; ++r) h[t][r] = (h[t][r] < 0.f) ? 0.f : h[t][r];
         }
+        STAMP_END(0);
         // ================= hidden -> hidden =================
         for (int l = 1; l < p.n_hidden; ++l) {
             f32x16 h2[HT];
@@ -340,7 +439,6 @@ __global__ __launch_bounds__(kThreads, 1) void mlp_fused_kernel(const MlpLaunch 
 #pragma unroll
             for (int kt = 0; kt < HT; ++kt) {
                 const int gnext = (g + 1 < G) ? g + 1 : 0;
-                issue_w(gnext);
                 const f32x4 *lw = wbuf + par * CH_MAX + lane;
                 f32x4 a_cur[HG], a_nxt[HG];
 #pragma unroll
@@ -355,12 +453,12 @@ __global__ __launch_bounds__(kThreads, 1) void mlp_fused_kernel(const MlpLaunch 
 #pragma unroll
                     for (int t = 0; t < HT; ++t)
                         h2[t] = __builtin_amdgcn_mfma_f32_32x32x2f32(a_cur[t / 4][t % 4], b, h2[t], 0, 0, 0);
-                    if (s >= KC_H / 2) commit_w1(par ^ 1, s - KC_H / 2);
+                    stage_step(s, KC_H, gnext, par ^ 1);
 #pragma unroll
                     for (int j = 0; j < HG; ++j) a_cur[j] = a_nxt[j];
-                    MLP_SLOT_SCHED(HT, 3);
+                    MLP_SLOT_SCHED(HT, 2);
                 }
-                __syncthreads();
+                MLP_CHUNK_BARRIER();
                 par ^= 1;
                 ++g;
             }
@@ -369,6 +467,7 @@ __global__ __launch_bounds__(kThreads, 1) void mlp_fused_kernel(const MlpLaunch 
 #pragma unroll
                 for (int r = 0; r < 16; ++r) h[t][r] = (h2[t][r] < 0.f) ? 0.f : h2[t][r];
         }
+        STAMP_END(1);
         // ================= hidden -> outputs, OC feature tiles per pass =================
         for (int pass = 0; pass < p.n_pass; ++pass) {
             f32x16 y[OC];
@@ -377,15 +476,15 @@ __global__ __launch_bounds__(kThreads, 1) void mlp_fused_kernel(const MlpLaunch 
             for (int t = 0; t < OC; ++t)
 #pragma unroll
                 for (int r = 0; r < 16; ++r) y[t][r] = bl[(t * 16 + r) * 2 + half];
-            // the next tile's first inputs ride under the last pass of this one
+            // the next tile's first inputs are requested before the epilogue of the last pass and
+            // finished after it (requesting them earlier would keep 16 more registers live through
+            // the pass's MFMA loop, where the accumulators already fill the register file)
             const bool prefetch_next = (pass + 1 == p.n_pass) && next_tile < p.n_tiles;
-            if (prefetch_next) issue_x(0, nn);
 #pragma unroll
             for (int kt = 0; kt < HT; ++kt) {
 #pragma unroll
                 for (int hf = 0; hf < OHALVES; ++hf) {
                     const int gnext = (g + 1 == G) ? 0 : g + 1;
-                    issue_w(gnext);
                     const f32x4 *lw = wbuf + par * CH_MAX + lane;
                     f32x4 a_cur[OG], a_nxt[OG];
 #pragma unroll
@@ -400,54 +499,126 @@ __global__ __launch_bounds__(kThreads, 1) void mlp_fused_kernel(const MlpLaunch 
 #pragma unroll
                         for (int t = 0; t < OC; ++t)
                             y[t] = __builtin_amdgcn_mfma_f32_32x32x2f32(a_cur[t / 4][t % 4], b, y[t], 0, 0, 0);
-                        // NV_MAX float4 per thread to commit, over the second half of the chunk's slots
-                        constexpr int per_slot = (NV_MAX + KC_O / 2 - 1) / (KC_O / 2);
-                        if (s >= KC_O / 2) {
-#pragma unroll
-                            for (int i = 0; i < per_slot; ++i) commit_w1(par ^ 1, (s - KC_O / 2) * per_slot + i);
-                        }
+                        stage_step(s, KC_O, gnext, par ^ 1);
 #pragma unroll
                         for (int j = 0; j < OG; ++j) a_cur[j] = a_nxt[j];
-                        MLP_SLOT_SCHED(OC, 3);
+                        MLP_SLOT_SCHED(OC, 2);
                     }
-                    __syncthreads();
+                    MLP_CHUNK_BARRIER();
                     par ^= 1;
                     ++g;
                 }
             }
-            if (prefetch_next) finish_x(0);
+            STAMP_END(2);
+            if (prefetch_next) issue_x(0, nn);
             // ---- epilogue: denormalise, limit, mask, store (+ residual outputs) ----
+            // Fast path (float32 outputs, contiguous samples, a full 32-sample wave tile): each
+            // 32-feature x 32-sample accumulator tile goes through the wave's 4 KB slice of the idle
+            // weight buffer, is read back row-wise and leaves as 4 dwordx4 stores of 8 full 128-byte
+            // rows each (instead of 16 dword stores), with one table read per row.
+            const bool tile_full = (tile * kTileSamples + wave * 32 + 32) <= p.n_samples;
+            if (p.epi_fast && tile_full) {
+                typedef f32x4 __attribute__((address_space(1))) *GF32x4;
+                typedef const f32x4 __attribute__((address_space(1))) *GCF32x4;
+                float *scr = reinterpret_cast<float *>(wbuf + (par ^ 1) * CH_MAX + wave * 256);
+                const int64_t n0 = tile * kTileSamples + wave * 32;
+                const int wrow = lane >> 3, wcol = (lane & 7) * 4;
 #pragma unroll
-            for (int t = 0; t < OC; ++t) {
+                for (int t = 0; t < OC; ++t) {
 #pragma unroll
-                for (int r = 0; r < 16; ++r) {
-                    const OEntry e = otab[(pass * OC + t) * 32 + rho(r) + 4 * half];
-                    if (e.out_feat < 0 || !valid) continue;
-                    float v = y[t][r] * e.scale + e.center;
-                    if (v < e.lo) v = e.lo;
-                    if (v >= e.hi) v = e.hi;
-                    v = v * e.mask;
-                    const int slot = e.out_feat >> 20, feat = e.out_feat & 0xFFFFF;
-                    const int64_t off = (int64_t)feat * out_fs[slot] + n * out_ss[slot];
-                    if (p.out64)
-                        ((GF64Ptr)out_base[slot])[off] = (double)v;
-                    else
-                        ((GF32Ptr)out_base[slot])[off] = v;
-                    if (e.res >= 0) {
-                        const int rslot = e.res >> 8, rs = e.res & 0xFF;
-                        GRawPtr sb = (GRawPtr)src_base[rs];
-                        const float before = (float)sb[(int64_t)feat * src_fs[rs] + n * src_ss[rs]];
-                        const float after = before + v;
-                        const int64_t roff = (int64_t)feat * out_fs[rslot] + n * out_ss[rslot];
-                        if (p.out64)
-                            ((GF64Ptr)out_base[rslot])[roff] = (double)after;
-                        else
-                            ((GF32Ptr)out_base[rslot])[roff] = after;
+                    for (int r = 0; r < 16; ++r) scr[(rho(r) + 4 * half) * 32 + (lane & 31)] = y[t][r];
+#pragma unroll
+                    for (int j = 0; j < 4; ++j) {
+                        const int row = wrow + 8 * j;
+                        const int idx = (pass * OC + t) * 32 + row;
+                        const OFast of = ofast[idx];
+                        f32x4 v = *reinterpret_cast<const f32x4 *>(scr + row * 32 + wcol);
+                        v = v * of.scale + of.center;
+                        if (p.has_limits) {
+                            const OSlow os = oslow[idx];
+#pragma unroll
+                            for (int q = 0; q < 4; ++q) {
+                                float x = v[q];
+                                if (x < os.lo) x = os.lo;
+                                if (x >= os.hi) x = os.hi;
+                                v[q] = x * os.mask;
+                            }
+                        }
+                        if (of.row != 0) *(GF32x4)(of.row + (n0 + wcol) * 4) = v;
+                        if (p.n_residual) {
+                            const ORes e = ores[idx];
+                            if (e.src_row != 0) {
+                                const f32x4 before = *(GCF32x4)(e.src_row + (n0 + wcol) * 4);
+                                *(GF32x4)(e.out_row + (n0 + wcol) * 4) = before + v;
+                            }
+                        }
+                    }
+                }
+            } else
+            {
+                typedef float __attribute__((address_space(1))) *GF32;
+                typedef double __attribute__((address_space(1))) *GF64;
+                const unsigned int n32 = (unsigned int)n;
+#pragma unroll
+                for (int t = 0; t < OC; ++t) {
+#pragma unroll
+                    for (int gq = 0; gq < 2; ++gq) {
+                        OFast of[8];
+                        OSlow os[8];
+                        float v[8];
+#pragma unroll
+                        for (int i = 0; i < 8; ++i) {
+                            const int idx = (pass * OC + t) * 32 + rho(gq * 8 + i) + 4 * half;
+                            of[i] = ofast[idx];
+                            os[i] = oslow[idx];
+                        }
+#pragma unroll
+                        for (int i = 0; i < 8; ++i) {
+                            float x = y[t][gq * 8 + i] * of[i].scale + of[i].center;
+                            if (p.has_limits) {
+                                if (x < os[i].lo) x = os[i].lo;
+                                if (x >= os[i].hi) x = os[i].hi;
+                                x = x * os[i].mask;
+                            }
+                            v[i] = x;
+                            if (valid && of[i].row != 0) {
+                                const int64_t addr = of[i].row + (int64_t)((uint64_t)n32 * (uint64_t)os[i].ss);
+                                if (p.out64)
+                                    *(GF64)addr = (double)x;
+                                else
+                                    *(GF32)addr = x;
+                            }
+                        }
+                        if (p.n_residual) {
+#pragma unroll
+                            for (int i = 0; i < 8; ++i) {
+                                const int idx = (pass * OC + t) * 32 + rho(gq * 8 + i) + 4 * half;
+                                const ORes e = ores[idx];
+                                if (valid && e.src_row != 0) {
+                                    const float before = (float)*(GRawPtr)(e.src_row + (int64_t)((uint64_t)n32 * (uint64_t)e.src_ss));
+                                    const float after = before + v[i];
+                                    const int64_t addr = e.out_row + (int64_t)((uint64_t)n32 * (uint64_t)e.out_ss);
+                                    if (p.out64)
+                                        *(GF64)addr = (double)after;
+                                    else
+                                        *(GF32)addr = after;
+                                }
+                            }
+                        }
                     }
                 }
             }
+            if (prefetch_next) finish_x(0);
+            MLP_CHUNK_BARRIER();
+            STAMP_END(3);
         }
     }
+#ifdef MLP_STAMPS
+    if (p.stamps && lane == 0) {
+        unsigned long long *o = p.stamps + ((size_t)blockIdx.x * 4 + wave) * 8;
+        for (int i = 0; i < 6; ++i) o[i] = st_acc[i];
+    }
+#endif
 }
 
 template <int HT, int OC>
@@ -473,6 +644,8 @@ struct fv3hip_mlp {
     int n_sources = 0, n_inputs = 0, K = 0, width = 0, n_hidden = 0, n_outputs = 0, F = 0, n_residual = 0;
     int n_chunks1 = 0, n_pass = 0, n_ktab = 0, n_otab = 0, n_bias = 0;
     int64_t flops = 0;
+    int has_limits = 0;
+    unsigned long long chunk_log_mask = 0;
     void *d_w = nullptr, *d_ktab = nullptr, *d_otab = nullptr, *d_bias = nullptr;
     int n_cu = 256;
     size_t lds_bytes = 0;
@@ -483,7 +656,9 @@ namespace {
 struct Variant {
     int HT, OC;
 };
-const Variant kVariants[] = {{1, 4}, {2, 4}, {4, 4}, {8, 4}, {8, 13}};
+// (an {8, 13} variant -- all 13 output tiles of the Zhao-Carr emulator in one pass -- was measured
+// slower than {8, 7}: 208 + 128 accumulator registers leave too little for the pipeline's staging)
+const Variant kVariants[] = {{1, 4}, {2, 4}, {4, 4}, {8, 4}, {8, 7}};
 
 template <int HT, int OC>
 int launch_variant(const fv3hip_mlp *m, const MlpLaunch &lp, bool src64, int grid, size_t lds, hipStream_t st)
@@ -565,6 +740,11 @@ extern "C" int fv3hip_mlp_create(const fv3hip_mlp_desc_t *d, fv3hip_mlp_t *out)
             OC = v.OC;
         }
     }
+    if (const char *force = getenv("FV3HIP_MLP_OC")) {  // tuning experiments only
+        const int want = atoi(force);
+        for (const Variant &v : kVariants)
+            if (v.HT == HT && v.OC == want) OC = want;
+    }
     FV3HIP_REQUIRE(HT > 0 && OC > 0, "no kernel variant for width %d", width);
 
     fv3hip_mlp *m = new fv3hip_mlp();
@@ -581,6 +761,7 @@ extern "C" int fv3hip_mlp_create(const fv3hip_mlp_desc_t *d, fv3hip_mlp_t *out)
     m->n_outputs = d->n_outputs;
     m->F = F;
     m->n_residual = d->n_residual;
+    m->has_limits = (d->out_min || d->out_max || d->out_mask) ? 1 : 0;
     m->n_chunks1 = ((K + 1) / 2 + 15) / 16;
     m->n_pass = (nt_out + OC - 1) / OC;
     m->n_ktab = 2 * 16 * m->n_chunks1;
@@ -596,7 +777,8 @@ extern "C" int fv3hip_mlp_create(const fv3hip_mlp_desc_t *d, fv3hip_mlp_t *out)
     const int n_out_chunks = m->n_pass * HT * OHALVES;
 
     // ---- packed weight stream ----
-    std::vector<float> w((size_t)(n_hid_chunks * CH_H + n_out_chunks * CH_O) * 4, 0.f);
+    // (+ one maximal chunk of zero padding: the two-half staging may read past a short last chunk)
+    std::vector<float> w((size_t)(n_hid_chunks * CH_H + n_out_chunks * CH_O + (CH_H > CH_O ? CH_H : CH_O)) * 4, 0.f);
     auto hid_slot = [&](int g, int s, int j, int lane, int e) -> float & {
         return w[(size_t)((g * CH_H + ((int64_t)(s * HG + j) * 64 + lane)) * 4 + e)];
     };
@@ -661,8 +843,9 @@ extern "C" int fv3hip_mlp_create(const fv3hip_mlp_desc_t *d, fv3hip_mlp_t *out)
                 e.src = d->in_source[i];
                 e.feat = d->in_feat_start[i] + f;
                 e.center = d->in_center ? d->in_center[k] : 0.f;
-                e.scale = d->in_scale ? d->in_scale[k] : 1.f;
+                e.scale = d->in_scale ? (float)(1.0 / (double)d->in_scale[k]) : 1.f;  // reciprocal
                 e.transform = d->in_transform ? d->in_transform[i] : 0;
+                if (e.transform == FV3HIP_TRANSFORM_LOG) m->chunk_log_mask |= 1ull << (k / 32);
                 e.eps = d->in_eps ? d->in_eps[i] : 0.f;
             }
     }
@@ -711,7 +894,8 @@ extern "C" int fv3hip_mlp_create(const fv3hip_mlp_desc_t *d, fv3hip_mlp_t *out)
         return rc;
     }
     const size_t wb = 2 * (size_t)((CH_H > CH_O) ? CH_H : CH_O) * 16;
-    m->lds_bytes = wb + (size_t)m->n_ktab * sizeof(KEntry) + (size_t)m->n_otab * sizeof(OEntry) +
+    m->lds_bytes = wb + (size_t)m->n_ktab * sizeof(KEntry) +
+                   (size_t)m->n_otab * (sizeof(OFast) + sizeof(OSlow) + (d->n_residual ? sizeof(ORes) : 0)) +
                    (size_t)((m->n_bias + 3) & ~3) * sizeof(float) + (size_t)(3 * kMaxSources + 3 * kMaxOutputs) * 8;
     if (m->lds_bytes > 160 * 1024) {
         fv3hip_mlp_destroy(m);
@@ -720,6 +904,11 @@ extern "C" int fv3hip_mlp_create(const fv3hip_mlp_desc_t *d, fv3hip_mlp_t *out)
     *out = m;
     return FV3HIP_OK;
 }
+
+#ifdef MLP_STAMPS
+static unsigned long long *g_mlp_stamps = nullptr;
+extern "C" void fv3hip_diag_set_mlp_stamps(void *p) { g_mlp_stamps = static_cast<unsigned long long *>(p); }
+#endif
 
 extern "C" int fv3hip_mlp_destroy(fv3hip_mlp_t m)
 {
@@ -749,9 +938,13 @@ extern "C" int fv3hip_mlp_predict(fv3hip_mlp_t m, const void *const *sources, co
     MlpLaunch lp;
     memset(&lp, 0, sizeof(lp));
     const int dt0 = src_dtype[0];
+    const bool src64 = (dt0 == FV3HIP_F64);
     FV3HIP_REQUIRE(dt0 == FV3HIP_F32 || dt0 == FV3HIP_F64, "source dtype must be F32 or F64");
+    FV3HIP_REQUIRE(n_samples < ((int64_t)1 << 32), "n_samples must be below 2^32");
     for (int i = 0; i < m->n_sources; ++i) {
         FV3HIP_REQUIRE(sources[i], "source %d is null", i);
+        FV3HIP_REQUIRE(src_sample_stride[i] >= 0 && src_sample_stride[i] * (dt0 == FV3HIP_F64 ? 8 : 4) < ((int64_t)1 << 32),
+                       "sample stride of source %d must be in [0, 4 GiB)", i);
         if (src_dtype[i] != dt0)
             return fail(FV3HIP_EUNSUPPORTED, "all sources must share one dtype (source 0 is %d, source %d is %d)", dt0, i, src_dtype[i]);
         lp.src[i] = sources[i];
@@ -761,6 +954,8 @@ extern "C" int fv3hip_mlp_predict(fv3hip_mlp_t m, const void *const *sources, co
     for (int i = m->n_sources; i < kMaxSources; ++i) lp.src[i] = sources[0];
     for (int j = 0; j < m->n_outputs + m->n_residual; ++j) {
         FV3HIP_REQUIRE(outputs[j], "output %d is null", j);
+        FV3HIP_REQUIRE(out_sample_stride[j] >= 0 && out_sample_stride[j] * (out_dtype == FV3HIP_F64 ? 8 : 4) < ((int64_t)1 << 32),
+                       "sample stride of output %d must be in [0, 4 GiB)", j);
         lp.out[j] = outputs[j];
         lp.out_fs[j] = out_feat_stride[j];
         lp.out_ss[j] = out_sample_stride[j];
@@ -776,10 +971,28 @@ extern "C" int fv3hip_mlp_predict(fv3hip_mlp_t m, const void *const *sources, co
     lp.n_otab = m->n_otab;
     lp.n_bias = m->n_bias;
     lp.out64 = (out_dtype == FV3HIP_F64);
+    lp.has_limits = m->has_limits;
+    {
+        bool fast = (out_dtype == FV3HIP_F32) && (n_samples % 4 == 0);
+        for (int j = 0; j < m->n_outputs + m->n_residual && fast; ++j)
+            fast = out_sample_stride[j] == 1 && (reinterpret_cast<uintptr_t>(outputs[j]) % 16 == 0) &&
+                   (out_feat_stride[j] % 4 == 0);
+        if (m->n_residual) {
+            fast = fast && !src64;
+            for (int i = 0; i < m->n_sources && fast; ++i)
+                fast = src_sample_stride[i] == 1 && (reinterpret_cast<uintptr_t>(sources[i]) % 16 == 0) &&
+                       (src_feat_stride[i] % 4 == 0);
+        }
+        lp.epi_fast = fast ? 1 : 0;
+    }
+    lp.chunk_log_mask = m->chunk_log_mask;
+    lp.n_residual = m->n_residual;
     lp.n_samples = n_samples;
     lp.n_tiles = ceil_div(n_samples, kTileSamples);
+#ifdef MLP_STAMPS
+    lp.stamps = g_mlp_stamps;
+#endif
     const int grid = (int)(lp.n_tiles < m->n_cu ? lp.n_tiles : m->n_cu);
-    const bool src64 = (dt0 == FV3HIP_F64);
     hipStream_t st = as_stream(stream);
 #define VARIANT_(H, O) \
     if (m->HT == H && m->OC == O) return launch_variant<H, O>(m, lp, src64, grid, m->lds_bytes, st)
@@ -787,7 +1000,7 @@ extern "C" int fv3hip_mlp_predict(fv3hip_mlp_t m, const void *const *sources, co
     VARIANT_(2, 4);
     VARIANT_(4, 4);
     VARIANT_(8, 4);
-    VARIANT_(8, 13);
+    VARIANT_(8, 7);
 #undef VARIANT_
     return fail(FV3HIP_EUNSUPPORTED, "no compiled kernel variant for HT=%d OC=%d", m->HT, m->OC);
 }
