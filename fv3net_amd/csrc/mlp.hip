@@ -121,7 +121,7 @@ struct MlpLaunch {
     int n_otab;
     int n_bias;
     int out64;
-    unsigned long long chunk_log_mask;  // bit c: layer-1 chunk c holds a log-transformed input
+    int n_log_chunks;   // layer-1 chunks [0, n_log_chunks) hold log-transformed inputs (the host orders them first)
     int epi_fast;      // outputs are float32, sample-contiguous and 16-byte aligned: row-wise dwordx4 stores
     int has_limits;    // any output limit or zero mask
     int n_residual;
@@ -139,7 +139,11 @@ struct MlpLaunch {
 // row of a 32x32 accumulator held by register r of a lane in half h is rho(r) + 4*h
 __host__ __device__ constexpr int rho(int r) { return (r & 3) + 8 * (r >> 2); }
 
-template <int HT, int OC, bool SRC64>
+// XBULK: the sources are sample-contiguous and 16-byte aligned, so the inputs of a layer-1 chunk
+// (32 features x 128 samples) are brought in by the whole workgroup with 16-byte loads, normalised
+// four at a time and parked in LDS; a k-pair slot then needs one ds_read for its B operand
+// instead of a table lookup, an address computation, a 4-byte load and the normalisation.
+template <int HT, int OC, bool SRC64, bool XBULK>
 __global__ __launch_bounds__(kThreads, 1) void mlp_fused_kernel(const MlpLaunch p)
 {
     constexpr int HG = (HT + 3) / 4;          // float4 groups of hidden-feature tiles
@@ -156,7 +160,8 @@ __global__ __launch_bounds__(kThreads, 1) void mlp_fused_kernel(const MlpLaunch 
 
     extern __shared__ __attribute__((aligned(16))) char smem[];
     f32x4 *wbuf = reinterpret_cast<f32x4 *>(smem);                       // [2][CH_MAX]
-    XAddr *xa_tab = reinterpret_cast<XAddr *>(wbuf + 2 * CH_MAX);        // [n_ktab] where input k lives
+    float *xs = reinterpret_cast<float *>(wbuf + 2 * CH_MAX);            // [2][32][128] normalised inputs (XBULK)
+    XAddr *xa_tab = reinterpret_cast<XAddr *>(xs + (XBULK ? 2 * 32 * kTileSamples : 0));  // [n_ktab] where input k lives
     XNorm *xn_tab = reinterpret_cast<XNorm *>(xa_tab + p.n_ktab);        // [n_ktab] how it is normalised
     OFast *ofast = reinterpret_cast<OFast *>(xn_tab + p.n_ktab);         // [n_otab]
     OSlow *oslow = reinterpret_cast<OSlow *>(ofast + p.n_otab);          // [n_otab]
@@ -319,6 +324,51 @@ __global__ __launch_bounds__(kThreads, 1) void mlp_fused_kernel(const MlpLaunch 
 #define STAMP_BEGIN() ((void)0)
 #define STAMP_END(i) ((void)0)
 #endif
+    // ---- XBULK: cooperative staging of a layer-1 chunk's inputs ----
+    typedef double d64x2 __attribute__((ext_vector_type(2)));
+    const int sg = tid & 31;  // sample group: samples 4*sg .. 4*sg+3 of the workgroup's 128
+    const int fr = tid >> 5;  // feature rows fr, fr+8, fr+16, fr+24 of the chunk's 32
+    f32x4 braw[XBULK && !SRC64 ? 4 : 1];
+    d64x2 brawd[XBULK && SRC64 ? 4 : 1][2];
+    auto bulk_issue = [&](int c, int64_t tile_n0) {
+        int64_t nb = tile_n0 + 4 * sg;
+        if (nb > p.n_samples - 4) nb = p.n_samples - 4;  // tail: those samples are never stored
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            const XAddr a = xa_tab[c * 32 + fr + 8 * i];
+            const int64_t addr = a.row + (a.ss ? nb * (SRC64 ? 8 : 4) : 0);
+            if (SRC64) {
+                typedef const d64x2 __attribute__((address_space(1))) *GD2;
+                brawd[SRC64 ? i : 0][0] = *(GD2)addr;
+                brawd[SRC64 ? i : 0][1] = *(GD2)(addr + 16);
+            } else {
+                typedef const f32x4 __attribute__((address_space(1))) *GF4;
+                braw[SRC64 ? 0 : i] = *(GF4)addr;
+            }
+        }
+    };
+    auto bulk_finish1 = [&](int c, int i, int buf, auto with_log) {
+        const int kk = fr + 8 * i;
+        const XNorm e = xn_tab[c * 32 + kk];
+        f32x4 v;
+        if (SRC64) {
+            const d64x2 lo = brawd[SRC64 ? i : 0][0], hi = brawd[SRC64 ? i : 0][1];
+            v[0] = (float)lo[0]; v[1] = (float)lo[1]; v[2] = (float)hi[0]; v[3] = (float)hi[1];
+        } else {
+            v = braw[SRC64 ? 0 : i];
+        }
+        if (decltype(with_log)::value) {
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+                const float lg = logf(v[q] < e.eps ? e.eps : v[q]);
+                v[q] = (e.flags & 1) ? lg : v[q];
+            }
+        }
+        v = (v - e.center) * e.rscale;
+        *reinterpret_cast<f32x4 *>(xs + (buf * 32 + kk) * kTileSamples + 4 * sg) = v;
+    };
+    int xb = 0;  // xs buffer the current layer-1 chunk reads
+
     int par = 0;  // LDS buffer holding the chunk about to be consumed
     int64_t tile = blockIdx.x;
     if (tile >= p.n_tiles) return;
@@ -326,14 +376,19 @@ __global__ __launch_bounds__(kThreads, 1) void mlp_fused_kernel(const MlpLaunch 
     // prime the pipeline: chunk 0 of the stream and the first tile's first inputs
     {
         int64_t n = tile * kTileSamples + wave * 32 + (lane & 31);
-        issue_x(0, n < p.n_samples ? n : p.n_samples - 1);
+        if (XBULK) bulk_issue(0, tile * kTileSamples); else issue_x(0, n < p.n_samples ? n : p.n_samples - 1);
 #pragma unroll
         for (int part = 0; part < 2; ++part) {
             issue_w(0, part);
 #pragma unroll
             for (int i = 0; i < NVH; ++i) commit_w1(0, part, i);
         }
-        finish_x(0);
+        if (XBULK) {
+#pragma unroll
+            for (int i = 0; i < 4; ++i) bulk_finish1(0, i, 0, std::true_type{});
+        } else {
+            finish_x(0);
+        }
         __syncthreads();
     }
 
@@ -361,14 +416,19 @@ __global__ __launch_bounds__(kThreads, 1) void mlp_fused_kernel(const MlpLaunch 
             //     has 8 slots (>= 4096 cycles) to land and the VALU work rides under the MFMAs;
             //   * the staged weights of the next chunk go to the other LDS buffer one float4 per
             //     slot in the second half of the chunk.
-            for (int c = 0; c < p.n_chunks1; ++c) {
+            // The host orders the input features with the log-transformed ones first, so chunks
+            // [0, n_log_chunks) need the transform and the rest finish an element with a subtract
+            // and a multiply.  Each kind has its own chunk loop: a flavour branch INSIDE one loop
+            // makes the register allocator shuttle all 128 accumulator registers between AGPRs and
+            // VGPRs on every chunk (measured: +2000 cycles per chunk).
+            using T_ = std::true_type;
+            using F_ = std::false_type;
+            const int L = p.n_log_chunks, NC = p.n_chunks1;
+            // per-sample path: chunk c consumes xcur, finishes its elements 8..15 in the first half of
+            // the slots and requests/finishes elements 0..7 of chunk cn in the second half
+            auto l1_chunk = [&](int c, int cn, auto with_log) __attribute__((always_inline)) {
                 const int gnext = (g + 1 < G) ? g + 1 : 0;
-                const int cn = (c + 1 < p.n_chunks1) ? c + 1 : c;
                 const f32x4 *lw = wbuf + par * CH_MAX + lane;
-                // The slot loop exists in four flavours: whether this chunk (elements 8..15, finished in
-                // the first half) and the next one (elements 0..7, second half) hold log-transformed
-                // inputs.  Chunks without them finish an element with a subtract and a multiply.
-                auto run_slots = [&](auto log_c, auto log_n) {
                 f32x4 a_cur[HG], a_nxt[HG];
 #pragma unroll
                 for (int j = 0; j < HG; ++j) a_cur[j] = lw[j * 64];
@@ -383,10 +443,8 @@ __global__ __launch_bounds__(kThreads, 1) void mlp_fused_kernel(const MlpLaunch 
                     if (s + 1 < KC_H) {
 #pragma unroll
                         for (int j = 0; j < HG; ++j) a_nxt[j] = lw[((s + 1) * HG + j) * 64];
-#ifndef MLP_ABLATE_TABLES
                         xa_nxt = xa_n[2 * (s + 1)];
                         xn_nxt = (s + 1 < KC_H / 2) ? xn_c[2 * (s + 1 + KC_H / 2)] : xn_n[2 * (s + 1 - KC_H / 2)];
-#endif
                     }
                     const float b = xcur[s];
 #pragma unroll
@@ -395,16 +453,9 @@ __global__ __launch_bounds__(kThreads, 1) void mlp_fused_kernel(const MlpLaunch 
                     // No branches in a slot (the scheduler only interleaves inside a basic block): on
                     // the last chunk the "next chunk" is the chunk itself, which re-derives values
                     // that are already there; re-finishing elements 8..15 of chunk 0 is idempotent.
-#ifndef MLP_ABLATE_ISSUE
                     issue_x1(xa_cur, s, nc);
-#endif
-#ifndef MLP_ABLATE_FINISH
-                    if (s < KC_H / 2) {
-                        if (decltype(log_c)::value) finish_x1(xn_cur, s + KC_H / 2); else finish_x1_plain(xn_cur, s + KC_H / 2);
-                    } else {
-                        if (decltype(log_n)::value) finish_x1(xn_cur, s - KC_H / 2); else finish_x1_plain(xn_cur, s - KC_H / 2);
-                    }
-#endif
+                    const int el = (s < KC_H / 2) ? s + KC_H / 2 : s - KC_H / 2;
+                    if (decltype(with_log)::value) finish_x1(xn_cur, el); else finish_x1_plain(xn_cur, el);
                     stage_step(s, KC_H, gnext, par ^ 1);
 #pragma unroll
                     for (int j = 0; j < HG; ++j) a_cur[j] = a_nxt[j];
@@ -412,15 +463,59 @@ __global__ __launch_bounds__(kThreads, 1) void mlp_fused_kernel(const MlpLaunch 
                     xn_cur = xn_nxt;
                     MLP_SLOT_SCHED(HT, 5);
                 }
-                };
-                const bool lc = (p.chunk_log_mask >> c) & 1, ln = (p.chunk_log_mask >> cn) & 1;
-                using T_ = std::true_type;
-                using F_ = std::false_type;
-                if (lc) { if (ln) run_slots(T_{}, T_{}); else run_slots(T_{}, F_{}); }
-                else { if (ln) run_slots(F_{}, T_{}); else run_slots(F_{}, F_{}); }
                 MLP_CHUNK_BARRIER();
                 par ^= 1;
                 ++g;
+            };
+            // XBULK path: the B operand comes from the LDS input tile xs[xb]; the tile of chunk cn of
+            // the workgroup tile starting at sample n0 is requested in slot 0 (4 x 16-byte loads per
+            // thread) and normalised and written to xs[xb ^ 1] in slots 8..11.
+            auto l1_chunk_bulk = [&](int cn, int64_t n0, auto with_log) __attribute__((always_inline)) {
+                const int gnext = (g + 1 < G) ? g + 1 : 0;
+                const f32x4 *lw = wbuf + par * CH_MAX + lane;
+                f32x4 a_cur[HG], a_nxt[HG];
+#pragma unroll
+                for (int j = 0; j < HG; ++j) a_cur[j] = lw[j * 64];
+                const float *xsb = xs + xb * 32 * kTileSamples + half * kTileSamples + wave * 32 + (lane & 31);
+                float b_cur = xsb[0], b_nxt = b_cur;
+#pragma unroll
+                for (int s = 0; s < KC_H; ++s) {
+                    if (s + 1 < KC_H) {
+#pragma unroll
+                        for (int j = 0; j < HG; ++j) a_nxt[j] = lw[((s + 1) * HG + j) * 64];
+                        b_nxt = xsb[2 * (s + 1) * kTileSamples];
+                    }
+#pragma unroll
+                    for (int t = 0; t < HT; ++t)
+                        h[t] = __builtin_amdgcn_mfma_f32_32x32x2f32(a_cur[t / 4][t % 4], b_cur, h[t], 0, 0, 0);
+                    if (s == 0) bulk_issue(cn, n0);
+                    if (s >= KC_H / 2 && s < KC_H / 2 + 4) bulk_finish1(cn, s - KC_H / 2, xb ^ 1, with_log);
+                    stage_step(s, KC_H, gnext, par ^ 1);
+#pragma unroll
+                    for (int j = 0; j < HG; ++j) a_cur[j] = a_nxt[j];
+                    b_cur = b_nxt;
+                    MLP_SLOT_SCHED(HT, 5);
+                }
+                MLP_CHUNK_BARRIER();
+                par ^= 1;
+                xb ^= 1;
+                ++g;
+            };
+            if (XBULK) {
+                const int64_t n0 = tile * kTileSamples;
+                int c = 0;
+                for (; c < L - 1; ++c) l1_chunk_bulk(c + 1, n0, T_{});
+                for (; c < NC - 1; ++c) l1_chunk_bulk(c + 1, n0, F_{});
+                // the last chunk brings in chunk 0 of the workgroup's next tile
+                const int64_t n1 = (next_tile < p.n_tiles ? next_tile : tile) * kTileSamples;
+                if (L > 0) l1_chunk_bulk(0, n1, T_{}); else l1_chunk_bulk(0, n1, F_{});
+            } else {
+                // a chunk that mixes both kinds (the boundary chunk, or the re-derivation on the last
+                // chunk) takes the with-log flavour, which selects per feature
+                int c = 0;
+                for (; c < L && c < NC - 1; ++c) l1_chunk(c, c + 1, T_{});
+                for (; c < NC - 1; ++c) l1_chunk(c, c + 1, F_{});
+                if (L > 0) l1_chunk(NC - 1, NC - 1, T_{}); else l1_chunk(NC - 1, NC - 1, F_{});
             }
 #pragma unroll
             for (int t = 0; t < HT; ++t)
@@ -510,7 +605,7 @@ __global__ __launch_bounds__(kThreads, 1) void mlp_fused_kernel(const MlpLaunch 
                 }
             }
             STAMP_END(2);
-            if (prefetch_next) issue_x(0, nn);
+            if (!XBULK && prefetch_next) issue_x(0, nn);
             // ---- epilogue: denormalise, limit, mask, store (+ residual outputs) ----
             // Fast path (float32 outputs, contiguous samples, a full 32-sample wave tile): each
             // 32-feature x 32-sample accumulator tile goes through the wave's 4 KB slice of the idle
@@ -608,7 +703,7 @@ __global__ __launch_bounds__(kThreads, 1) void mlp_fused_kernel(const MlpLaunch 
                     }
                 }
             }
-            if (prefetch_next) finish_x(0);
+            if (!XBULK && prefetch_next) finish_x(0);
             MLP_CHUNK_BARRIER();
             STAMP_END(3);
         }
@@ -645,7 +740,7 @@ struct fv3hip_mlp {
     int n_chunks1 = 0, n_pass = 0, n_ktab = 0, n_otab = 0, n_bias = 0;
     int64_t flops = 0;
     int has_limits = 0;
-    unsigned long long chunk_log_mask = 0;
+    int n_log_chunks = 0;
     void *d_w = nullptr, *d_ktab = nullptr, *d_otab = nullptr, *d_bias = nullptr;
     int n_cu = 256;
     size_t lds_bytes = 0;
@@ -660,22 +755,22 @@ struct Variant {
 // slower than {8, 7}: 208 + 128 accumulator registers leave too little for the pipeline's staging)
 const Variant kVariants[] = {{1, 4}, {2, 4}, {4, 4}, {8, 4}, {8, 7}};
 
-template <int HT, int OC>
-int launch_variant(const fv3hip_mlp *m, const MlpLaunch &lp, bool src64, int grid, size_t lds, hipStream_t st)
+template <int HT, int OC, bool SRC64, bool XBULK>
+int launch_one(const MlpLaunch &lp, int grid, size_t lds, hipStream_t st)
 {
-    if (src64) {
-        auto kern = mlp_fused_kernel<HT, OC, true>;
-        FV3HIP_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(kern),
-                                             hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-        hipLaunchKernelGGL(kern, dim3(grid), dim3(kThreads), lds, st, lp);
-    } else {
-        auto kern = mlp_fused_kernel<HT, OC, false>;
-        FV3HIP_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(kern),
-                                             hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-        hipLaunchKernelGGL(kern, dim3(grid), dim3(kThreads), lds, st, lp);
-    }
-    (void)m;
+    auto kern = mlp_fused_kernel<HT, OC, SRC64, XBULK>;
+    FV3HIP_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(kern),
+                                         hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+    hipLaunchKernelGGL(kern, dim3(grid), dim3(kThreads), lds, st, lp);
     return check_launch("mlp_fused_kernel");
+}
+
+template <int HT, int OC>
+int launch_variant(const fv3hip_mlp *m, const MlpLaunch &lp, bool src64, bool xbulk, int grid, size_t lds, hipStream_t st)
+{
+    (void)m;
+    if (src64) return xbulk ? launch_one<HT, OC, true, true>(lp, grid, lds, st) : launch_one<HT, OC, true, false>(lp, grid, lds, st);
+    return xbulk ? launch_one<HT, OC, false, true>(lp, grid, lds, st) : launch_one<HT, OC, false, false>(lp, grid, lds, st);
 }
 
 template <typename T>
@@ -776,6 +871,36 @@ extern "C" int fv3hip_mlp_create(const fv3hip_mlp_desc_t *d, fv3hip_mlp_t *out)
     const int n_hid_chunks = m->n_chunks1 + (d->n_hidden - 1) * HT;
     const int n_out_chunks = m->n_pass * HT * OHALVES;
 
+    // ---- input table ----
+    // Network input k' is original input feature perm[k']: the log-transformed features come first
+    // (any order of the contraction index is the same dense layer), so that whole layer-1 chunks
+    // are either with or without the transform.
+    std::vector<KEntry> ktab(m->n_ktab);
+    for (auto &e : ktab) e = KEntry{-1, 0, 0.f, 1.f, 0, 0.f, 0, 0};
+    std::vector<int> perm;
+    perm.reserve(K);
+    {
+        std::vector<KEntry> orig(K);
+        int k = 0;
+        for (int i = 0; i < d->n_inputs; ++i)
+            for (int f = 0; f < d->in_nfeat[i]; ++f, ++k) {
+                KEntry &e = orig[k];
+                e = KEntry{-1, 0, 0.f, 1.f, 0, 0.f, 0, 0};
+                e.src = d->in_source[i];
+                e.feat = d->in_feat_start[i] + f;
+                e.center = d->in_center ? d->in_center[k] : 0.f;
+                e.scale = d->in_scale ? (float)(1.0 / (double)d->in_scale[k]) : 1.f;  // reciprocal
+                e.transform = d->in_transform ? d->in_transform[i] : 0;
+                e.eps = d->in_eps ? d->in_eps[i] : 0.f;
+            }
+        for (int k2 = 0; k2 < K; ++k2)
+            if (orig[k2].transform == FV3HIP_TRANSFORM_LOG) perm.push_back(k2);
+        const int n_log = (int)perm.size();
+        for (int k2 = 0; k2 < K; ++k2)
+            if (orig[k2].transform != FV3HIP_TRANSFORM_LOG) perm.push_back(k2);
+        for (int k2 = 0; k2 < K; ++k2) ktab[k2] = orig[perm[k2]];
+        m->n_log_chunks = (n_log + 31) / 32;
+    }
     // ---- packed weight stream ----
     // (+ one maximal chunk of zero padding: the two-half staging may read past a short last chunk)
     std::vector<float> w((size_t)(n_hid_chunks * CH_H + n_out_chunks * CH_O + (CH_H > CH_O ? CH_H : CH_O)) * 4, 0.f);
@@ -792,7 +917,7 @@ extern "C" int fv3hip_mlp_create(const fv3hip_mlp_desc_t *d, fv3hip_mlp_t *out)
                         for (int e = 0; e < 4; ++e) {
                             const int k = 2 * (g * 16 + s) + (lane >> 5);
                             const int f = 32 * (4 * j + e) + (lane & 31);
-                            if (k < K && f < width) hid_slot(g, s, j, lane, e) = W[(size_t)k * width + f];
+                            if (k < K && f < width) hid_slot(g, s, j, lane, e) = W[(size_t)perm[k] * width + f];
                         }
     }
     // hidden layers l >= 1: k = 32*kt + rho(s) + 4*half (the accumulator layout of the layer before)
@@ -831,23 +956,6 @@ extern "C" int fv3hip_mlp_create(const fv3hip_mlp_desc_t *d, fv3hip_mlp_t *out)
                                             W[(size_t)k * F + f];
                                 }
                 }
-    }
-    // ---- input table ----
-    std::vector<KEntry> ktab(m->n_ktab);
-    for (auto &e : ktab) e = KEntry{-1, 0, 0.f, 1.f, 0, 0.f, 0, 0};
-    {
-        int k = 0;
-        for (int i = 0; i < d->n_inputs; ++i)
-            for (int f = 0; f < d->in_nfeat[i]; ++f, ++k) {
-                KEntry &e = ktab[k];
-                e.src = d->in_source[i];
-                e.feat = d->in_feat_start[i] + f;
-                e.center = d->in_center ? d->in_center[k] : 0.f;
-                e.scale = d->in_scale ? (float)(1.0 / (double)d->in_scale[k]) : 1.f;  // reciprocal
-                e.transform = d->in_transform ? d->in_transform[i] : 0;
-                if (e.transform == FV3HIP_TRANSFORM_LOG) m->chunk_log_mask |= 1ull << (k / 32);
-                e.eps = d->in_eps ? d->in_eps[i] : 0.f;
-            }
     }
     // ---- output table ----
     std::vector<OEntry> otab(m->n_otab);
@@ -894,7 +1002,7 @@ extern "C" int fv3hip_mlp_create(const fv3hip_mlp_desc_t *d, fv3hip_mlp_t *out)
         return rc;
     }
     const size_t wb = 2 * (size_t)((CH_H > CH_O) ? CH_H : CH_O) * 16;
-    m->lds_bytes = wb + (size_t)m->n_ktab * sizeof(KEntry) +
+    m->lds_bytes = wb + 2 * 32 * kTileSamples * sizeof(float) /* XBULK input tiles */ + (size_t)m->n_ktab * sizeof(KEntry) +
                    (size_t)m->n_otab * (sizeof(OFast) + sizeof(OSlow) + (d->n_residual ? sizeof(ORes) : 0)) +
                    (size_t)((m->n_bias + 3) & ~3) * sizeof(float) + (size_t)(3 * kMaxSources + 3 * kMaxOutputs) * 8;
     if (m->lds_bytes > 160 * 1024) {
@@ -985,7 +1093,7 @@ extern "C" int fv3hip_mlp_predict(fv3hip_mlp_t m, const void *const *sources, co
         }
         lp.epi_fast = fast ? 1 : 0;
     }
-    lp.chunk_log_mask = m->chunk_log_mask;
+    lp.n_log_chunks = m->n_log_chunks;
     lp.n_residual = m->n_residual;
     lp.n_samples = n_samples;
     lp.n_tiles = ceil_div(n_samples, kTileSamples);
@@ -993,13 +1101,20 @@ extern "C" int fv3hip_mlp_predict(fv3hip_mlp_t m, const void *const *sources, co
     lp.stamps = g_mlp_stamps;
 #endif
     const int grid = (int)(lp.n_tiles < m->n_cu ? lp.n_tiles : m->n_cu);
+    // inputs of a chunk are staged cooperatively when every source is sample-contiguous and aligned
+    bool xbulk = (n_samples % 4 == 0) && (n_samples >= 4);
+    for (int i = 0; i < m->n_sources && xbulk; ++i)
+        xbulk = src_sample_stride[i] == 1 && (reinterpret_cast<uintptr_t>(sources[i]) % 16 == 0) &&
+                (src_feat_stride[i] % (src64 ? 2 : 4) == 0);
     hipStream_t st = as_stream(stream);
 #define VARIANT_(H, O) \
-    if (m->HT == H && m->OC == O) return launch_variant<H, O>(m, lp, src64, grid, m->lds_bytes, st)
+    if (m->HT == H && m->OC == O) return launch_variant<H, O>(m, lp, src64, xbulk, grid, m->lds_bytes, st)
+#ifndef MLP_FAST_BUILD  // (experiments compile the flagship variant only)
     VARIANT_(1, 4);
     VARIANT_(2, 4);
     VARIANT_(4, 4);
     VARIANT_(8, 4);
+#endif
     VARIANT_(8, 7);
 #undef VARIANT_
     return fail(FV3HIP_EUNSUPPORTED, "no compiled kernel variant for HT=%d OC=%d", m->HT, m->OC);
