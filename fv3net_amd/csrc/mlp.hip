@@ -243,6 +243,7 @@ __global__ __launch_bounds__(kThreads, 1) void mlp_fused_kernel(const MlpLaunch 
     }
     __syncthreads();
 
+    int par = 0;  // LDS buffer holding the chunk about to be consumed
     // ---- weight-stream helpers ----
     const int n_hid_chunks = p.n_chunks1 + (p.n_hidden - 1) * HT;  // hidden-type chunks per tile
     const int n_out_chunks = p.n_pass * HT * OHALVES;              // output-type chunks per tile
@@ -259,14 +260,21 @@ __global__ __launch_bounds__(kThreads, 1) void mlp_fused_kernel(const MlpLaunch 
     // (for a chunk type with fewer than 2*NVH float4s per thread the second half reads on into the
     // stream -- the host pads it by one maximal chunk -- and lands in LDS words nobody reads)
     auto issue_w = [&](int g, int part) {  // global -> registers
+#ifndef MLP_ABLATE_WLOAD
         const f32x4 *gp = chunk_src(g) + part * NVH * kThreads;
 #pragma unroll
         for (int i = 0; i < NVH; ++i) stage[i] = gp[i * kThreads];
+#endif
     };
     auto commit_w1 = [&](int buf, int part, int i) {  // one staged float4 -> the other LDS buffer
+#ifndef MLP_ABLATE_WCOMMIT
         if (i < NVH) wbuf[buf * CH_MAX + tid + (part * NVH + i) * kThreads] = stage[i];
+#else
+        if (i < NVH) asm volatile("" ::"v"(stage[i]));
+#endif
     };
-    // slot s of a chunk of KC slots: its share of staging chunk `gnext` into buffer `buf`
+    // slot s of a chunk of KC slots: its share of staging chunk `gnext` into buffer `buf`.  The last
+    // slot stages nothing: it opens with the chunk barrier (see run_slot).
     auto stage_step = [&](int s, int KC, int gnext, int buf) {
         const int Q = KC / 4, per = (NVH + Q - 1) / Q;
         if (s == 0) issue_w(gnext, 0);
@@ -274,10 +282,51 @@ __global__ __launch_bounds__(kThreads, 1) void mlp_fused_kernel(const MlpLaunch 
 #pragma unroll
             for (int i = 0; i < per; ++i) commit_w1(buf, 0, (s - Q) * per + i);
         }
-        if (s == 2 * Q) issue_w(gnext, 1);
-        if (s >= 3 * Q) {
+        if (s == 2 * Q - 1) issue_w(gnext, 1);  // (after this slot's commit, which frees the registers)
+        if (s >= 3 * Q - 1 && s < 4 * Q - 1) {
 #pragma unroll
-            for (int i = 0; i < per; ++i) commit_w1(buf, 1, (s - 3 * Q) * per + i);
+            for (int i = 0; i < per; ++i) commit_w1(buf, 1, (s - (3 * Q - 1)) * per + i);
+        }
+    };
+    // One k-pair slot: NT MFMAs on the A fragments in a_cur, with the A fragments of the next slot
+    // read from LDS meanwhile.  The chunk barrier sits at the START of the chunk's last slot, not
+    // after it: by then every wave has committed its share of the next chunk (stage_step) and issued
+    // its last read of this one, so after the barrier the first fragments of the NEXT chunk are
+    // read from the other buffer under the last slot's MFMAs -- no LDS latency is exposed at a
+    // chunk boundary.  (__syncthreads() would also drain vmcnt; only LDS traffic matters here.)
+    constexpr int AG = (HG > OG) ? HG : OG;
+    f32x4 a_cur[AG];
+    auto run_slot = [&](auto &acc, auto nt_c, auto ng_c, auto q_c, int s, int KC, float b, auto &&side) __attribute__((always_inline)) {
+        constexpr int NT = decltype(nt_c)::value, NG = decltype(ng_c)::value, Q = decltype(q_c)::value;
+        f32x4 a_nxt[AG];
+        if (s + 1 < KC) {
+            const f32x4 *lw = wbuf + par * CH_MAX + lane;
+#pragma unroll
+            for (int j = 0; j < NG; ++j) a_nxt[j] = lw[((s + 1) * NG + j) * 64];
+#pragma unroll
+            for (int j = NG; j < AG; ++j) a_nxt[j] = a_cur[j];
+#pragma unroll
+            for (int t = 0; t < NT; ++t)
+                acc[t] = __builtin_amdgcn_mfma_f32_32x32x2f32(a_cur[t / 4][t % 4], b, acc[t], 0, 0, 0);
+            side(s);
+#pragma unroll
+            for (int j = 0; j < AG; ++j) a_cur[j] = a_nxt[j];
+            MLP_SLOT_SCHED(NT, Q);
+        } else {
+            acc[0] = __builtin_amdgcn_mfma_f32_32x32x2f32(a_cur[0][0], b, acc[0], 0, 0, 0);
+            __builtin_amdgcn_sched_barrier(0);
+            MLP_CHUNK_BARRIER();
+            __builtin_amdgcn_sched_barrier(0);
+            const f32x4 *lwn = wbuf + (par ^ 1) * CH_MAX + lane;
+#pragma unroll
+            for (int j = 0; j < AG; ++j) a_nxt[j] = lwn[j * 64];
+#pragma unroll
+            for (int t = 1; t < NT; ++t)
+                acc[t] = __builtin_amdgcn_mfma_f32_32x32x2f32(a_cur[t / 4][t % 4], b, acc[t], 0, 0, 0);
+            side(s);
+#pragma unroll
+            for (int j = 0; j < AG; ++j) a_cur[j] = a_nxt[j];
+            MLP_SLOT_SCHED(NT - 1, Q);
         }
     };
 
@@ -313,6 +362,7 @@ __global__ __launch_bounds__(kThreads, 1) void mlp_fused_kernel(const MlpLaunch 
     };
 #ifdef MLP_STAMPS
     unsigned long long st_acc[6] = {0, 0, 0, 0, 0, 0}, st_t0 = 0;
+    unsigned long long sl_acc[17] = {0,0,0,0,0,0,0,0,0,0,0,0,0,0,0,0,0};
 #define STAMP_BEGIN() st_t0 = __builtin_readcyclecounter()
 #define STAMP_END(i)                                         \
     {                                                        \
@@ -330,26 +380,34 @@ __global__ __launch_bounds__(kThreads, 1) void mlp_fused_kernel(const MlpLaunch 
     const int fr = tid >> 5;  // feature rows fr, fr+8, fr+16, fr+24 of the chunk's 32
     f32x4 braw[XBULK && !SRC64 ? 4 : 1];
     d64x2 brawd[XBULK && SRC64 ? 4 : 1][2];
-    auto bulk_issue = [&](int c, int64_t tile_n0) {
+    auto bulk_sample = [&](int64_t tile_n0) -> unsigned int {
         int64_t nb = tile_n0 + 4 * sg;
         if (nb > p.n_samples - 4) nb = p.n_samples - 4;  // tail: those samples are never stored
-#pragma unroll
-        for (int i = 0; i < 4; ++i) {
-            const XAddr a = xa_tab[c * 32 + fr + 8 * i];
-            const int64_t addr = a.row + (a.ss ? nb * (SRC64 ? 8 : 4) : 0);
-            if (SRC64) {
-                typedef const d64x2 __attribute__((address_space(1))) *GD2;
-                brawd[SRC64 ? i : 0][0] = *(GD2)addr;
-                brawd[SRC64 ? i : 0][1] = *(GD2)(addr + 16);
-            } else {
-                typedef const f32x4 __attribute__((address_space(1))) *GF4;
-                braw[SRC64 ? 0 : i] = *(GF4)addr;
-            }
+        return (unsigned int)nb;
+    };
+    auto bulk_issue1 = [&](const XAddr a, int i, unsigned int nb) {
+        // one v_mad_u64_u32 (a.ss is the sample stride in bytes, 0 for the padding rows)
+        const int64_t addr = a.row + (int64_t)((uint64_t)nb * (uint64_t)a.ss);
+        if (SRC64) {
+            typedef const d64x2 __attribute__((address_space(1))) *GD2;
+            brawd[SRC64 ? i : 0][0] = *(GD2)addr;
+            brawd[SRC64 ? i : 0][1] = *(GD2)(addr + (a.ss ? 16 : 0));
+        } else {
+            typedef const f32x4 __attribute__((address_space(1))) *GF4;
+#ifdef MLP_NT_X
+            braw[SRC64 ? 0 : i] = __builtin_nontemporal_load((GF4)addr);
+#else
+            braw[SRC64 ? 0 : i] = *(GF4)addr;
+#endif
         }
     };
-    auto bulk_finish1 = [&](int c, int i, int buf, auto with_log) {
+    auto bulk_issue = [&](int c, int64_t tile_n0) {
+        const unsigned int nb = bulk_sample(tile_n0);
+#pragma unroll
+        for (int i = 0; i < 4; ++i) bulk_issue1(xa_tab[c * 32 + fr + 8 * i], i, nb);
+    };
+    auto bulk_finish_e = [&](const XNorm e, int i, int buf, auto with_log) {
         const int kk = fr + 8 * i;
-        const XNorm e = xn_tab[c * 32 + kk];
         f32x4 v;
         if (SRC64) {
             const d64x2 lo = brawd[SRC64 ? i : 0][0], hi = brawd[SRC64 ? i : 0][1];
@@ -364,12 +422,20 @@ __global__ __launch_bounds__(kThreads, 1) void mlp_fused_kernel(const MlpLaunch 
                 v[q] = (e.flags & 1) ? lg : v[q];
             }
         }
+#ifndef MLP_ABLATE_FMATH
         v = (v - e.center) * e.rscale;
+#endif
+#ifndef MLP_ABLATE_FWRITE
         *reinterpret_cast<f32x4 *>(xs + (buf * 32 + kk) * kTileSamples + 4 * sg) = v;
+#else
+        asm volatile("" ::"v"(v));
+#endif
+    };
+    auto bulk_finish1 = [&](int c, int i, int buf, auto with_log) {
+        bulk_finish_e(xn_tab[c * 32 + fr + 8 * i], i, buf, with_log);
     };
     int xb = 0;  // xs buffer the current layer-1 chunk reads
 
-    int par = 0;  // LDS buffer holding the chunk about to be consumed
     int64_t tile = blockIdx.x;
     if (tile >= p.n_tiles) return;
 
@@ -390,7 +456,10 @@ __global__ __launch_bounds__(kThreads, 1) void mlp_fused_kernel(const MlpLaunch 
             finish_x(0);
         }
         __syncthreads();
+#pragma unroll
+        for (int j = 0; j < AG; ++j) a_cur[j] = wbuf[lane + j * 64];
     }
+    float b_cur = XBULK ? xs[half * kTileSamples + wave * 32 + (lane & 31)] : 0.f;  // XBULK: B operand of the next slot
 
     for (; tile < p.n_tiles; tile += gridDim.x) {
         const int64_t n = tile * kTileSamples + wave * 32 + (lane & 31);
@@ -426,12 +495,11 @@ __global__ __launch_bounds__(kThreads, 1) void mlp_fused_kernel(const MlpLaunch 
             const int L = p.n_log_chunks, NC = p.n_chunks1;
             // per-sample path: chunk c consumes xcur, finishes its elements 8..15 in the first half of
             // the slots and requests/finishes elements 0..7 of chunk cn in the second half
+            using HT_c = std::integral_constant<int, HT>;
+            using HG_c = std::integral_constant<int, HG>;
+            using Q5_c = std::integral_constant<int, 5>;
             auto l1_chunk = [&](int c, int cn, auto with_log) __attribute__((always_inline)) {
                 const int gnext = (g + 1 < G) ? g + 1 : 0;
-                const f32x4 *lw = wbuf + par * CH_MAX + lane;
-                f32x4 a_cur[HG], a_nxt[HG];
-#pragma unroll
-                for (int j = 0; j < HG; ++j) a_cur[j] = lw[j * 64];
                 // table entries are read one slot ahead of their use
                 const XAddr *xa_n = xa_tab + 2 * cn * KC_H + half;    // issue: element s of chunk cn
                 const XNorm *xn_c = xn_tab + 2 * c * KC_H + half;     // finish, first half: chunk c, s+8
@@ -440,63 +508,78 @@ __global__ __launch_bounds__(kThreads, 1) void mlp_fused_kernel(const MlpLaunch 
                 XNorm xn_cur = xn_c[2 * (KC_H / 2)], xn_nxt = xn_cur;
 #pragma unroll
                 for (int s = 0; s < KC_H; ++s) {
-                    if (s + 1 < KC_H) {
-#pragma unroll
-                        for (int j = 0; j < HG; ++j) a_nxt[j] = lw[((s + 1) * HG + j) * 64];
-                        xa_nxt = xa_n[2 * (s + 1)];
-                        xn_nxt = (s + 1 < KC_H / 2) ? xn_c[2 * (s + 1 + KC_H / 2)] : xn_n[2 * (s + 1 - KC_H / 2)];
-                    }
-                    const float b = xcur[s];
-#pragma unroll
-                    for (int t = 0; t < HT; ++t)
-                        h[t] = __builtin_amdgcn_mfma_f32_32x32x2f32(a_cur[t / 4][t % 4], b, h[t], 0, 0, 0);
                     // No branches in a slot (the scheduler only interleaves inside a basic block): on
                     // the last chunk the "next chunk" is the chunk itself, which re-derives values
                     // that are already there; re-finishing elements 8..15 of chunk 0 is idempotent.
-                    issue_x1(xa_cur, s, nc);
-                    const int el = (s < KC_H / 2) ? s + KC_H / 2 : s - KC_H / 2;
-                    if (decltype(with_log)::value) finish_x1(xn_cur, el); else finish_x1_plain(xn_cur, el);
-                    stage_step(s, KC_H, gnext, par ^ 1);
-#pragma unroll
-                    for (int j = 0; j < HG; ++j) a_cur[j] = a_nxt[j];
-                    xa_cur = xa_nxt;
-                    xn_cur = xn_nxt;
-                    MLP_SLOT_SCHED(HT, 5);
+                    run_slot(h, HT_c{}, HG_c{}, Q5_c{}, s, KC_H, xcur[s], [&](int s_) {
+                        if (s_ + 1 < KC_H) {
+                            xa_nxt = xa_n[2 * (s_ + 1)];
+                            xn_nxt = (s_ + 1 < KC_H / 2) ? xn_c[2 * (s_ + 1 + KC_H / 2)] : xn_n[2 * (s_ + 1 - KC_H / 2)];
+                        }
+                        issue_x1(xa_cur, s_, nc);
+                        const int el = (s_ < KC_H / 2) ? s_ + KC_H / 2 : s_ - KC_H / 2;
+                        if (decltype(with_log)::value) finish_x1(xn_cur, el); else finish_x1_plain(xn_cur, el);
+                        stage_step(s_, KC_H, gnext, par ^ 1);
+                        xa_cur = xa_nxt;
+                        xn_cur = xn_nxt;
+                    });
                 }
-                MLP_CHUNK_BARRIER();
                 par ^= 1;
                 ++g;
             };
             // XBULK path: the B operand comes from the LDS input tile xs[xb]; the tile of chunk cn of
-            // the workgroup tile starting at sample n0 is requested in slot 0 (4 x 16-byte loads per
-            // thread) and normalised and written to xs[xb ^ 1] in slots 8..11.
+            // the workgroup tile starting at sample n0 is requested in slot 1 (4 x 16-byte loads per
+            // thread) and normalised and written to xs[xb ^ 1] in slots 9..12.
             auto l1_chunk_bulk = [&](int cn, int64_t n0, auto with_log) __attribute__((always_inline)) {
                 const int gnext = (g + 1 < G) ? g + 1 : 0;
-                const f32x4 *lw = wbuf + par * CH_MAX + lane;
-                f32x4 a_cur[HG], a_nxt[HG];
-#pragma unroll
-                for (int j = 0; j < HG; ++j) a_cur[j] = lw[j * 64];
                 const float *xsb = xs + xb * 32 * kTileSamples + half * kTileSamples + wave * 32 + (lane & 31);
-                float b_cur = xsb[0], b_nxt = b_cur;
+                const float *xsn = xs + (xb ^ 1) * 32 * kTileSamples + half * kTileSamples + wave * 32 + (lane & 31);
+                const unsigned int nb = bulk_sample(n0);
+                XAddr xa4[4];
+                XNorm xn4[4];
+#ifdef MLP_STAMPS
+                unsigned long long sl_t = 0;
+#endif
 #pragma unroll
                 for (int s = 0; s < KC_H; ++s) {
-                    if (s + 1 < KC_H) {
-#pragma unroll
-                        for (int j = 0; j < HG; ++j) a_nxt[j] = lw[((s + 1) * HG + j) * 64];
-                        b_nxt = xsb[2 * (s + 1) * kTileSamples];
+#ifdef MLP_STAMPS
+                    if (!decltype(with_log)::value) {
+                        const unsigned long long t_ = __builtin_readcyclecounter();
+                        if (s > 0) sl_acc[s - 1] += t_ - sl_t;
+                        sl_t = t_;
                     }
+#endif
+                    run_slot(h, HT_c{}, HG_c{}, Q5_c{}, s, KC_H, b_cur, [&](int s_) {
+                        // (the last slot runs this after the chunk barrier: xs[xb ^ 1] is complete)
+                        b_cur = (s_ + 1 < KC_H) ? xsb[2 * (s_ + 1) * kTileSamples] : xsn[0];
+                        // table entries are read a slot before they are used
+#ifndef MLP_ABLATE_BISSUE
+                        if (s_ == 0) {
 #pragma unroll
-                    for (int t = 0; t < HT; ++t)
-                        h[t] = __builtin_amdgcn_mfma_f32_32x32x2f32(a_cur[t / 4][t % 4], b_cur, h[t], 0, 0, 0);
-                    if (s == 0) bulk_issue(cn, n0);
-                    if (s >= KC_H / 2 && s < KC_H / 2 + 4) bulk_finish1(cn, s - KC_H / 2, xb ^ 1, with_log);
-                    stage_step(s, KC_H, gnext, par ^ 1);
+                            for (int i = 0; i < 4; ++i) xa4[i] = xa_tab[cn * 32 + fr + 8 * i];
+                        }
+                        if (s_ == 1) {
 #pragma unroll
-                    for (int j = 0; j < HG; ++j) a_cur[j] = a_nxt[j];
-                    b_cur = b_nxt;
-                    MLP_SLOT_SCHED(HT, 5);
+                            for (int i = 0; i < 4; ++i) bulk_issue1(xa4[i], i, nb);
+                        }
+#endif
+#ifndef MLP_ABLATE_BFINISH
+                        if (s_ == KC_H / 2) {
+#pragma unroll
+                            for (int i = 0; i < 4; ++i) xn4[i] = xn_tab[cn * 32 + fr + 8 * i];
+                        }
+                        if (s_ > KC_H / 2 && s_ <= KC_H / 2 + 4) bulk_finish_e(xn4[s_ - KC_H / 2 - 1], s_ - KC_H / 2 - 1, xb ^ 1, with_log);
+#endif
+                        stage_step(s_, KC_H, gnext, par ^ 1);
+                    });
                 }
-                MLP_CHUNK_BARRIER();
+#ifdef MLP_STAMPS
+                if (!decltype(with_log)::value) {
+                    const unsigned long long t_ = __builtin_readcyclecounter();
+                    sl_acc[KC_H - 1] += t_ - sl_t;
+                    sl_acc[16] += 1;
+                }
+#endif
                 par ^= 1;
                 xb ^= 1;
                 ++g;
@@ -534,26 +617,11 @@ __global__ __launch_bounds__(kThreads, 1) void mlp_fused_kernel(const MlpLaunch 
 #pragma unroll
             for (int kt = 0; kt < HT; ++kt) {
                 const int gnext = (g + 1 < G) ? g + 1 : 0;
-                const f32x4 *lw = wbuf + par * CH_MAX + lane;
-                f32x4 a_cur[HG], a_nxt[HG];
 #pragma unroll
-                for (int j = 0; j < HG; ++j) a_cur[j] = lw[j * 64];
-#pragma unroll
-                for (int s = 0; s < KC_H; ++s) {
-                    if (s + 1 < KC_H) {
-#pragma unroll
-                        for (int j = 0; j < HG; ++j) a_nxt[j] = lw[((s + 1) * HG + j) * 64];
-                    }
-                    const float b = h[kt][s];
-#pragma unroll
-                    for (int t = 0; t < HT; ++t)
-                        h2[t] = __builtin_amdgcn_mfma_f32_32x32x2f32(a_cur[t / 4][t % 4], b, h2[t], 0, 0, 0);
-                    stage_step(s, KC_H, gnext, par ^ 1);
-#pragma unroll
-                    for (int j = 0; j < HG; ++j) a_cur[j] = a_nxt[j];
-                    MLP_SLOT_SCHED(HT, 2);
-                }
-                MLP_CHUNK_BARRIER();
+                for (int s = 0; s < KC_H; ++s)
+                    run_slot(h2, std::integral_constant<int, HT>{}, std::integral_constant<int, HG>{},
+                             std::integral_constant<int, 2>{}, s, KC_H, h[kt][s],
+                             [&](int s_) { stage_step(s_, KC_H, gnext, par ^ 1); });
                 par ^= 1;
                 ++g;
             }
@@ -580,26 +648,11 @@ __global__ __launch_bounds__(kThreads, 1) void mlp_fused_kernel(const MlpLaunch 
 #pragma unroll
                 for (int hf = 0; hf < OHALVES; ++hf) {
                     const int gnext = (g + 1 == G) ? 0 : g + 1;
-                    const f32x4 *lw = wbuf + par * CH_MAX + lane;
-                    f32x4 a_cur[OG], a_nxt[OG];
 #pragma unroll
-                    for (int j = 0; j < OG; ++j) a_cur[j] = lw[j * 64];
-#pragma unroll
-                    for (int s = 0; s < KC_O; ++s) {
-                        if (s + 1 < KC_O) {
-#pragma unroll
-                            for (int j = 0; j < OG; ++j) a_nxt[j] = lw[((s + 1) * OG + j) * 64];
-                        }
-                        const float b = h[kt][hf * KC_O + s];
-#pragma unroll
-                        for (int t = 0; t < OC; ++t)
-                            y[t] = __builtin_amdgcn_mfma_f32_32x32x2f32(a_cur[t / 4][t % 4], b, y[t], 0, 0, 0);
-                        stage_step(s, KC_O, gnext, par ^ 1);
-#pragma unroll
-                        for (int j = 0; j < OG; ++j) a_cur[j] = a_nxt[j];
-                        MLP_SLOT_SCHED(OC, 2);
-                    }
-                    MLP_CHUNK_BARRIER();
+                    for (int s = 0; s < KC_O; ++s)
+                        run_slot(y, std::integral_constant<int, OC>{}, std::integral_constant<int, OG>{},
+                                 std::integral_constant<int, 2>{}, s, KC_O, h[kt][hf * KC_O + s],
+                                 [&](int s_) { stage_step(s_, KC_O, gnext, par ^ 1); });
                     par ^= 1;
                     ++g;
                 }
@@ -710,8 +763,9 @@ __global__ __launch_bounds__(kThreads, 1) void mlp_fused_kernel(const MlpLaunch 
     }
 #ifdef MLP_STAMPS
     if (p.stamps && lane == 0) {
-        unsigned long long *o = p.stamps + ((size_t)blockIdx.x * 4 + wave) * 8;
+        unsigned long long *o = p.stamps + ((size_t)blockIdx.x * 4 + wave) * 32;
         for (int i = 0; i < 6; ++i) o[i] = st_acc[i];
+        for (int i = 0; i < 17; ++i) o[8 + i] = sl_acc[i];
     }
 #endif
 }
