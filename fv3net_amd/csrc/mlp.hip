@@ -48,11 +48,18 @@ namespace {
 // for the NEXT chunk.
 #define MLP_CHUNK_BARRIER() asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory")
 
+// Measured on gfx950 (scratch/ubench): beside fp32 32x32x2 MFMAs a VALU instruction is never free --
+// a run of n VALU instructions between two MFMAs costs about 8 + 4n cycles of matrix-pipe time --
+// while LDS reads/writes, SALU and s_nop are free and a global load costs ~6.  So a slot's VALU
+// work goes into ONE run behind its first MFMA, and the memory instructions are spread over the
+// other gaps.
 #define MLP_SLOT_SCHED(NT, Q)                                                          \
-    _Pragma("unroll") for (int _i = 0; _i < (NT); ++_i)                                \
+    __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);                                 \
+    __builtin_amdgcn_sched_group_barrier(0x002 | 0x400, 64, 0);                        \
+    _Pragma("unroll") for (int _i = 1; _i < (NT); ++_i)                                \
     {                                                                                  \
         __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);                             \
-        __builtin_amdgcn_sched_group_barrier(0x002 | 0x004 | 0x010 | 0x080 | 0x400, (Q), 0); \
+        __builtin_amdgcn_sched_group_barrier(0x004 | 0x010 | 0x080, (Q), 0);           \
     }                                                                                  \
     __builtin_amdgcn_sched_barrier(0)
 
@@ -110,6 +117,7 @@ struct OEntry {  // one network output feature as the host describes it (32 byte
 };
 
 struct MlpLaunch {
+    unsigned int w_bytes;  // size of the packed weight stream
     const f32x4 *w;     // packed weight stream
     const KEntry *ktab; // [2 * 16 * n_chunks1]
     const OEntry *otab; // [32 * OC * n_pass]
@@ -253,17 +261,23 @@ __global__ __launch_bounds__(kThreads, 1) void mlp_fused_kernel(const MlpLaunch 
     // at mid-chunk and committed in the last quarter): half the staging registers.
     constexpr int NVH = (NV_MAX + 1) / 2;
     f32x4 stage[NVH];
-    auto chunk_src = [&](int g) -> const f32x4 * {
-        return (g < n_hid_chunks) ? p.w + (int64_t)g * CH_H + tid
-                                  : p.w + (int64_t)n_hid_chunks * CH_H + (int64_t)(g - n_hid_chunks) * CH_O + tid;
+    // Buffer loads: the stream's base sits in an SGPR resource descriptor, the chunk offset in an
+    // SGPR and the per-thread offset in one loop-invariant VGPR -- no per-load VALU address math.
+    typedef int i32x4 __attribute__((ext_vector_type(4)));
+    const __amdgpu_buffer_rsrc_t w_rsrc =
+        __builtin_amdgcn_make_buffer_rsrc(const_cast<f32x4 *>(p.w), 0, p.w_bytes, 0x00020000);
+    const unsigned int w_voff = (unsigned int)tid * 16u;
+    auto chunk_off = [&](int g) -> int {  // float4 index of chunk g in the stream
+        return (g < n_hid_chunks) ? g * CH_H : n_hid_chunks * CH_H + (g - n_hid_chunks) * CH_O;
     };
     // (for a chunk type with fewer than 2*NVH float4s per thread the second half reads on into the
     // stream -- the host pads it by one maximal chunk -- and lands in LDS words nobody reads)
     auto issue_w = [&](int g, int part) {  // global -> registers
 #ifndef MLP_ABLATE_WLOAD
-        const f32x4 *gp = chunk_src(g) + part * NVH * kThreads;
+        const int base = (chunk_off(g) + part * NVH * kThreads) * 16;
 #pragma unroll
-        for (int i = 0; i < NVH; ++i) stage[i] = gp[i * kThreads];
+        for (int i = 0; i < NVH; ++i)
+            stage[i] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(w_rsrc, w_voff, base + i * kThreads * 16, 0));
 #endif
     };
     auto commit_w1 = [&](int buf, int part, int i) {  // one staged float4 -> the other LDS buffer
@@ -537,6 +551,14 @@ __global__ __launch_bounds__(kThreads, 1) void mlp_fused_kernel(const MlpLaunch 
                 const unsigned int nb = bulk_sample(n0);
                 XAddr xa4[4];
                 XNorm xn4[4];
+                // (opaque bases: the four entries are then read at immediate offsets from one address)
+                typedef const XAddr __attribute__((address_space(3))) *LXAddr;
+                typedef const XNorm __attribute__((address_space(3))) *LXNorm;
+                LXAddr xa_c = (LXAddr)(xa_tab + cn * 32 + fr);
+                LXNorm xn_c = (LXNorm)(xn_tab + cn * 32 + fr);
+                asm volatile("" : "+v"(xa_c), "+v"(xn_c));
+                const XAddr *xa_g = (const XAddr *)xa_c;
+                const XNorm *xn_g = (const XNorm *)xn_c;
 #ifdef MLP_STAMPS
                 unsigned long long sl_t = 0;
 #endif
@@ -556,7 +578,7 @@ __global__ __launch_bounds__(kThreads, 1) void mlp_fused_kernel(const MlpLaunch 
 #ifndef MLP_ABLATE_BISSUE
                         if (s_ == 0) {
 #pragma unroll
-                            for (int i = 0; i < 4; ++i) xa4[i] = xa_tab[cn * 32 + fr + 8 * i];
+                            for (int i = 0; i < 4; ++i) xa4[i] = xa_g[8 * i];
                         }
                         if (s_ == 1) {
 #pragma unroll
@@ -566,7 +588,7 @@ __global__ __launch_bounds__(kThreads, 1) void mlp_fused_kernel(const MlpLaunch 
 #ifndef MLP_ABLATE_BFINISH
                         if (s_ == KC_H / 2) {
 #pragma unroll
-                            for (int i = 0; i < 4; ++i) xn4[i] = xn_tab[cn * 32 + fr + 8 * i];
+                            for (int i = 0; i < 4; ++i) xn4[i] = xn_g[8 * i];
                         }
                         if (s_ > KC_H / 2 && s_ <= KC_H / 2 + 4) bulk_finish_e(xn4[s_ - KC_H / 2 - 1], s_ - KC_H / 2 - 1, xb ^ 1, with_log);
 #endif
@@ -795,6 +817,7 @@ struct fv3hip_mlp {
     int64_t flops = 0;
     int has_limits = 0;
     int n_log_chunks = 0;
+    unsigned int w_bytes = 0;
     void *d_w = nullptr, *d_ktab = nullptr, *d_otab = nullptr, *d_bias = nullptr;
     int n_cu = 256;
     size_t lds_bytes = 0;
@@ -1050,6 +1073,8 @@ extern "C" int fv3hip_mlp_create(const fv3hip_mlp_desc_t *d, fv3hip_mlp_t *out)
                 }
 
     int rc;
+    FV3HIP_REQUIRE(w.size() * sizeof(float) < (1ull << 31), "model too large: the packed weight stream exceeds 2 GiB");
+    m->w_bytes = (unsigned int)(w.size() * sizeof(float));
     if ((rc = upload(w, &m->d_w)) || (rc = upload(ktab, &m->d_ktab)) || (rc = upload(otab, &m->d_otab)) ||
         (rc = upload(bias, &m->d_bias))) {
         fv3hip_mlp_destroy(m);
@@ -1123,6 +1148,7 @@ extern "C" int fv3hip_mlp_predict(fv3hip_mlp_t m, const void *const *sources, co
         lp.out_ss[j] = out_sample_stride[j];
     }
     lp.w = static_cast<const f32x4 *>(m->d_w);
+    lp.w_bytes = m->w_bytes;
     lp.ktab = static_cast<const KEntry *>(m->d_ktab);
     lp.otab = static_cast<const OEntry *>(m->d_otab);
     lp.bias = static_cast<const float *>(m->d_bias);
