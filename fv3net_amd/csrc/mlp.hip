@@ -32,6 +32,7 @@
 #include <cstddef>
 #include <cstdlib>
 #include <type_traits>
+#include <cfloat>
 #include <vector>
 
 #include "common.h"
@@ -130,6 +131,7 @@ struct MlpLaunch {
     int n_bias;
     int out64;
     int n_log_chunks;   // layer-1 chunks [0, n_log_chunks) hold log-transformed inputs (the host orders them first)
+    int n_logfast_chunks;  // the leading ones of them that are all-log with every eps >= FLT_MIN
     int epi_fast;      // outputs are float32, sample-contiguous and 16-byte aligned: row-wise dwordx4 stores
     int has_limits;    // any output limit or zero mask
     int n_residual;
@@ -147,6 +149,9 @@ struct MlpLaunch {
 // row of a 32x32 accumulator held by register r of a lane in half h is rho(r) + 4*h
 __host__ __device__ constexpr int rho(int r) { return (r & 3) + 8 * (r >> 2); }
 
+#ifndef MLP_STAMP_LOGFLAVOUR
+#define MLP_STAMP_LOGFLAVOUR 0
+#endif
 // XBULK: the sources are sample-contiguous and 16-byte aligned, so the inputs of a layer-1 chunk
 // (32 features x 128 samples) are brought in by the whole workgroup with 16-byte loads, normalised
 // four at a time and parked in LDS; a k-pair slot then needs one ds_read for its B operand
@@ -429,12 +434,23 @@ __global__ __launch_bounds__(kThreads, 1) void mlp_fused_kernel(const MlpLaunch 
         } else {
             v = braw[SRC64 ? 0 : i];
         }
-        if (decltype(with_log)::value) {
+        // with_log: 0 = no transform in this chunk; 1 = log where flagged, libm-accurate; 2 = every
+        // feature of the chunk is log-transformed with eps >= FLT_MIN, so the argument is a normal
+        // number and v_log_f32 (1 ulp in log2) times ln 2 needs no denormal rescaling; the extra
+        // rounding of the product keeps it within 2 ulp -- the reference's own float32 log
+        // (numpy/TF SIMD kernels) is not correctly rounded either.  Non-finite values pass as in libm.
+        constexpr int LOGM = (int)decltype(with_log)::value;
+        if (LOGM == 1) {
 #pragma unroll
             for (int q = 0; q < 4; ++q) {
                 const float lg = logf(v[q] < e.eps ? e.eps : v[q]);
                 v[q] = (e.flags & 1) ? lg : v[q];
             }
+        }
+        if (LOGM == 2) {
+#pragma unroll
+            for (int q = 0; q < 4; ++q)
+                v[q] = __builtin_amdgcn_logf(v[q] < e.eps ? e.eps : v[q]) * 0.693147180559945f;
         }
 #ifndef MLP_ABLATE_FMATH
         v = (v - e.center) * e.rscale;
@@ -465,7 +481,7 @@ __global__ __launch_bounds__(kThreads, 1) void mlp_fused_kernel(const MlpLaunch 
         }
         if (XBULK) {
 #pragma unroll
-            for (int i = 0; i < 4; ++i) bulk_finish1(0, i, 0, std::true_type{});
+            for (int i = 0; i < 4; ++i) bulk_finish1(0, i, 0, std::integral_constant<int, 1>{});
         } else {
             finish_x(0);
         }
@@ -565,7 +581,7 @@ __global__ __launch_bounds__(kThreads, 1) void mlp_fused_kernel(const MlpLaunch 
 #pragma unroll
                 for (int s = 0; s < KC_H; ++s) {
 #ifdef MLP_STAMPS
-                    if (!decltype(with_log)::value) {
+                    if ((int)decltype(with_log)::value == MLP_STAMP_LOGFLAVOUR) {
                         const unsigned long long t_ = __builtin_readcyclecounter();
                         if (s > 0) sl_acc[s - 1] += t_ - sl_t;
                         sl_t = t_;
@@ -596,7 +612,7 @@ __global__ __launch_bounds__(kThreads, 1) void mlp_fused_kernel(const MlpLaunch 
                     });
                 }
 #ifdef MLP_STAMPS
-                if (!decltype(with_log)::value) {
+                if ((int)decltype(with_log)::value == MLP_STAMP_LOGFLAVOUR) {
                     const unsigned long long t_ = __builtin_readcyclecounter();
                     sl_acc[KC_H - 1] += t_ - sl_t;
                     sl_acc[16] += 1;
@@ -608,12 +624,19 @@ __global__ __launch_bounds__(kThreads, 1) void mlp_fused_kernel(const MlpLaunch 
             };
             if (XBULK) {
                 const int64_t n0 = tile * kTileSamples;
-                int c = 0;
-                for (; c < L - 1; ++c) l1_chunk_bulk(c + 1, n0, T_{});
-                for (; c < NC - 1; ++c) l1_chunk_bulk(c + 1, n0, F_{});
+                using M0_ = std::integral_constant<int, 0>;
+                using M1_ = std::integral_constant<int, 1>;
+                using M2_ = std::integral_constant<int, 2>;
+                const int NF = p.n_logfast_chunks;  // chunks [0, NF) take the fast log (NF <= L)
+                int c = 0;  // chunk c prepares the inputs of chunk c + 1
+                for (; c + 1 < NF; ++c) l1_chunk_bulk(c + 1, n0, M2_{});
+                for (; c + 1 < L; ++c) l1_chunk_bulk(c + 1, n0, M1_{});
+                for (; c < NC - 1; ++c) l1_chunk_bulk(c + 1, n0, M0_{});
                 // the last chunk brings in chunk 0 of the workgroup's next tile
                 const int64_t n1 = (next_tile < p.n_tiles ? next_tile : tile) * kTileSamples;
-                if (L > 0) l1_chunk_bulk(0, n1, T_{}); else l1_chunk_bulk(0, n1, F_{});
+                if (NF > 0) l1_chunk_bulk(0, n1, M2_{});
+                else if (L > 0) l1_chunk_bulk(0, n1, M1_{});
+                else l1_chunk_bulk(0, n1, M0_{});
             } else {
                 // a chunk that mixes both kinds (the boundary chunk, or the re-derivation on the last
                 // chunk) takes the with-log flavour, which selects per feature
@@ -816,7 +839,7 @@ struct fv3hip_mlp {
     int n_chunks1 = 0, n_pass = 0, n_ktab = 0, n_otab = 0, n_bias = 0;
     int64_t flops = 0;
     int has_limits = 0;
-    int n_log_chunks = 0;
+    int n_log_chunks = 0, n_logfast_chunks = 0;
     unsigned int w_bytes = 0;
     void *d_w = nullptr, *d_ktab = nullptr, *d_otab = nullptr, *d_bias = nullptr;
     int n_cu = 256;
@@ -977,6 +1000,9 @@ extern "C" int fv3hip_mlp_create(const fv3hip_mlp_desc_t *d, fv3hip_mlp_t *out)
             if (orig[k2].transform != FV3HIP_TRANSFORM_LOG) perm.push_back(k2);
         for (int k2 = 0; k2 < K; ++k2) ktab[k2] = orig[perm[k2]];
         m->n_log_chunks = (n_log + 31) / 32;
+        bool eps_normal = true;
+        for (int k2 = 0; k2 < n_log; ++k2) eps_normal = eps_normal && ktab[k2].eps >= FLT_MIN;
+        m->n_logfast_chunks = eps_normal ? n_log / 32 : 0;
     }
     // ---- packed weight stream ----
     // (+ one maximal chunk of zero padding: the two-half staging may read past a short last chunk)
@@ -1174,6 +1200,7 @@ extern "C" int fv3hip_mlp_predict(fv3hip_mlp_t m, const void *const *sources, co
         lp.epi_fast = fast ? 1 : 0;
     }
     lp.n_log_chunks = m->n_log_chunks;
+    lp.n_logfast_chunks = m->n_logfast_chunks;
     lp.n_residual = m->n_residual;
     lp.n_samples = n_samples;
     lp.n_tiles = ceil_div(n_samples, kTileSamples);
