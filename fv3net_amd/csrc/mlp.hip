@@ -31,6 +31,7 @@
 #include <cmath>
 #include <cstddef>
 #include <cstdlib>
+#include <cstring>
 #include <type_traits>
 #include <cfloat>
 #include <vector>
@@ -132,7 +133,7 @@ struct MlpLaunch {
     int out64;
     int n_log_chunks;   // layer-1 chunks [0, n_log_chunks) hold log-transformed inputs (the host orders them first)
     int n_logfast_chunks;  // the leading ones of them that are all-log with every eps >= FLT_MIN
-    int epi_fast;      // outputs are float32, sample-contiguous and 16-byte aligned: row-wise dwordx4 stores
+    int epi_fast;      // sources and outputs are sample-contiguous and 16-byte aligned, n_samples % 32 == 0: fast-I/O kernel
     int has_limits;    // any output limit or zero mask
     int n_residual;
     int64_t n_samples;
@@ -149,14 +150,33 @@ struct MlpLaunch {
 // row of a 32x32 accumulator held by register r of a lane in half h is rho(r) + 4*h
 __host__ __device__ constexpr int rho(int r) { return (r & 3) + 8 * (r >> 2); }
 
-#ifndef MLP_STAMP_LOGFLAVOUR
-#define MLP_STAMP_LOGFLAVOUR 0
+#ifndef MLP_STAMP_PHASE
+#define MLP_STAMP_PHASE 0  // per-slot stamps: 0/1/2 layer-1 XBULK chunks by log mode, 10 hidden, 20+NT output
 #endif
-// XBULK: the sources are sample-contiguous and 16-byte aligned, so the inputs of a layer-1 chunk
+#ifdef MLP_STAMPS
+#define SLOT_STAMP(phase, s)                                          \
+    if ((phase) == MLP_STAMP_PHASE) {                                 \
+        const unsigned long long t_ = __builtin_readcyclecounter();   \
+        if ((s) > 0) sl_acc[(s) - 1] += t_ - sl_t;                    \
+        sl_t = t_;                                                    \
+    }
+#define CHUNK_STAMP_END(phase, KC)                                    \
+    if ((phase) == MLP_STAMP_PHASE) {                                 \
+        const unsigned long long t_ = __builtin_readcyclecounter();   \
+        sl_acc[(KC) - 1] += t_ - sl_t;                                \
+        sl_acc[16] += 1;                                              \
+    }
+#else
+#define SLOT_STAMP(phase, s) ((void)0)
+#define CHUNK_STAMP_END(phase, KC) ((void)0)
+#endif
+// XBULK ("fast I/O" kernels): sources AND outputs are sample-contiguous and 16-byte aligned and
+// n_samples is a multiple of 32.  Outputs then leave through the row-wise LDS-transposed epilogue
+// (the general per-value epilogue is not compiled into these kernels), and the inputs of a layer-1 chunk
 // (32 features x 128 samples) are brought in by the whole workgroup with 16-byte loads, normalised
 // four at a time and parked in LDS; a k-pair slot then needs one ds_read for its B operand
 // instead of a table lookup, an address computation, a 4-byte load and the normalisation.
-template <int HT, int OC, bool SRC64, bool XBULK>
+template <int HT, int OC, int OL, bool SRC64, bool XBULK>
 __global__ __launch_bounds__(kThreads, 1) void mlp_fused_kernel(const MlpLaunch p)
 {
     constexpr int HG = (HT + 3) / 4;          // float4 groups of hidden-feature tiles
@@ -381,7 +401,7 @@ __global__ __launch_bounds__(kThreads, 1) void mlp_fused_kernel(const MlpLaunch 
     };
 #ifdef MLP_STAMPS
     unsigned long long st_acc[6] = {0, 0, 0, 0, 0, 0}, st_t0 = 0;
-    unsigned long long sl_acc[17] = {0,0,0,0,0,0,0,0,0,0,0,0,0,0,0,0,0};
+    unsigned long long sl_acc[17] = {0,0,0,0,0,0,0,0,0,0,0,0,0,0,0,0,0}, sl_t = 0;
 #define STAMP_BEGIN() st_t0 = __builtin_readcyclecounter()
 #define STAMP_END(i)                                         \
     {                                                        \
@@ -575,18 +595,9 @@ __global__ __launch_bounds__(kThreads, 1) void mlp_fused_kernel(const MlpLaunch 
                 asm volatile("" : "+v"(xa_c), "+v"(xn_c));
                 const XAddr *xa_g = (const XAddr *)xa_c;
                 const XNorm *xn_g = (const XNorm *)xn_c;
-#ifdef MLP_STAMPS
-                unsigned long long sl_t = 0;
-#endif
 #pragma unroll
                 for (int s = 0; s < KC_H; ++s) {
-#ifdef MLP_STAMPS
-                    if ((int)decltype(with_log)::value == MLP_STAMP_LOGFLAVOUR) {
-                        const unsigned long long t_ = __builtin_readcyclecounter();
-                        if (s > 0) sl_acc[s - 1] += t_ - sl_t;
-                        sl_t = t_;
-                    }
-#endif
+                    SLOT_STAMP((int)decltype(with_log)::value, s);
                     run_slot(h, HT_c{}, HG_c{}, Q5_c{}, s, KC_H, b_cur, [&](int s_) {
                         // (the last slot runs this after the chunk barrier: xs[xb ^ 1] is complete)
                         b_cur = (s_ + 1 < KC_H) ? xsb[2 * (s_ + 1) * kTileSamples] : xsn[0];
@@ -611,13 +622,7 @@ __global__ __launch_bounds__(kThreads, 1) void mlp_fused_kernel(const MlpLaunch 
                         stage_step(s_, KC_H, gnext, par ^ 1);
                     });
                 }
-#ifdef MLP_STAMPS
-                if ((int)decltype(with_log)::value == MLP_STAMP_LOGFLAVOUR) {
-                    const unsigned long long t_ = __builtin_readcyclecounter();
-                    sl_acc[KC_H - 1] += t_ - sl_t;
-                    sl_acc[16] += 1;
-                }
-#endif
+                CHUNK_STAMP_END((int)decltype(with_log)::value, KC_H);
                 par ^= 1;
                 xb ^= 1;
                 ++g;
@@ -663,10 +668,13 @@ __global__ __launch_bounds__(kThreads, 1) void mlp_fused_kernel(const MlpLaunch 
             for (int kt = 0; kt < HT; ++kt) {
                 const int gnext = (g + 1 < G) ? g + 1 : 0;
 #pragma unroll
-                for (int s = 0; s < KC_H; ++s)
+                for (int s = 0; s < KC_H; ++s) {
+                    SLOT_STAMP(10, s);
                     run_slot(h2, std::integral_constant<int, HT>{}, std::integral_constant<int, HG>{},
                              std::integral_constant<int, 2>{}, s, KC_H, h[kt][s],
                              [&](int s_) { stage_step(s_, KC_H, gnext, par ^ 1); });
+                }
+                CHUNK_STAMP_END(10, KC_H);
                 par ^= 1;
                 ++g;
             }
@@ -677,31 +685,43 @@ __global__ __launch_bounds__(kThreads, 1) void mlp_fused_kernel(const MlpLaunch 
         }
         STAMP_END(1);
         // ================= hidden -> outputs, OC feature tiles per pass =================
-        for (int pass = 0; pass < p.n_pass; ++pass) {
-            f32x16 y[OC];
+        // (the last pass may hold fewer feature tiles: OL of them -- its weight chunks keep the OC
+        // layout, the missing tiles' MFMAs and stores are simply not there)
+        auto run_pass = [&](int pass) __attribute__((always_inline)) {
+            constexpr int NTP = OC;
+            f32x16 y[NTP];
             const float *bl = biasl + p.n_hidden * HT * 32 + pass * OC * 32;
 #pragma unroll
-            for (int t = 0; t < OC; ++t)
+            for (int t = 0; t < NTP; ++t)
 #pragma unroll
                 for (int r = 0; r < 16; ++r) y[t][r] = bl[(t * 16 + r) * 2 + half];
             // the next tile's first inputs are requested before the epilogue of the last pass and
             // finished after it (requesting them earlier would keep 16 more registers live through
             // the pass's MFMA loop, where the accumulators already fill the register file)
             const bool prefetch_next = (pass + 1 == p.n_pass) && next_tile < p.n_tiles;
+            // Only the MFMA loops exist twice (OC tiles, and OL tiles for a shorter last pass); the
+            // epilogue is shared -- the tiles a short pass leaves out have no output rows.
+            auto mfma_loops = [&](auto nt_c) __attribute__((always_inline)) {
 #pragma unroll
-            for (int kt = 0; kt < HT; ++kt) {
+                for (int kt = 0; kt < HT; ++kt) {
 #pragma unroll
-                for (int hf = 0; hf < OHALVES; ++hf) {
-                    const int gnext = (g + 1 == G) ? 0 : g + 1;
+                    for (int hf = 0; hf < OHALVES; ++hf) {
+                        const int gnext = (g + 1 == G) ? 0 : g + 1;
 #pragma unroll
-                    for (int s = 0; s < KC_O; ++s)
-                        run_slot(y, std::integral_constant<int, OC>{}, std::integral_constant<int, OG>{},
-                                 std::integral_constant<int, 2>{}, s, KC_O, h[kt][hf * KC_O + s],
-                                 [&](int s_) { stage_step(s_, KC_O, gnext, par ^ 1); });
-                    par ^= 1;
-                    ++g;
+                        for (int s = 0; s < KC_O; ++s) {
+                            SLOT_STAMP(20 + (int)decltype(nt_c)::value, s);
+                            run_slot(y, nt_c, std::integral_constant<int, OG>{},
+                                     std::integral_constant<int, 2>{}, s, KC_O, h[kt][hf * KC_O + s],
+                                     [&](int s_) { stage_step(s_, KC_O, gnext, par ^ 1); });
+                        }
+                        CHUNK_STAMP_END(20 + (int)decltype(nt_c)::value, KC_O);
+                        par ^= 1;
+                        ++g;
+                    }
                 }
-            }
+            };
+            if (OL != OC && pass + 1 == p.n_pass) mfma_loops(std::integral_constant<int, OL>{});
+            else mfma_loops(std::integral_constant<int, OC>{});
             STAMP_END(2);
             if (!XBULK && prefetch_next) issue_x(0, nn);
             // ---- epilogue: denormalise, limit, mask, store (+ residual outputs) ----
@@ -709,17 +729,49 @@ __global__ __launch_bounds__(kThreads, 1) void mlp_fused_kernel(const MlpLaunch 
             // 32-feature x 32-sample accumulator tile goes through the wave's 4 KB slice of the idle
             // weight buffer, is read back row-wise and leaves as 4 dwordx4 stores of 8 full 128-byte
             // rows each (instead of 16 dword stores), with one table read per row.
-            const bool tile_full = (tile * kTileSamples + wave * 32 + 32) <= p.n_samples;
-            if (p.epi_fast && tile_full) {
+            // (FAST kernels: n_samples is a multiple of 32, so a wave's 32 samples are all there or
+            // all beyond the end)
+            if (XBULK) {
                 typedef f32x4 __attribute__((address_space(1))) *GF32x4;
                 typedef const f32x4 __attribute__((address_space(1))) *GCF32x4;
-                float *scr = reinterpret_cast<float *>(wbuf + (par ^ 1) * CH_MAX + wave * 256);
+                typedef d64x2 __attribute__((address_space(1))) *GF64x2;
+                typedef const d64x2 __attribute__((address_space(1))) *GCF64x2;
+                // (two 4 KB slices per wave, used alternately: tile t+1 is written while tile t is read
+                // back and stored, so the LDS round trip of one tile hides behind the next)
+                constexpr int SCRB = (CH_MAX >= 4 * 2 * 256) ? 2 : 1;  // (the small variants' buffer holds one slice per wave)
+                float *scr0 = reinterpret_cast<float *>(wbuf + (par ^ 1) * CH_MAX + wave * 256 * SCRB);
                 const int64_t n0 = tile * kTileSamples + wave * 32;
                 const int wrow = lane >> 3, wcol = (lane & 7) * 4;
+                auto put4 = [&](int64_t row_addr, const f32x4 v) {
+                    if (p.out64) {
+                        const d64x2 lo = {(double)v[0], (double)v[1]}, hi = {(double)v[2], (double)v[3]};
+                        *(GF64x2)(row_addr + (n0 + wcol) * 8) = lo;
+                        *(GF64x2)(row_addr + (n0 + wcol) * 8 + 16) = hi;
+                    } else {
+                        *(GF32x4)(row_addr + (n0 + wcol) * 4) = v;
+                    }
+                };
+#ifdef MLP_ABLATE_EPI
 #pragma unroll
-                for (int t = 0; t < OC; ++t) {
+                for (int t = 0; t < NTP; ++t) asm volatile("" ::"v"(y[t][0]));
+                if (n0 < 0) {
+#else
+                if (n0 < p.n_samples) {
+#endif
+                auto put_tile = [&](int t) {
+                    float *scr = scr0 + (t % SCRB) * 1024;
 #pragma unroll
                     for (int r = 0; r < 16; ++r) scr[(rho(r) + 4 * half) * 32 + (lane & 31)] = y[t][r];
+                };
+                if (SCRB == 2) put_tile(0);
+#pragma unroll
+                for (int t = 0; t < NTP; ++t) {
+                    if (SCRB == 2) {
+                        if (t + 1 < NTP) put_tile(t + 1);
+                    } else {
+                        put_tile(t);
+                    }
+                    const float *scr = scr0 + (t % SCRB) * 1024;
 #pragma unroll
                     for (int j = 0; j < 4; ++j) {
                         const int row = wrow + 8 * j;
@@ -737,15 +789,24 @@ __global__ __launch_bounds__(kThreads, 1) void mlp_fused_kernel(const MlpLaunch 
                                 v[q] = x * os.mask;
                             }
                         }
-                        if (of.row != 0) *(GF32x4)(of.row + (n0 + wcol) * 4) = v;
+                        if (of.row != 0) put4(of.row, v);
                         if (p.n_residual) {
                             const ORes e = ores[idx];
                             if (e.src_row != 0) {
-                                const f32x4 before = *(GCF32x4)(e.src_row + (n0 + wcol) * 4);
-                                *(GF32x4)(e.out_row + (n0 + wcol) * 4) = before + v;
+                                f32x4 before;
+                                if (SRC64) {
+                                    const d64x2 lo = *(GCF64x2)(e.src_row + (n0 + wcol) * 8);
+                                    const d64x2 hi = *(GCF64x2)(e.src_row + (n0 + wcol) * 8 + 16);
+                                    before[0] = (float)lo[0]; before[1] = (float)lo[1];
+                                    before[2] = (float)hi[0]; before[3] = (float)hi[1];
+                                } else {
+                                    before = *(GCF32x4)(e.src_row + (n0 + wcol) * 4);
+                                }
+                                put4(e.out_row, before + v);
                             }
                         }
                     }
+                }
                 }
             } else
             {
@@ -753,7 +814,7 @@ __global__ __launch_bounds__(kThreads, 1) void mlp_fused_kernel(const MlpLaunch 
                 typedef double __attribute__((address_space(1))) *GF64;
                 const unsigned int n32 = (unsigned int)n;
 #pragma unroll
-                for (int t = 0; t < OC; ++t) {
+                for (int t = 0; t < NTP; ++t) {
 #pragma unroll
                     for (int gq = 0; gq < 2; ++gq) {
                         OFast of[8];
@@ -804,7 +865,8 @@ __global__ __launch_bounds__(kThreads, 1) void mlp_fused_kernel(const MlpLaunch 
             if (!XBULK && prefetch_next) finish_x(0);
             MLP_CHUNK_BARRIER();
             STAMP_END(3);
-        }
+        };
+        for (int pass = 0; pass < p.n_pass; ++pass) run_pass(pass);
     }
 #ifdef MLP_STAMPS
     if (p.stamps && lane == 0) {
@@ -834,7 +896,7 @@ using namespace fv3hip;
 // ---------------------------------------------------------------------------------------------
 struct fv3hip_mlp {
     int device = 0;
-    int HT = 0, OC = 0;
+    int HT = 0, OC = 0, OL = 0;
     int n_sources = 0, n_inputs = 0, K = 0, width = 0, n_hidden = 0, n_outputs = 0, F = 0, n_residual = 0;
     int n_chunks1 = 0, n_pass = 0, n_ktab = 0, n_otab = 0, n_bias = 0;
     int64_t flops = 0;
@@ -849,28 +911,20 @@ struct fv3hip_mlp {
 namespace {
 
 struct Variant {
-    int HT, OC;
+    int HT, OC, OL;  // hidden tiles, output tiles per pass, output tiles in the last pass
 };
 // (an {8, 13} variant -- all 13 output tiles of the Zhao-Carr emulator in one pass -- was measured
 // slower than {8, 7}: 208 + 128 accumulator registers leave too little for the pipeline's staging)
-const Variant kVariants[] = {{1, 4}, {2, 4}, {4, 4}, {8, 4}, {8, 7}};
+const Variant kVariants[] = {{1, 4, 4}, {2, 4, 4}, {4, 4, 4}, {8, 4, 4}, {8, 7, 7}, {8, 7, 6}};
 
-template <int HT, int OC, bool SRC64, bool XBULK>
+template <int HT, int OC, int OL, bool SRC64, bool XBULK>
 int launch_one(const MlpLaunch &lp, int grid, size_t lds, hipStream_t st)
 {
-    auto kern = mlp_fused_kernel<HT, OC, SRC64, XBULK>;
+    auto kern = mlp_fused_kernel<HT, OC, OL, SRC64, XBULK>;
     FV3HIP_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(kern),
                                          hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
     hipLaunchKernelGGL(kern, dim3(grid), dim3(kThreads), lds, st, lp);
     return check_launch("mlp_fused_kernel");
-}
-
-template <int HT, int OC>
-int launch_variant(const fv3hip_mlp *m, const MlpLaunch &lp, bool src64, bool xbulk, int grid, size_t lds, hipStream_t st)
-{
-    (void)m;
-    if (src64) return xbulk ? launch_one<HT, OC, true, true>(lp, grid, lds, st) : launch_one<HT, OC, true, false>(lp, grid, lds, st);
-    return xbulk ? launch_one<HT, OC, false, true>(lp, grid, lds, st) : launch_one<HT, OC, false, false>(lp, grid, lds, st);
 }
 
 template <typename T>
@@ -924,21 +978,27 @@ extern "C" int fv3hip_mlp_create(const fv3hip_mlp_desc_t *d, fv3hip_mlp_t *out)
     // tiling that wastes the fewest padded feature tiles
     const int width = d->width;
     const int nt_out = (F + 31) / 32;
-    int HT = 0, OC = 0, best_cost = 1 << 30;
+    int HT = 0, OC = 0, OL = 0, best_cost = 1 << 30;
+    const char *force = getenv("FV3HIP_MLP_OC");  // tuning experiments only: "7" or "7,6"
+    int want_oc = 0, want_ol = 0;
+    if (force) {
+        want_oc = atoi(force);
+        const char *comma = strchr(force, ',');
+        want_ol = comma ? atoi(comma + 1) : want_oc;
+    }
     for (const Variant &v : kVariants) {
         if (v.HT * 32 < width) continue;
         if (HT && v.HT != HT) continue;
+        if (force && (v.OC != want_oc || v.OL != want_ol)) continue;
+        const int np = (nt_out + v.OC - 1) / v.OC;
+        if (nt_out - (np - 1) * v.OC > v.OL) continue;  // the last pass must hold what is left
         if (!HT) HT = v.HT;
-        const int cost = ((nt_out + v.OC - 1) / v.OC) * v.OC;
+        const int cost = (np - 1) * v.OC + v.OL;  // feature tiles computed
         if (cost < best_cost || (cost == best_cost && v.OC > OC)) {
             best_cost = cost;
             OC = v.OC;
+            OL = v.OL;
         }
-    }
-    if (const char *force = getenv("FV3HIP_MLP_OC")) {  // tuning experiments only
-        const int want = atoi(force);
-        for (const Variant &v : kVariants)
-            if (v.HT == HT && v.OC == want) OC = want;
     }
     FV3HIP_REQUIRE(HT > 0 && OC > 0, "no kernel variant for width %d", width);
 
@@ -948,6 +1008,7 @@ extern "C" int fv3hip_mlp_create(const fv3hip_mlp_desc_t *d, fv3hip_mlp_t *out)
     if (hipGetDeviceProperties(&prop, m->device) == hipSuccess) m->n_cu = prop.multiProcessorCount;
     m->HT = HT;
     m->OC = OC;
+    m->OL = OL;
     m->n_sources = d->n_sources;
     m->n_inputs = d->n_inputs;
     m->K = K;
@@ -1187,16 +1248,14 @@ extern "C" int fv3hip_mlp_predict(fv3hip_mlp_t m, const void *const *sources, co
     lp.out64 = (out_dtype == FV3HIP_F64);
     lp.has_limits = m->has_limits;
     {
-        bool fast = (out_dtype == FV3HIP_F32) && (n_samples % 4 == 0);
+        const int oal = (out_dtype == FV3HIP_F64) ? 2 : 4, sal = src64 ? 2 : 4;  // elements per 16 bytes
+        bool fast = (n_samples % 32 == 0);
         for (int j = 0; j < m->n_outputs + m->n_residual && fast; ++j)
             fast = out_sample_stride[j] == 1 && (reinterpret_cast<uintptr_t>(outputs[j]) % 16 == 0) &&
-                   (out_feat_stride[j] % 4 == 0);
-        if (m->n_residual) {
-            fast = fast && !src64;
-            for (int i = 0; i < m->n_sources && fast; ++i)
-                fast = src_sample_stride[i] == 1 && (reinterpret_cast<uintptr_t>(sources[i]) % 16 == 0) &&
-                       (src_feat_stride[i] % 4 == 0);
-        }
+                   (out_feat_stride[j] % oal == 0);
+        for (int i = 0; i < m->n_sources && fast; ++i)
+            fast = src_sample_stride[i] == 1 && (reinterpret_cast<uintptr_t>(sources[i]) % 16 == 0) &&
+                   (src_feat_stride[i] % sal == 0);
         lp.epi_fast = fast ? 1 : 0;
     }
     lp.n_log_chunks = m->n_log_chunks;
@@ -1208,21 +1267,26 @@ extern "C" int fv3hip_mlp_predict(fv3hip_mlp_t m, const void *const *sources, co
     lp.stamps = g_mlp_stamps;
 #endif
     const int grid = (int)(lp.n_tiles < m->n_cu ? lp.n_tiles : m->n_cu);
-    // inputs of a chunk are staged cooperatively when every source is sample-contiguous and aligned
-    bool xbulk = (n_samples % 4 == 0) && (n_samples >= 4);
-    for (int i = 0; i < m->n_sources && xbulk; ++i)
-        xbulk = src_sample_stride[i] == 1 && (reinterpret_cast<uintptr_t>(sources[i]) % 16 == 0) &&
-                (src_feat_stride[i] % (src64 ? 2 : 4) == 0);
+    // fast-I/O kernels when every source and output is sample-contiguous and aligned (see the kernel)
+    const bool xbulk = lp.epi_fast != 0;
     hipStream_t st = as_stream(stream);
-#define VARIANT_(H, O) \
-    if (m->HT == H && m->OC == O) return launch_variant<H, O>(m, lp, src64, xbulk, grid, m->lds_bytes, st)
+    // (the general kernels exist with OL == OC only; the packed model is the same for any OL)
+#define VARIANT_(H, O, L)                                                                          \
+    if (m->HT == H && m->OC == O && m->OL == L) {                                                  \
+        if (xbulk)                                                                                 \
+            return src64 ? launch_one<H, O, L, true, true>(lp, grid, m->lds_bytes, st)             \
+                         : launch_one<H, O, L, false, true>(lp, grid, m->lds_bytes, st);           \
+        return src64 ? launch_one<H, O, O, true, false>(lp, grid, m->lds_bytes, st)                \
+                     : launch_one<H, O, O, false, false>(lp, grid, m->lds_bytes, st);              \
+    }
 #ifndef MLP_FAST_BUILD  // (experiments compile the flagship variant only)
-    VARIANT_(1, 4);
-    VARIANT_(2, 4);
-    VARIANT_(4, 4);
-    VARIANT_(8, 4);
+    VARIANT_(1, 4, 4)
+    VARIANT_(2, 4, 4)
+    VARIANT_(4, 4, 4)
+    VARIANT_(8, 4, 4)
 #endif
-    VARIANT_(8, 7);
+    VARIANT_(8, 7, 7)
+    VARIANT_(8, 7, 6)
 #undef VARIANT_
-    return fail(FV3HIP_EUNSUPPORTED, "no compiled kernel variant for HT=%d OC=%d", m->HT, m->OC);
+    return fail(FV3HIP_EUNSUPPORTED, "no compiled kernel variant for HT=%d OC=%d OL=%d", m->HT, m->OC, m->OL);
 }
