@@ -122,11 +122,12 @@ struct MlpLaunch {
     unsigned int w_bytes;  // size of the packed weight stream
     const f32x4 *w;     // packed weight stream
     const KEntry *ktab; // [2 * 16 * n_chunks1]
-    const OEntry *otab; // [32 * OC * n_pass]
+    const OEntry *otab; // [32 * n_otiles]
     const float *bias;  // packed biases
     int n_chunks1;      // layer-1 chunks of 16 k-pairs
     int n_hidden;
-    int n_pass;
+    int n_otiles;       // 32-feature output tiles (= output-type chunks per sample tile)
+    int64_t sink;       // fast-I/O launches: device row of n_samples values that padded output rows are stored to
     int n_ktab;
     int n_otab;
     int n_bias;
@@ -176,20 +177,27 @@ __host__ __device__ constexpr int rho(int r) { return (r & 3) + 8 * (r >> 2); }
 // (32 features x 128 samples) are brought in by the whole workgroup with 16-byte loads, normalised
 // four at a time and parked in LDS; a k-pair slot then needs one ds_read for its B operand
 // instead of a table lookup, an address computation, a 4-byte load and the normalisation.
-template <int HT, int OC, int OL, bool SRC64, bool XBULK>
+template <int HT, bool SRC64, bool XBULK>
 __global__ __launch_bounds__(kThreads, 1) void mlp_fused_kernel(const MlpLaunch p)
 {
     constexpr int HG = (HT + 3) / 4;          // float4 groups of hidden-feature tiles
-    constexpr int OG = (OC + 3) / 4;          // float4 groups of output-feature tiles
-    constexpr int KC_H = 16;                  // k-pairs per hidden-type chunk
-    constexpr int KC_O = (OG <= 2) ? 16 : 8;  // k-pairs per output-type chunk
+    constexpr int KC_H = 16;                  // slots (k-pairs) per hidden-type chunk
+    // The output layer runs TILE-MAJOR: one 32-feature output tile at a time over the whole
+    // contraction, a single 16-register accumulator (a dependent chain of fp32 32x32x2 MFMAs issues
+    // at the full rate -- measured).  An output-type chunk is the weights of one output tile; a slot
+    // is GS consecutive k-pairs of it.  The tile's epilogue then runs as side work of the NEXT tile's
+    // MFMAs, and the output layer needs 32 accumulator registers instead of 16 per feature tile.
+    constexpr int GS = (HT == 1) ? 4 : 8;     // k-pairs (MFMAs) per output slot
+    constexpr int NGO = GS / 4;               // float4 A fragments per output slot
+    constexpr int KC_O = HT * 16 / GS;        // slots per output-type chunk
     constexpr int CH_H = KC_H * HG * 64;      // float4 per hidden-type chunk
-    constexpr int CH_O = KC_O * OG * 64;      // float4 per output-type chunk
+    constexpr int CH_O = KC_O * NGO * 64;     // float4 per output-type chunk
     constexpr int NV_H = CH_H / kThreads;
     constexpr int NV_O = CH_O / kThreads;
     constexpr int NV_MAX = (NV_H > NV_O) ? NV_H : NV_O;
     constexpr int CH_MAX = (CH_H > CH_O) ? CH_H : CH_O;
-    constexpr int OHALVES = 16 / KC_O;        // output-type chunks per 32-feature k tile
+    // the epilogue of output tile t rides under the MFMAs of tile t+1 (needs enough slots per chunk)
+    constexpr bool EPI_SIDE = XBULK && KC_O >= 12;
 
     extern __shared__ __attribute__((aligned(16))) char smem[];
     f32x4 *wbuf = reinterpret_cast<f32x4 *>(smem);                       // [2][CH_MAX]
@@ -246,7 +254,7 @@ __global__ __launch_bounds__(kThreads, 1) void mlp_fused_kernel(const MlpLaunch 
             sl.hi = e.hi;
             sl.mask = e.mask;
             sl.ss = 0;
-            f.row = 0;
+            f.row = p.sink;  // (fast-I/O launches: rows without an output are stored to a scratch row; else 0)
             int slot = 0, feat = 0;
             if (e.out_feat >= 0) {
                 slot = e.out_feat >> 20;
@@ -279,7 +287,7 @@ __global__ __launch_bounds__(kThreads, 1) void mlp_fused_kernel(const MlpLaunch 
     int par = 0;  // LDS buffer holding the chunk about to be consumed
     // ---- weight-stream helpers ----
     const int n_hid_chunks = p.n_chunks1 + (p.n_hidden - 1) * HT;  // hidden-type chunks per tile
-    const int n_out_chunks = p.n_pass * HT * OHALVES;              // output-type chunks per tile
+    const int n_out_chunks = p.n_otiles;                           // output-type chunks per tile (one per 32 outputs)
     const int G = n_hid_chunks + n_out_chunks;
     // The next chunk is staged through registers in two halves (first half requested at the start
     // of a chunk and committed to the other LDS buffer in its second quarter, second half requested
@@ -333,7 +341,7 @@ __global__ __launch_bounds__(kThreads, 1) void mlp_fused_kernel(const MlpLaunch 
     // its last read of this one, so after the barrier the first fragments of the NEXT chunk are
     // read from the other buffer under the last slot's MFMAs -- no LDS latency is exposed at a
     // chunk boundary.  (__syncthreads() would also drain vmcnt; only LDS traffic matters here.)
-    constexpr int AG = (HG > OG) ? HG : OG;
+    constexpr int AG = (HG > NGO) ? HG : NGO;
     f32x4 a_cur[AG];
     auto run_slot = [&](auto &acc, auto nt_c, auto ng_c, auto q_c, int s, int KC, float b, auto &&side) __attribute__((always_inline)) {
         constexpr int NT = decltype(nt_c)::value, NG = decltype(ng_c)::value, Q = decltype(q_c)::value;
@@ -684,189 +692,257 @@ __global__ __launch_bounds__(kThreads, 1) void mlp_fused_kernel(const MlpLaunch 
                 for (int r = 0; r < 16; ++r) h[t][r] = (h2[t][r] < 0.f) ? 0.f : h2[t][r];
         }
         STAMP_END(1);
-        // ================= hidden -> outputs, OC feature tiles per pass =================
-        // (the last pass may hold fewer feature tiles: OL of them -- its weight chunks keep the OC
-        // layout, the missing tiles' MFMAs and stores are simply not there)
-        auto run_pass = [&](int pass) __attribute__((always_inline)) {
-            constexpr int NTP = OC;
-            f32x16 y[NTP];
-            const float *bl = biasl + p.n_hidden * HT * 32 + pass * OC * 32;
+        // ================= hidden -> outputs, one 32-feature tile per chunk =================
+        {
+            typedef f32x4 __attribute__((address_space(1))) *GF32x4;
+            typedef const f32x4 __attribute__((address_space(1))) *GCF32x4;
+            typedef d64x2 __attribute__((address_space(1))) *GF64x2;
+            typedef const d64x2 __attribute__((address_space(1))) *GCF64x2;
+            const int64_t n0t = tile * kTileSamples + wave * 32;
+            const int e_wrow = lane >> 3, e_wcol = (lane & 7) * 4;
+            // ---- fast-I/O epilogue pieces.  (n_samples is a multiple of 32: a wave's 32 samples are all
+            // there or all beyond the end.)  An accumulator tile goes through the wave's 4 KB slice of
+            // the xs half that is idle during the output layer, is read back row-wise and leaves as
+            // 4 x dwordx4 stores of 8 full 128-byte rows each, with one table read per row.
+            float *scr = xs + (xb ^ 1) * 32 * kTileSamples + wave * 1024;
+            auto epi_put_tile = [&](const f32x16 &y) {
 #pragma unroll
-            for (int t = 0; t < NTP; ++t)
+                for (int r = 0; r < 16; ++r) scr[(rho(r) + 4 * half) * 32 + (lane & 31)] = y[r];
+            };
+            auto epi_put4 = [&](int64_t row_addr, const f32x4 v) {
+                if (p.out64) {
+                    const d64x2 lo = {(double)v[0], (double)v[1]}, hi = {(double)v[2], (double)v[3]};
+                    *(GF64x2)(row_addr + (n0t + e_wcol) * 8) = lo;
+                    *(GF64x2)(row_addr + (n0t + e_wcol) * 8 + 16) = hi;
+                } else {
+                    *(GF32x4)(row_addr + (n0t + e_wcol) * 4) = v;
+                }
+            };
+            // (plain_c: float32 outputs, no limits / masks, no residual outputs -- decided once per
+            // tile loop, so that the side work inside the MFMA slots is branch-free: the MFMAs of a
+            // slot queue only one deep, every branch in its side work is matrix-pipe idle time)
+            auto epi_row = [&](const OFast of, f32x4 v, int idx, auto plain_c) {
+                v = v * of.scale + of.center;
+                if (decltype(plain_c)::value) {
+                    *(GF32x4)(of.row + (n0t + e_wcol) * 4) = v;  // (padded rows point at the sink row)
+                    return;
+                }
+                if (p.has_limits) {
+                    const OSlow os = oslow[idx];
 #pragma unroll
-                for (int r = 0; r < 16; ++r) y[t][r] = bl[(t * 16 + r) * 2 + half];
-            // the next tile's first inputs are requested before the epilogue of the last pass and
-            // finished after it (requesting them earlier would keep 16 more registers live through
-            // the pass's MFMA loop, where the accumulators already fill the register file)
-            const bool prefetch_next = (pass + 1 == p.n_pass) && next_tile < p.n_tiles;
-            // Only the MFMA loops exist twice (OC tiles, and OL tiles for a shorter last pass); the
-            // epilogue is shared -- the tiles a short pass leaves out have no output rows.
-            auto mfma_loops = [&](auto nt_c) __attribute__((always_inline)) {
-#pragma unroll
-                for (int kt = 0; kt < HT; ++kt) {
-#pragma unroll
-                    for (int hf = 0; hf < OHALVES; ++hf) {
-                        const int gnext = (g + 1 == G) ? 0 : g + 1;
-#pragma unroll
-                        for (int s = 0; s < KC_O; ++s) {
-                            SLOT_STAMP(20 + (int)decltype(nt_c)::value, s);
-                            run_slot(y, nt_c, std::integral_constant<int, OG>{},
-                                     std::integral_constant<int, 2>{}, s, KC_O, h[kt][hf * KC_O + s],
-                                     [&](int s_) { stage_step(s_, KC_O, gnext, par ^ 1); });
+                    for (int q = 0; q < 4; ++q) {
+                        float x = v[q];
+                        if (x < os.lo) x = os.lo;
+                        if (x >= os.hi) x = os.hi;
+                        v[q] = x * os.mask;
+                    }
+                }
+                if (of.row != 0) epi_put4(of.row, v);
+                if (p.n_residual) {
+                    const ORes e = ores[idx];
+                    if (e.src_row != 0) {
+                        f32x4 before;
+                        if (SRC64) {
+                            const d64x2 lo = *(GCF64x2)(e.src_row + (n0t + e_wcol) * 8);
+                            const d64x2 hi = *(GCF64x2)(e.src_row + (n0t + e_wcol) * 8 + 16);
+                            before[0] = (float)lo[0]; before[1] = (float)lo[1];
+                            before[2] = (float)hi[0]; before[3] = (float)hi[1];
+                        } else {
+                            before = *(GCF32x4)(e.src_row + (n0t + e_wcol) * 4);
                         }
-                        CHUNK_STAMP_END(20 + (int)decltype(nt_c)::value, KC_O);
-                        par ^= 1;
-                        ++g;
+                        epi_put4(e.out_row, before + v);
                     }
                 }
             };
-            if (OL != OC && pass + 1 == p.n_pass) mfma_loops(std::integral_constant<int, OL>{});
-            else mfma_loops(std::integral_constant<int, OC>{});
-            STAMP_END(2);
-            if (!XBULK && prefetch_next) issue_x(0, nn);
-            // ---- epilogue: denormalise, limit, mask, store (+ residual outputs) ----
-            // Fast path (float32 outputs, contiguous samples, a full 32-sample wave tile): each
-            // 32-feature x 32-sample accumulator tile goes through the wave's 4 KB slice of the idle
-            // weight buffer, is read back row-wise and leaves as 4 dwordx4 stores of 8 full 128-byte
-            // rows each (instead of 16 dword stores), with one table read per row.
-            // (FAST kernels: n_samples is a multiple of 32, so a wave's 32 samples are all there or
-            // all beyond the end)
-            if (XBULK) {
-                typedef f32x4 __attribute__((address_space(1))) *GF32x4;
-                typedef const f32x4 __attribute__((address_space(1))) *GCF32x4;
-                typedef d64x2 __attribute__((address_space(1))) *GF64x2;
-                typedef const d64x2 __attribute__((address_space(1))) *GCF64x2;
-                // (two 4 KB slices per wave, used alternately: tile t+1 is written while tile t is read
-                // back and stored, so the LDS round trip of one tile hides behind the next)
-                constexpr int SCRB = (CH_MAX >= 4 * 2 * 256) ? 2 : 1;  // (the small variants' buffer holds one slice per wave)
-                float *scr0 = reinterpret_cast<float *>(wbuf + (par ^ 1) * CH_MAX + wave * 256 * SCRB);
-                const int64_t n0 = tile * kTileSamples + wave * 32;
-                const int wrow = lane >> 3, wcol = (lane & 7) * 4;
-                auto put4 = [&](int64_t row_addr, const f32x4 v) {
-                    if (p.out64) {
-                        const d64x2 lo = {(double)v[0], (double)v[1]}, hi = {(double)v[2], (double)v[3]};
-                        *(GF64x2)(row_addr + (n0 + wcol) * 8) = lo;
-                        *(GF64x2)(row_addr + (n0 + wcol) * 8 + 16) = hi;
-                    } else {
-                        *(GF32x4)(row_addr + (n0 + wcol) * 4) = v;
-                    }
-                };
-#ifdef MLP_ABLATE_EPI
+            // the whole epilogue of output tile t at once (matrix pipe idle)
+            auto epi_fast_now = [&](const f32x16 &y, int t) {
+                if (n0t >= p.n_samples) return;
+                epi_put_tile(y);
 #pragma unroll
-                for (int t = 0; t < NTP; ++t) asm volatile("" ::"v"(y[t][0]));
-                if (n0 < 0) {
-#else
-                if (n0 < p.n_samples) {
-#endif
-                auto put_tile = [&](int t) {
-                    float *scr = scr0 + (t % SCRB) * 1024;
+                for (int j = 0; j < 4; ++j) {
+                    const int row = e_wrow + 8 * j, idx = t * 32 + row;
+                    epi_row(ofast[idx], *reinterpret_cast<const f32x4 *>(scr + row * 32 + e_wcol), idx, std::false_type{});
+                }
+            };
+            // ... or spread over the slots of the next tile's chunk (EPI_SIDE, KC_O >= 12):
+            //   slot 1: accumulator tile -> scratch;  slot 8: rows 0,1 (table entry + transposed row) read;
+            //   slot 9: they are finished and stored, rows 2,3 read;  slot 10: those finished and stored.
+            // Why slots 8..10: vmcnt retires loads AND stores in issue order, so a store must not be
+            // older than a staging load that is waited for soon -- the second half of the weight
+            // staging is requested in slot KC/2 - 1 and committed from slot 3KC/4 - 1 on; stores issued
+            // after the request are younger than it, and the next chunk's first commit is >= 10 slots
+            // (~2 us) away.  All of it ends before the chunk's last slot, whose barrier orders the
+            // scratch against whatever the other waves do next.
+            OFast e_of[2];
+            f32x4 e_v[2];
+            auto epi_side = [&](const f32x16 &y, int t, int s_, auto plain_c) __attribute__((always_inline)) {
+                if (!decltype(plain_c)::value && n0t >= p.n_samples) return;  // (plain: only for full tiles)
+                if (s_ == 1) epi_put_tile(y);
+                if (s_ == 9 || s_ == 10) {
 #pragma unroll
-                    for (int r = 0; r < 16; ++r) scr[(rho(r) + 4 * half) * 32 + (lane & 31)] = y[t][r];
-                };
-                if (SCRB == 2) put_tile(0);
+                    for (int i = 0; i < 2; ++i) epi_row(e_of[i], e_v[i], t * 32 + e_wrow + 8 * (2 * (s_ - 9) + i), plain_c);
+                }
+                if (s_ == 8 || s_ == 9) {
 #pragma unroll
-                for (int t = 0; t < NTP; ++t) {
-                    if (SCRB == 2) {
-                        if (t + 1 < NTP) put_tile(t + 1);
-                    } else {
-                        put_tile(t);
-                    }
-                    const float *scr = scr0 + (t % SCRB) * 1024;
-#pragma unroll
-                    for (int j = 0; j < 4; ++j) {
-                        const int row = wrow + 8 * j;
-                        const int idx = (pass * OC + t) * 32 + row;
-                        const OFast of = ofast[idx];
-                        f32x4 v = *reinterpret_cast<const f32x4 *>(scr + row * 32 + wcol);
-                        v = v * of.scale + of.center;
-                        if (p.has_limits) {
-                            const OSlow os = oslow[idx];
-#pragma unroll
-                            for (int q = 0; q < 4; ++q) {
-                                float x = v[q];
-                                if (x < os.lo) x = os.lo;
-                                if (x >= os.hi) x = os.hi;
-                                v[q] = x * os.mask;
-                            }
-                        }
-                        if (of.row != 0) put4(of.row, v);
-                        if (p.n_residual) {
-                            const ORes e = ores[idx];
-                            if (e.src_row != 0) {
-                                f32x4 before;
-                                if (SRC64) {
-                                    const d64x2 lo = *(GCF64x2)(e.src_row + (n0 + wcol) * 8);
-                                    const d64x2 hi = *(GCF64x2)(e.src_row + (n0 + wcol) * 8 + 16);
-                                    before[0] = (float)lo[0]; before[1] = (float)lo[1];
-                                    before[2] = (float)hi[0]; before[3] = (float)hi[1];
-                                } else {
-                                    before = *(GCF32x4)(e.src_row + (n0 + wcol) * 4);
-                                }
-                                put4(e.out_row, before + v);
-                            }
-                        }
+                    for (int i = 0; i < 2; ++i) {
+                        const int row = e_wrow + 8 * (2 * (s_ - 8) + i);
+                        e_of[i] = ofast[t * 32 + row];
+                        e_v[i] = *reinterpret_cast<const f32x4 *>(scr + row * 32 + e_wcol);
                     }
                 }
-                }
-            } else
-            {
+            };
+            // ---- general epilogue (any strides / dtypes): per-value stores straight from the accumulator
+            auto epi_general = [&](const f32x16 &y, int t) {
                 typedef float __attribute__((address_space(1))) *GF32;
                 typedef double __attribute__((address_space(1))) *GF64;
                 const unsigned int n32 = (unsigned int)n;
 #pragma unroll
-                for (int t = 0; t < NTP; ++t) {
+                for (int gq = 0; gq < 2; ++gq) {
+                    OFast of[8];
+                    OSlow os[8];
+                    float v[8];
 #pragma unroll
-                    for (int gq = 0; gq < 2; ++gq) {
-                        OFast of[8];
-                        OSlow os[8];
-                        float v[8];
+                    for (int i = 0; i < 8; ++i) {
+                        const int idx = t * 32 + rho(gq * 8 + i) + 4 * half;
+                        of[i] = ofast[idx];
+                        os[i] = oslow[idx];
+                    }
 #pragma unroll
-                        for (int i = 0; i < 8; ++i) {
-                            const int idx = (pass * OC + t) * 32 + rho(gq * 8 + i) + 4 * half;
-                            of[i] = ofast[idx];
-                            os[i] = oslow[idx];
+                    for (int i = 0; i < 8; ++i) {
+                        float x = y[gq * 8 + i] * of[i].scale + of[i].center;
+                        if (p.has_limits) {
+                            if (x < os[i].lo) x = os[i].lo;
+                            if (x >= os[i].hi) x = os[i].hi;
+                            x = x * os[i].mask;
                         }
+                        v[i] = x;
+                        if (valid && of[i].row != 0) {
+                            const int64_t addr = of[i].row + (int64_t)((uint64_t)n32 * (uint64_t)os[i].ss);
+                            if (p.out64)
+                                *(GF64)addr = (double)x;
+                            else
+                                *(GF32)addr = x;
+                        }
+                    }
+                    if (p.n_residual) {
 #pragma unroll
                         for (int i = 0; i < 8; ++i) {
-                            float x = y[t][gq * 8 + i] * of[i].scale + of[i].center;
-                            if (p.has_limits) {
-                                if (x < os[i].lo) x = os[i].lo;
-                                if (x >= os[i].hi) x = os[i].hi;
-                                x = x * os[i].mask;
-                            }
-                            v[i] = x;
-                            if (valid && of[i].row != 0) {
-                                const int64_t addr = of[i].row + (int64_t)((uint64_t)n32 * (uint64_t)os[i].ss);
+                            const int idx = t * 32 + rho(gq * 8 + i) + 4 * half;
+                            const ORes e = ores[idx];
+                            if (valid && e.src_row != 0) {
+                                const float before = (float)*(GRawPtr)(e.src_row + (int64_t)((uint64_t)n32 * (uint64_t)e.src_ss));
+                                const float after = before + v[i];
+                                const int64_t addr = e.out_row + (int64_t)((uint64_t)n32 * (uint64_t)e.out_ss);
                                 if (p.out64)
-                                    *(GF64)addr = (double)x;
+                                    *(GF64)addr = (double)after;
                                 else
-                                    *(GF32)addr = x;
-                            }
-                        }
-                        if (p.n_residual) {
-#pragma unroll
-                            for (int i = 0; i < 8; ++i) {
-                                const int idx = (pass * OC + t) * 32 + rho(gq * 8 + i) + 4 * half;
-                                const ORes e = ores[idx];
-                                if (valid && e.src_row != 0) {
-                                    const float before = (float)*(GRawPtr)(e.src_row + (int64_t)((uint64_t)n32 * (uint64_t)e.src_ss));
-                                    const float after = before + v[i];
-                                    const int64_t addr = e.out_row + (int64_t)((uint64_t)n32 * (uint64_t)e.out_ss);
-                                    if (p.out64)
-                                        *(GF64)addr = (double)after;
-                                    else
-                                        *(GF32)addr = after;
-                                }
+                                    *(GF32)addr = after;
                             }
                         }
                     }
                 }
+            };
+
+            // one slot of an output chunk: GS MFMAs of the single accumulator (A fragment i of the
+            // slot, B = hidden activation of k-pair s*GS+i), next slot's fragments read meanwhile,
+            // chunk barrier + next chunk's first fragments in the last slot (as run_slot)
+            auto run_slot_out = [&](f32x16 &acc, int s, auto &&side) __attribute__((always_inline)) {
+                f32x4 a_nxt[AG];
+                if (s + 1 < KC_O) {
+                    const f32x4 *lw = wbuf + par * CH_MAX + lane;
+#pragma unroll
+                    for (int j = 0; j < NGO; ++j) a_nxt[j] = lw[((s + 1) * NGO + j) * 64];
+#pragma unroll
+                    for (int j = NGO; j < AG; ++j) a_nxt[j] = a_cur[j];
+#pragma unroll
+                    for (int i = 0; i < GS; ++i)
+                        acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a_cur[i / 4][i % 4], h[(s * GS + i) / 16][(s * GS + i) % 16], acc, 0, 0, 0);
+                    side(s);
+#pragma unroll
+                    for (int j = 0; j < AG; ++j) a_cur[j] = a_nxt[j];
+                    MLP_SLOT_SCHED(GS, 2);
+                } else {
+                    acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a_cur[0][0], h[(s * GS) / 16][(s * GS) % 16], acc, 0, 0, 0);
+                    __builtin_amdgcn_sched_barrier(0);
+                    MLP_CHUNK_BARRIER();
+                    __builtin_amdgcn_sched_barrier(0);
+                    const f32x4 *lwn = wbuf + (par ^ 1) * CH_MAX + lane;
+#pragma unroll
+                    for (int j = 0; j < AG; ++j) a_nxt[j] = lwn[j * 64];
+#pragma unroll
+                    for (int i = 1; i < GS; ++i)
+                        acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a_cur[i / 4][i % 4], h[(s * GS + i) / 16][(s * GS + i) % 16], acc, 0, 0, 0);
+                    side(s);
+#pragma unroll
+                    for (int j = 0; j < AG; ++j) a_cur[j] = a_nxt[j];
+                    MLP_SLOT_SCHED(GS - 1, 2);
+                }
+            };
+
+            // accumulator init = bias of output tile t (clamped: the look-ahead may run one past the end)
+            typedef const float __attribute__((address_space(3))) *LBias;
+            auto load_bias = [&](f32x16 &y, int t) {
+                const int tc = t < p.n_otiles ? t : p.n_otiles - 1;
+                LBias bl = (LBias)(biasl + p.n_hidden * HT * 32 + tc * 32 + half);
+                asm volatile("" : "+v"(bl));  // (opaque base: the 16 reads use immediate offsets)
+                const float *blg = (const float *)bl;
+#pragma unroll
+                for (int r = 0; r < 16; ++r) y[r] = blg[r * 2];
+            };
+            // one output tile = one chunk.  EPI_SIDE: two accumulators used alternately -- while `y`
+            // accumulates tile t, `yo` still holds tile t-1: its epilogue runs in slots 1..10, then
+            // (slot 12) it is re-initialised with the bias of tile t+1.
+            auto out_chunk = [&](f32x16 &y, f32x16 &yo, int t, auto has_prev_c, auto plain_c) __attribute__((always_inline)) {
+                const int gnext = (g + 1 == G) ? 0 : g + 1;
+#pragma unroll
+                for (int s = 0; s < KC_O; ++s) {
+                    SLOT_STAMP(20, s);
+                    run_slot_out(y, s, [&](int s_) {
+                        stage_step(s_, KC_O, gnext, par ^ 1);
+                        if (EPI_SIDE) {
+                            if (decltype(has_prev_c)::value) epi_side(yo, t - 1, s_, plain_c);
+                            if (s_ == 12) load_bias(yo, t + 1);
+                        }
+                    });
+                }
+                CHUNK_STAMP_END(20, KC_O);
+                par ^= 1;
+                ++g;
+            };
+            f32x16 yA, yB;
+            const int NT = p.n_otiles;
+            auto tile_loop = [&](auto plain_c) __attribute__((always_inline)) {
+                if constexpr (EPI_SIDE) {
+                    load_bias(yA, 0);
+                    out_chunk(yA, yB, 0, std::false_type{}, plain_c);
+                    for (int t = 1; t < NT; t += 2) {
+                        out_chunk(yB, yA, t, std::true_type{}, plain_c);
+                        if (t + 1 < NT) out_chunk(yA, yB, t + 1, std::true_type{}, plain_c);
+                    }
+                } else {
+                    for (int t = 0; t < NT; ++t) {
+                        load_bias(yA, t);
+                        out_chunk(yA, yB, t, std::false_type{}, plain_c);
+                        // (general kernels: the next tile's first inputs are requested before the last
+                        // epilogue and finished after it)
+                        const bool prefetch_next = (t + 1 == NT) && next_tile < p.n_tiles;
+                        if (!XBULK && prefetch_next) issue_x(0, nn);
+                        if (XBULK) epi_fast_now(yA, t); else epi_general(yA, t);
+                        if (!XBULK && prefetch_next) finish_x(0);
+                    }
+                }
+            };
+            if (EPI_SIDE && !p.has_limits && !p.out64 && !p.n_residual && (tile + 1) * kTileSamples <= p.n_samples)
+                tile_loop(std::true_type{});
+            else tile_loop(std::false_type{});
+            STAMP_END(2);
+            if (EPI_SIDE) {  // the last tile's epilogue (tile NT-1 sits in yA if NT is odd)
+                if (NT & 1) epi_fast_now(yA, NT - 1); else epi_fast_now(yB, NT - 1);
             }
-            if (!XBULK && prefetch_next) finish_x(0);
-            MLP_CHUNK_BARRIER();
+            // the scratch half of xs is rewritten by the next tile's first layer-1 chunk
+            if (XBULK) MLP_CHUNK_BARRIER();
             STAMP_END(3);
-        };
-        for (int pass = 0; pass < p.n_pass; ++pass) run_pass(pass);
+        }
     }
 #ifdef MLP_STAMPS
     if (p.stamps && lane == 0) {
@@ -875,15 +951,6 @@ __global__ __launch_bounds__(kThreads, 1) void mlp_fused_kernel(const MlpLaunch 
         for (int i = 0; i < 17; ++i) o[8 + i] = sl_acc[i];
     }
 #endif
-}
-
-template <int HT, int OC>
-constexpr size_t wbuf_bytes()
-{
-    constexpr int HG = (HT + 3) / 4, OG = (OC + 3) / 4;
-    constexpr int KC_O = (OG <= 2) ? 16 : 8;
-    constexpr int CH_H = 16 * HG * 64, CH_O = KC_O * OG * 64;
-    return 2 * (size_t)((CH_H > CH_O) ? CH_H : CH_O) * 16;
 }
 
 }  // namespace
@@ -896,13 +963,15 @@ using namespace fv3hip;
 // ---------------------------------------------------------------------------------------------
 struct fv3hip_mlp {
     int device = 0;
-    int HT = 0, OC = 0, OL = 0;
+    int HT = 0;
     int n_sources = 0, n_inputs = 0, K = 0, width = 0, n_hidden = 0, n_outputs = 0, F = 0, n_residual = 0;
-    int n_chunks1 = 0, n_pass = 0, n_ktab = 0, n_otab = 0, n_bias = 0;
+    int n_chunks1 = 0, n_otiles = 0, n_ktab = 0, n_otab = 0, n_bias = 0;
     int64_t flops = 0;
     int has_limits = 0;
     int n_log_chunks = 0, n_logfast_chunks = 0;
     unsigned int w_bytes = 0;
+    void *d_sink = nullptr;
+    size_t sink_bytes = 0;
     void *d_w = nullptr, *d_ktab = nullptr, *d_otab = nullptr, *d_bias = nullptr;
     int n_cu = 256;
     size_t lds_bytes = 0;
@@ -910,17 +979,12 @@ struct fv3hip_mlp {
 
 namespace {
 
-struct Variant {
-    int HT, OC, OL;  // hidden tiles, output tiles per pass, output tiles in the last pass
-};
-// (an {8, 13} variant -- all 13 output tiles of the Zhao-Carr emulator in one pass -- was measured
-// slower than {8, 7}: 208 + 128 accumulator registers leave too little for the pipeline's staging)
-const Variant kVariants[] = {{1, 4, 4}, {2, 4, 4}, {4, 4, 4}, {8, 4, 4}, {8, 7, 7}, {8, 7, 6}};
+const int kHiddenTilings[] = {1, 2, 4, 8};  // compiled kernel variants: hidden width <= 32 * HT
 
-template <int HT, int OC, int OL, bool SRC64, bool XBULK>
+template <int HT, bool SRC64, bool XBULK>
 int launch_one(const MlpLaunch &lp, int grid, size_t lds, hipStream_t st)
 {
-    auto kern = mlp_fused_kernel<HT, OC, OL, SRC64, XBULK>;
+    auto kern = mlp_fused_kernel<HT, SRC64, XBULK>;
     FV3HIP_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(kern),
                                          hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
     hipLaunchKernelGGL(kern, dim3(grid), dim3(kThreads), lds, st, lp);
@@ -974,41 +1038,19 @@ extern "C" int fv3hip_mlp_create(const fv3hip_mlp_desc_t *d, fv3hip_mlp_t *out)
         FV3HIP_REQUIRE(d->res_output[r] >= 0 && d->res_output[r] < d->n_outputs, "res_output[%d] out of range", r);
     }
 
-    // pick the kernel variant: smallest hidden tiling that holds `width`, then the output
-    // tiling that wastes the fewest padded feature tiles
+    // pick the kernel variant: the smallest hidden tiling that holds `width`
     const int width = d->width;
     const int nt_out = (F + 31) / 32;
-    int HT = 0, OC = 0, OL = 0, best_cost = 1 << 30;
-    const char *force = getenv("FV3HIP_MLP_OC");  // tuning experiments only: "7" or "7,6"
-    int want_oc = 0, want_ol = 0;
-    if (force) {
-        want_oc = atoi(force);
-        const char *comma = strchr(force, ',');
-        want_ol = comma ? atoi(comma + 1) : want_oc;
-    }
-    for (const Variant &v : kVariants) {
-        if (v.HT * 32 < width) continue;
-        if (HT && v.HT != HT) continue;
-        if (force && (v.OC != want_oc || v.OL != want_ol)) continue;
-        const int np = (nt_out + v.OC - 1) / v.OC;
-        if (nt_out - (np - 1) * v.OC > v.OL) continue;  // the last pass must hold what is left
-        if (!HT) HT = v.HT;
-        const int cost = (np - 1) * v.OC + v.OL;  // feature tiles computed
-        if (cost < best_cost || (cost == best_cost && v.OC > OC)) {
-            best_cost = cost;
-            OC = v.OC;
-            OL = v.OL;
-        }
-    }
-    FV3HIP_REQUIRE(HT > 0 && OC > 0, "no kernel variant for width %d", width);
+    int HT = 0;
+    for (int v : kHiddenTilings)
+        if (!HT && v * 32 >= width) HT = v;
+    FV3HIP_REQUIRE(HT > 0, "no kernel variant for width %d", width);
 
     fv3hip_mlp *m = new fv3hip_mlp();
     hipGetDevice(&m->device);
     hipDeviceProp_t prop;
     if (hipGetDeviceProperties(&prop, m->device) == hipSuccess) m->n_cu = prop.multiProcessorCount;
     m->HT = HT;
-    m->OC = OC;
-    m->OL = OL;
     m->n_sources = d->n_sources;
     m->n_inputs = d->n_inputs;
     m->K = K;
@@ -1019,18 +1061,17 @@ extern "C" int fv3hip_mlp_create(const fv3hip_mlp_desc_t *d, fv3hip_mlp_t *out)
     m->n_residual = d->n_residual;
     m->has_limits = (d->out_min || d->out_max || d->out_mask) ? 1 : 0;
     m->n_chunks1 = ((K + 1) / 2 + 15) / 16;
-    m->n_pass = (nt_out + OC - 1) / OC;
+    m->n_otiles = nt_out;
     m->n_ktab = 2 * 16 * m->n_chunks1;
-    m->n_otab = 32 * OC * m->n_pass;
-    m->n_bias = d->n_hidden * HT * 32 + m->n_pass * OC * 32;
+    m->n_otab = 32 * nt_out;
+    m->n_bias = d->n_hidden * HT * 32 + nt_out * 32;
     m->flops = 2 * ((int64_t)K * width + (int64_t)(d->n_hidden - 1) * width * width + (int64_t)width * F);
 
-    const int HG = (HT + 3) / 4, OG = (OC + 3) / 4;
-    const int KC_O = (OG <= 2) ? 16 : 8;
-    const int OHALVES = 16 / KC_O;
-    const int64_t CH_H = 16 * HG * 64, CH_O = (int64_t)KC_O * OG * 64;  // float4 per chunk
+    const int HG = (HT + 3) / 4;
+    const int GS = (HT == 1) ? 4 : 8, NGO = GS / 4, KC_O = HT * 16 / GS;  // as in the kernel
+    const int64_t CH_H = 16 * HG * 64, CH_O = (int64_t)KC_O * NGO * 64;  // float4 per chunk
     const int n_hid_chunks = m->n_chunks1 + (d->n_hidden - 1) * HT;
-    const int n_out_chunks = m->n_pass * HT * OHALVES;
+    const int n_out_chunks = nt_out;
 
     // ---- input table ----
     // Network input k' is original input feature perm[k']: the log-transformed features come first
@@ -1099,27 +1140,23 @@ extern "C" int fv3hip_mlp_create(const fv3hip_mlp_desc_t *d, fv3hip_mlp_t *out)
                         }
         }
     }
-    // output layer
+    // output layer, tile-major: chunk t = output features 32t..32t+31 over the whole contraction;
+    // slot s holds k-pairs GS*s .. GS*s+GS-1, four per float4: k-pair m pairs hidden activations
+    // k = 32*(m/16) + rho(m%16) + 4*half (the accumulator layout of the last hidden layer)
     {
         const float *W = d->out_kernel;
         const size_t base = (size_t)n_hid_chunks * CH_H * 4;
-        for (int pass = 0; pass < m->n_pass; ++pass)
-            for (int kt = 0; kt < HT; ++kt)
-                for (int hf = 0; hf < OHALVES; ++hf) {
-                    const int go = (pass * HT + kt) * OHALVES + hf;
-                    for (int s = 0; s < KC_O; ++s)
-                        for (int j = 0; j < OG; ++j)
-                            for (int lane = 0; lane < 64; ++lane)
-                                for (int e = 0; e < 4; ++e) {
-                                    const int t = 4 * j + e;
-                                    if (t >= OC) continue;
-                                    const int k = 32 * kt + rho(hf * KC_O + s) + 4 * (lane >> 5);
-                                    const int f = 32 * (pass * OC + t) + (lane & 31);
-                                    if (k < width && f < F)
-                                        w[base + (size_t)((go * CH_O + ((int64_t)(s * OG + j) * 64 + lane)) * 4 + e)] =
-                                            W[(size_t)k * F + f];
-                                }
-                }
+        for (int t = 0; t < nt_out; ++t)
+            for (int s = 0; s < KC_O; ++s)
+                for (int j = 0; j < NGO; ++j)
+                    for (int lane = 0; lane < 64; ++lane)
+                        for (int e = 0; e < 4; ++e) {
+                            const int mm = GS * s + 4 * j + e;
+                            const int k = 32 * (mm / 16) + rho(mm % 16) + 4 * (lane >> 5);
+                            const int f = 32 * t + (lane & 31);
+                            if (k < width && f < F)
+                                w[base + (size_t)((t * CH_O + ((int64_t)(s * NGO + j) * 64 + lane)) * 4 + e)] = W[(size_t)k * F + f];
+                        }
     }
     // ---- output table ----
     std::vector<OEntry> otab(m->n_otab);
@@ -1151,13 +1188,12 @@ extern "C" int fv3hip_mlp_create(const fv3hip_mlp_desc_t *d, fv3hip_mlp_t *out)
                     const int f = 32 * t + rho(r) + 4 * hf;
                     if (f < width) bias[(size_t)l * HT * 32 + (t * 16 + r) * 2 + hf] = d->hidden_biases[l][f];
                 }
-    for (int pass = 0; pass < m->n_pass; ++pass)
-        for (int t = 0; t < OC; ++t)
-            for (int r = 0; r < 16; ++r)
-                for (int hf = 0; hf < 2; ++hf) {
-                    const int f = 32 * (pass * OC + t) + rho(r) + 4 * hf;
-                    if (f < F) bias[(size_t)d->n_hidden * HT * 32 + (size_t)pass * OC * 32 + (t * 16 + r) * 2 + hf] = d->out_bias[f];
-                }
+    for (int t = 0; t < nt_out; ++t)
+        for (int r = 0; r < 16; ++r)
+            for (int hf = 0; hf < 2; ++hf) {
+                const int f = 32 * t + rho(r) + 4 * hf;
+                if (f < F) bias[(size_t)d->n_hidden * HT * 32 + (size_t)t * 32 + r * 2 + hf] = d->out_bias[f];
+            }
 
     int rc;
     FV3HIP_REQUIRE(w.size() * sizeof(float) < (1ull << 31), "model too large: the packed weight stream exceeds 2 GiB");
@@ -1168,7 +1204,8 @@ extern "C" int fv3hip_mlp_create(const fv3hip_mlp_desc_t *d, fv3hip_mlp_t *out)
         return rc;
     }
     const size_t wb = 2 * (size_t)((CH_H > CH_O) ? CH_H : CH_O) * 16;
-    m->lds_bytes = wb + 2 * 32 * kTileSamples * sizeof(float) /* XBULK input tiles */ + (size_t)m->n_ktab * sizeof(KEntry) +
+    // (the fast-I/O kernels add the 32 KB input tiles at launch)
+    m->lds_bytes = wb + (size_t)m->n_ktab * sizeof(KEntry) +
                    (size_t)m->n_otab * (sizeof(OFast) + sizeof(OSlow) + (d->n_residual ? sizeof(ORes) : 0)) +
                    (size_t)((m->n_bias + 3) & ~3) * sizeof(float) + (size_t)(3 * kMaxSources + 3 * kMaxOutputs) * 8;
     if (m->lds_bytes > 160 * 1024) {
@@ -1187,6 +1224,7 @@ extern "C" void fv3hip_diag_set_mlp_stamps(void *p) { g_mlp_stamps = static_cast
 extern "C" int fv3hip_mlp_destroy(fv3hip_mlp_t m)
 {
     if (!m) return FV3HIP_OK;
+    if (m->d_sink) hipFree(m->d_sink);
     if (m->d_w) hipFree(m->d_w);
     if (m->d_ktab) hipFree(m->d_ktab);
     if (m->d_otab) hipFree(m->d_otab);
@@ -1241,7 +1279,7 @@ extern "C" int fv3hip_mlp_predict(fv3hip_mlp_t m, const void *const *sources, co
     lp.bias = static_cast<const float *>(m->d_bias);
     lp.n_chunks1 = m->n_chunks1;
     lp.n_hidden = m->n_hidden;
-    lp.n_pass = m->n_pass;
+    lp.n_otiles = m->n_otiles;
     lp.n_ktab = m->n_ktab;
     lp.n_otab = m->n_otab;
     lp.n_bias = m->n_bias;
@@ -1268,25 +1306,36 @@ extern "C" int fv3hip_mlp_predict(fv3hip_mlp_t m, const void *const *sources, co
 #endif
     const int grid = (int)(lp.n_tiles < m->n_cu ? lp.n_tiles : m->n_cu);
     // fast-I/O kernels when every source and output is sample-contiguous and aligned (see the kernel)
-    const bool xbulk = lp.epi_fast != 0;
+    bool xbulk = lp.epi_fast != 0;
     hipStream_t st = as_stream(stream);
-    // (the general kernels exist with OL == OC only; the packed model is the same for any OL)
-#define VARIANT_(H, O, L)                                                                          \
-    if (m->HT == H && m->OC == O && m->OL == L) {                                                  \
-        if (xbulk)                                                                                 \
-            return src64 ? launch_one<H, O, L, true, true>(lp, grid, m->lds_bytes, st)             \
-                         : launch_one<H, O, L, false, true>(lp, grid, m->lds_bytes, st);           \
-        return src64 ? launch_one<H, O, O, true, false>(lp, grid, m->lds_bytes, st)                \
-                     : launch_one<H, O, O, false, false>(lp, grid, m->lds_bytes, st);              \
+    constexpr size_t kLdsMax = 160 * 1024, kXsBytes = 2 * 32 * kTileSamples * sizeof(float);
+    if (m->lds_bytes + kXsBytes > kLdsMax) xbulk = false;  // (large tables: the general kernels still fit)
+    const size_t lds = m->lds_bytes + (xbulk ? kXsBytes : 0);
+    lp.sink = 0;
+    if (xbulk) {
+        // scratch row for the padded output rows (kept with the model; grown on demand -- a first
+        // call or a larger n_samples allocates, so warm the model up before capturing a graph)
+        const size_t need = (size_t)n_samples * 8;
+        if (m->sink_bytes < need) {
+            if (m->d_sink) FV3HIP_CHECK_HIP(hipFree(m->d_sink));
+            m->d_sink = nullptr;
+            m->sink_bytes = 0;
+            FV3HIP_CHECK_HIP(hipMalloc(&m->d_sink, need));
+            m->sink_bytes = need;
+        }
+        lp.sink = reinterpret_cast<int64_t>(m->d_sink);
+    }
+#define VARIANT_(H)                                                                                \
+    if (m->HT == H) {                                                                              \
+        if (xbulk) return src64 ? launch_one<H, true, true>(lp, grid, lds, st) : launch_one<H, false, true>(lp, grid, lds, st); \
+        return src64 ? launch_one<H, true, false>(lp, grid, lds, st) : launch_one<H, false, false>(lp, grid, lds, st);          \
     }
 #ifndef MLP_FAST_BUILD  // (experiments compile the flagship variant only)
-    VARIANT_(1, 4, 4)
-    VARIANT_(2, 4, 4)
-    VARIANT_(4, 4, 4)
-    VARIANT_(8, 4, 4)
+    VARIANT_(1)
+    VARIANT_(2)
+    VARIANT_(4)
 #endif
-    VARIANT_(8, 7, 7)
-    VARIANT_(8, 7, 6)
+    VARIANT_(8)
 #undef VARIANT_
-    return fail(FV3HIP_EUNSUPPORTED, "no compiled kernel variant for HT=%d OC=%d OL=%d", m->HT, m->OC, m->OL);
+    return fail(FV3HIP_EUNSUPPORTED, "no compiled kernel variant for HT=%d", m->HT);
 }
