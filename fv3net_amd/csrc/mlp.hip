@@ -396,9 +396,9 @@ __global__ __launch_bounds__(kThreads, 1) void mlp_fused_kernel(const MlpLaunch 
         const float lg = logf(raw < e.eps ? e.eps : raw);
         const float v = (e.flags & 1) ? lg : raw;
         // (x - mean) * (1 / (std + eps)) instead of the reference's division: <= 1 ulp apart
-        xcur[s] = (v - e.center) * e.rscale;
+        xcur[s] = v - e.center;  // (1 / std lives in the layer-1 weights)
     };
-    auto finish_x1_plain = [&](const XNorm e, int s) { xcur[s] = ((float)xraw[s] - e.center) * e.rscale; };
+    auto finish_x1_plain = [&](const XNorm e, int s) { xcur[s] = (float)xraw[s] - e.center; };
     auto issue_x = [&](int c, int64_t nc) {  // a whole chunk at once (tile boundaries only)
 #pragma unroll
         for (int s = 0; s < KC_H; ++s) issue_x1(xa_tab[2 * (c * KC_H + s) + half], s, nc);
@@ -481,7 +481,7 @@ __global__ __launch_bounds__(kThreads, 1) void mlp_fused_kernel(const MlpLaunch 
                 v[q] = __builtin_amdgcn_logf(v[q] < e.eps ? e.eps : v[q]) * 0.693147180559945f;
         }
 #ifndef MLP_ABLATE_FMATH
-        v = (v - e.center) * e.rscale;
+        v = v - e.center;  // (1 / std lives in the layer-1 weights)
 #endif
 #ifndef MLP_ABLATE_FWRITE
         *reinterpret_cast<f32x4 *>(xs + (buf * 32 + kk) * kTileSamples + 4 * sg) = v;
@@ -722,7 +722,7 @@ __global__ __launch_bounds__(kThreads, 1) void mlp_fused_kernel(const MlpLaunch 
             // tile loop, so that the side work inside the MFMA slots is branch-free: the MFMAs of a
             // slot queue only one deep, every branch in its side work is matrix-pipe idle time)
             auto epi_row = [&](const OFast of, f32x4 v, int idx, auto plain_c) {
-                v = v * of.scale + of.center;
+                // (v is the physical value: scale and center live in the output weights and bias)
                 if (decltype(plain_c)::value) {
                     *(GF32x4)(of.row + (n0t + e_wcol) * 4) = v;  // (padded rows point at the sink row)
                     return;
@@ -809,7 +809,7 @@ __global__ __launch_bounds__(kThreads, 1) void mlp_fused_kernel(const MlpLaunch 
                     }
 #pragma unroll
                     for (int i = 0; i < 8; ++i) {
-                        float x = y[gq * 8 + i] * of[i].scale + of[i].center;
+                        float x = y[gq * 8 + i];  // (physical value: scale and center live in the weights)
                         if (p.has_limits) {
                             if (x < os[i].lo) x = os[i].lo;
                             if (x >= os[i].hi) x = os[i].hi;
@@ -1112,7 +1112,8 @@ extern "C" int fv3hip_mlp_create(const fv3hip_mlp_desc_t *d, fv3hip_mlp_t *out)
     auto hid_slot = [&](int g, int s, int j, int lane, int e) -> float & {
         return w[(size_t)((g * CH_H + ((int64_t)(s * HG + j) * 64 + lane)) * 4 + e)];
     };
-    // layer 1: k = 2 * kpair + half
+    // layer 1: k = 2 * kpair + half.  The inputs' 1 / (std + eps) is folded into the row of the kernel that
+    // multiplies them (one rounding per weight, once): the kernel only subtracts the mean.
     {
         const float *W = d->hidden_kernels[0];
         for (int g = 0; g < m->n_chunks1; ++g)
@@ -1122,7 +1123,7 @@ extern "C" int fv3hip_mlp_create(const fv3hip_mlp_desc_t *d, fv3hip_mlp_t *out)
                         for (int e = 0; e < 4; ++e) {
                             const int k = 2 * (g * 16 + s) + (lane >> 5);
                             const int f = 32 * (4 * j + e) + (lane & 31);
-                            if (k < K && f < width) hid_slot(g, s, j, lane, e) = W[(size_t)perm[k] * width + f];
+                            if (k < K && f < width) hid_slot(g, s, j, lane, e) = W[(size_t)perm[k] * width + f] * ktab[k].scale;
                         }
     }
     // hidden layers l >= 1: k = 32*kt + rho(s) + 4*half (the accumulator layout of the layer before)
@@ -1140,7 +1141,8 @@ extern "C" int fv3hip_mlp_create(const fv3hip_mlp_desc_t *d, fv3hip_mlp_t *out)
                         }
         }
     }
-    // output layer, tile-major: chunk t = output features 32t..32t+31 over the whole contraction;
+    // output layer (the outputs' denormalisation y * scale + center is folded into kernel and bias, so
+    // the accumulator already holds the physical value), tile-major: chunk t = output features 32t..32t+31 over the whole contraction;
     // slot s holds k-pairs GS*s .. GS*s+GS-1, four per float4: k-pair m pairs hidden activations
     // k = 32*(m/16) + rho(m%16) + 4*half (the accumulator layout of the last hidden layer)
     {
@@ -1155,7 +1157,8 @@ extern "C" int fv3hip_mlp_create(const fv3hip_mlp_desc_t *d, fv3hip_mlp_t *out)
                             const int k = 32 * (mm / 16) + rho(mm % 16) + 4 * (lane >> 5);
                             const int f = 32 * t + (lane & 31);
                             if (k < width && f < F)
-                                w[base + (size_t)((t * CH_O + ((int64_t)(s * NGO + j) * 64 + lane)) * 4 + e)] = W[(size_t)k * F + f];
+                                w[base + (size_t)((t * CH_O + ((int64_t)(s * NGO + j) * 64 + lane)) * 4 + e)] =
+                                    W[(size_t)k * F + f] * (d->out_scale ? d->out_scale[f] : 1.f);
                         }
     }
     // ---- output table ----
@@ -1192,7 +1195,9 @@ extern "C" int fv3hip_mlp_create(const fv3hip_mlp_desc_t *d, fv3hip_mlp_t *out)
         for (int r = 0; r < 16; ++r)
             for (int hf = 0; hf < 2; ++hf) {
                 const int f = 32 * t + rho(r) + 4 * hf;
-                if (f < F) bias[(size_t)d->n_hidden * HT * 32 + (size_t)t * 32 + r * 2 + hf] = d->out_bias[f];
+                if (f < F)
+                    bias[(size_t)d->n_hidden * HT * 32 + (size_t)t * 32 + r * 2 + hf] =
+                        (float)((double)d->out_bias[f] * (d->out_scale ? d->out_scale[f] : 1.f) + (d->out_center ? d->out_center[f] : 0.f));
             }
 
     int rc;
