@@ -1080,7 +1080,7 @@ extern "C" int fv3hip_mlp_create(const fv3hip_mlp_desc_t *d, fv3hip_mlp_t *out)
     std::vector<KEntry> ktab(m->n_ktab);
     for (auto &e : ktab) e = KEntry{-1, 0, 0.f, 1.f, 0, 0.f, 0, 0};
     std::vector<int> perm;
-    perm.reserve(K);
+    perm.reserve(m->n_ktab);
     {
         std::vector<KEntry> orig(K);
         int k = 0;
@@ -1097,14 +1097,28 @@ extern "C" int fv3hip_mlp_create(const fv3hip_mlp_desc_t *d, fv3hip_mlp_t *out)
             }
         for (int k2 = 0; k2 < K; ++k2)
             if (orig[k2].transform == FV3HIP_TRANSFORM_LOG) perm.push_back(k2);
-        const int n_log = (int)perm.size();
+        int n_log = (int)perm.size();
+        // if the chunk count allows, pad the log block to whole chunks (entries -1: zero weight rows
+        // reading a constant, eps = 1 so that the logarithm is of a normal number) -- then no chunk
+        // mixes both kinds and every log chunk takes the fast path
+        const int n_pad = (32 - n_log % 32) % 32;
+        if (n_log > 0 && n_log + n_pad + (K - n_log) <= m->n_ktab)
+            for (int i = 0; i < n_pad; ++i) perm.push_back(-1);
+        const int n_log_padded = (int)perm.size();
         for (int k2 = 0; k2 < K; ++k2)
             if (orig[k2].transform != FV3HIP_TRANSFORM_LOG) perm.push_back(k2);
-        for (int k2 = 0; k2 < K; ++k2) ktab[k2] = orig[perm[k2]];
-        m->n_log_chunks = (n_log + 31) / 32;
+        for (size_t k2 = 0; k2 < perm.size(); ++k2) {
+            if (perm[k2] >= 0) {
+                ktab[k2] = orig[perm[k2]];
+            } else {
+                ktab[k2].transform = FV3HIP_TRANSFORM_LOG;
+                ktab[k2].eps = 1.f;
+            }
+        }
+        m->n_log_chunks = (n_log_padded + 31) / 32;
         bool eps_normal = true;
-        for (int k2 = 0; k2 < n_log; ++k2) eps_normal = eps_normal && ktab[k2].eps >= FLT_MIN;
-        m->n_logfast_chunks = eps_normal ? n_log / 32 : 0;
+        for (int k2 = 0; k2 < n_log_padded; ++k2) eps_normal = eps_normal && ktab[k2].eps >= FLT_MIN;
+        m->n_logfast_chunks = eps_normal ? n_log_padded / 32 : 0;
     }
     // ---- packed weight stream ----
     // (+ one maximal chunk of zero padding: the two-half staging may read past a short last chunk)
@@ -1123,7 +1137,8 @@ extern "C" int fv3hip_mlp_create(const fv3hip_mlp_desc_t *d, fv3hip_mlp_t *out)
                         for (int e = 0; e < 4; ++e) {
                             const int k = 2 * (g * 16 + s) + (lane >> 5);
                             const int f = 32 * (4 * j + e) + (lane & 31);
-                            if (k < K && f < width) hid_slot(g, s, j, lane, e) = W[(size_t)perm[k] * width + f] * ktab[k].scale;
+                            if (k < (int)perm.size() && perm[k] >= 0 && f < width)
+                                hid_slot(g, s, j, lane, e) = W[(size_t)perm[k] * width + f] * ktab[k].scale;
                         }
     }
     // hidden layers l >= 1: k = 32*kt + rho(s) + 4*half (the accumulator layout of the layer before)
