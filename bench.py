@@ -301,7 +301,7 @@ def main():
                 "unit": "TFLOP/s",
                 "frac": achieved / PEAK_FP32_MFMA_TFLOPS,
                 "traffic": None,
-                "kernel": "mlp_fused_kernel<8,7,6,false,true>",
+                "kernel": "mlp_fused_kernel<8,false,true>",
                 "kernel_ms": kernel_ms,
             },
         }
