@@ -94,6 +94,9 @@ SIGNATURES = {
         [c_void_p, c_int, c_int64, c_int, c_int, c_int, c_int, c_int, c_int, c_int, c_int, c_void_p, c_void_p],
     ),
     "fv3hip_block_upsample": (c_int, [c_void_p, c_int, c_int64, c_int, c_int, c_int, c_void_p, c_void_p]),
+    "fv3hip_cube_edge_rows": (c_int, [c_void_p, c_int, c_int, c_int64, c_int, c_void_p, c_void_p]),
+    "fv3hip_interp_center_to_outer": (c_int, [c_void_p, c_int, c_int64, c_int, c_int, c_int, c_void_p, c_void_p,
+                                              c_void_p, c_void_p]),
     "fv3hip_pressure_at_interface": (
         c_int,
         [c_void_p, c_int, c_int64, c_int, c_int64, c_double, c_void_p, c_void_p],

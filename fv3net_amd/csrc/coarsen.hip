@@ -446,6 +446,59 @@ __global__ void upsample_kernel(const U *__restrict__ in, U *__restrict__ out, i
     }
 }
 
+
+// ---------------------------------------------------------------------------------------
+// Cell centres -> cell edges across the cube (external/vcm/vcm/cubedsphere/xgcm.py:7-34,
+// regridz.py:123-135: xgcm.Grid.interp(delp, axis) with FV3_FACE_CONNECTIONS)
+// ---------------------------------------------------------------------------------------
+// rows[t][e][o][j]: the four boundary vectors of tile t, indexed along the edge:
+//   e = 0: x = 0 (j = y), 1: x = n-1 (j = y), 2: y = 0 (j = x), 3: y = n-1 (j = x)
+template <typename U>
+__global__ void cube_edge_rows_kernel(const U *__restrict__ in, U *__restrict__ rows, int n_tiles, int64_t n_mid,
+                                      int n)
+{
+    const int64_t total = (int64_t)n_tiles * 4 * n_mid * n;
+    for (int64_t idx = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; idx < total;
+         idx += (int64_t)gridDim.x * blockDim.x) {
+        const int j = (int)(idx % n);
+        int64_t r = idx / n;
+        const int64_t o = r % n_mid;
+        r /= n_mid;
+        const int e = (int)(r % 4);
+        const int64_t t = r / 4;
+        const int y = (e == 0 || e == 1) ? j : (e == 2 ? 0 : n - 1);
+        const int x = (e == 2 || e == 3) ? j : (e == 0 ? 0 : n - 1);
+        rows[idx] = in[((t * n_mid + o) * n + y) * n + x];
+    }
+}
+
+// out[o][y][x'] = 0.5 * (left + right) along `axis` (0 = x: nx+1 points, 1 = y: ny+1 points); beyond the
+// tile the neighbours come from lo / hi [o][along-edge index]
+template <typename T>
+__global__ void interp_to_outer_kernel(const T *__restrict__ in, const T *__restrict__ lo, const T *__restrict__ hi,
+                                       T *__restrict__ out, int64_t n_outer, int ny, int nx, int axis)
+{
+    const int nyo = ny + (axis == 1), nxo = nx + (axis == 0);
+    const int64_t total = n_outer * nyo * nxo;
+    for (int64_t idx = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; idx < total;
+         idx += (int64_t)gridDim.x * blockDim.x) {
+        const int x = (int)(idx % nxo);
+        const int64_t r = idx / nxo;
+        const int y = (int)(r % nyo);
+        const int64_t o = r / nyo;
+        const T *f = in + o * (int64_t)ny * nx;
+        T a, b;
+        if (axis == 0) {
+            a = (x == 0) ? lo[o * ny + y] : f[(int64_t)y * nx + x - 1];
+            b = (x == nx) ? hi[o * ny + y] : f[(int64_t)y * nx + x];
+        } else {
+            a = (y == 0) ? lo[o * nx + x] : f[(int64_t)(y - 1) * nx + x];
+            b = (y == ny) ? hi[o * nx + x] : f[(int64_t)y * nx + x];
+        }
+        out[idx] = (T)0.5 * (a + b);
+    }
+}
+
 }  // namespace
 }  // namespace fv3hip
 
@@ -528,4 +581,47 @@ extern "C" int fv3hip_block_upsample(const void *in, int elem_size, int64_t n_ou
                            static_cast<const uint64_t *>(in), static_cast<uint64_t *>(out), n_outer,
                            ny_in, nx_in, ny_out, nx_out, factor);
     return check_launch("upsample_kernel");
+}
+
+extern "C" int fv3hip_cube_edge_rows(const void *in, int elem_size, int n_tiles, int64_t n_mid, int n, void *rows,
+                                     void *stream)
+{
+    FV3HIP_REQUIRE(elem_size == 4 || elem_size == 8, "elem_size must be 4 or 8, got %d", elem_size);
+    FV3HIP_REQUIRE(n_tiles >= 0 && n_mid >= 0 && n >= 0, "negative extent");
+    if (n_tiles == 0 || n_mid == 0 || n == 0) return FV3HIP_OK;
+    FV3HIP_REQUIRE(in && rows, "null pointer");
+    const int64_t total = (int64_t)n_tiles * 4 * n_mid * n;
+    int64_t blocks = ceil_div(total, 256);
+    if (blocks > 256 * 64) blocks = 256 * 64;
+    hipStream_t st = as_stream(stream);
+    if (elem_size == 4)
+        hipLaunchKernelGGL((cube_edge_rows_kernel<uint32_t>), dim3((unsigned)blocks), dim3(256), 0, st,
+                           static_cast<const uint32_t *>(in), static_cast<uint32_t *>(rows), n_tiles, n_mid, n);
+    else
+        hipLaunchKernelGGL((cube_edge_rows_kernel<uint64_t>), dim3((unsigned)blocks), dim3(256), 0, st,
+                           static_cast<const uint64_t *>(in), static_cast<uint64_t *>(rows), n_tiles, n_mid, n);
+    return check_launch("cube_edge_rows_kernel");
+}
+
+extern "C" int fv3hip_interp_center_to_outer(const void *in, int dtype, int64_t n_outer, int ny, int nx, int axis,
+                                             const void *lo, const void *hi, void *out, void *stream)
+{
+    FV3HIP_REQUIRE(axis == 0 || axis == 1, "axis must be 0 ('x') or 1 ('y'), got %d", axis);
+    FV3HIP_REQUIRE(dtype == FV3HIP_F32 || dtype == FV3HIP_F64, "dtype must be F32 or F64");
+    FV3HIP_REQUIRE(n_outer >= 0 && ny >= 0 && nx >= 0, "negative extent");
+    if (n_outer == 0 || ny == 0 || nx == 0) return FV3HIP_OK;
+    FV3HIP_REQUIRE(in && lo && hi && out, "null pointer");
+    const int64_t total = n_outer * (ny + (axis == 1)) * (nx + (axis == 0));
+    int64_t blocks = ceil_div(total, 256);
+    if (blocks > 256 * 64) blocks = 256 * 64;
+    hipStream_t st = as_stream(stream);
+    if (dtype == FV3HIP_F32)
+        hipLaunchKernelGGL((interp_to_outer_kernel<float>), dim3((unsigned)blocks), dim3(256), 0, st,
+                           static_cast<const float *>(in), static_cast<const float *>(lo), static_cast<const float *>(hi),
+                           static_cast<float *>(out), n_outer, ny, nx, axis);
+    else
+        hipLaunchKernelGGL((interp_to_outer_kernel<double>), dim3((unsigned)blocks), dim3(256), 0, st,
+                           static_cast<const double *>(in), static_cast<const double *>(lo), static_cast<const double *>(hi),
+                           static_cast<double *>(out), n_outer, ny, nx, axis);
+    return check_launch("interp_to_outer_kernel");
 }

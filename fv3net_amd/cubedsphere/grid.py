@@ -1,0 +1,98 @@
+"""Cube-face connectivity and the centre-to-edge interpolation the coarsening path takes from
+xgcm (``vcm.cubedsphere.xgcm.create_fv3_grid(...).interp``; external/vcm/vcm/cubedsphere/xgcm.py:7-97,
+used at regridz.py:123-135 and coarsen_restarts.py:825-853).
+
+xgcm itself is not part of the reference tree (xgcm==0.6.1, constraints.txt:316).  What it
+computes here: every tile is padded with one row of its two neighbours along the interpolated axis
+-- the left neighbour's last line along its connecting axis, the right neighbour's first; a
+neighbour connected through its *other* axis contributes that line reversed -- then
+``0.5 * (left + right)`` on the n+1 cell edges.  The reference's pressure-level regression
+fixtures (``u``, ``v``) pin this on all 12 cube edges (tests/test_oracle_coarsen.py).
+
+The padding rows are the only data that ever crosses tiles on the coarse-graining path: with tiles
+sharded over GPUs they are what ``fv3net_amd.parallel.exchange_edge_rows`` all-gathers.
+"""
+from typing import Hashable
+
+import numpy as np
+import torch
+
+from .. import ops
+from ..xr_compat import DataArray, from_compat, to_compat
+from ._device import like_input, on_device
+from .constants import COORD_X_CENTER, COORD_X_OUTER, COORD_Y_CENTER, COORD_Y_OUTER
+
+# xgcm.py:7-34: tile -> axis -> ((left neighbour, its axis), (right neighbour, its axis)); none "reversed"
+FV3_FACE_CONNECTIONS = {
+    0: {"x": ((4, "y"), (1, "x")), "y": ((5, "y"), (2, "x"))},
+    1: {"x": ((0, "x"), (3, "y")), "y": ((5, "x"), (2, "y"))},
+    2: {"x": ((0, "y"), (3, "x")), "y": ((1, "y"), (4, "x"))},
+    3: {"x": ((2, "x"), (5, "y")), "y": ((1, "x"), (4, "y"))},
+    4: {"x": ((2, "y"), (5, "x")), "y": ((3, "y"), (0, "x"))},
+    5: {"x": ((4, "x"), (1, "y")), "y": ((3, "x"), (0, "y"))},
+}
+
+# index of a tile's boundary vector in ops.cube_edge_rows: (axis, first/last line along it)
+_ROW = {("x", "first"): 0, ("x", "last"): 1, ("y", "first"): 2, ("y", "last"): 3}
+
+
+def halos_from_rows(rows: torch.Tensor, tiles, axis: str):
+    """(lo, hi) [len(tiles), ..., n] for ``axis`` from the boundary vectors of ALL six tiles
+    (``rows`` [6, 4, ..., n] as returned by ``ops.cube_edge_rows``)."""
+    lo, hi = [], []
+    for t in tiles:
+        (ln, la), (rn, ra) = FV3_FACE_CONNECTIONS[int(t)][axis]
+        left = rows[ln, _ROW[(la, "last")]]
+        right = rows[rn, _ROW[(ra, "first")]]
+        lo.append(left if la == axis else left.flip(-1))
+        hi.append(right if ra == axis else right.flip(-1))
+    return torch.stack(lo), torch.stack(hi)
+
+
+def interp_tiles_to_edges(field: torch.Tensor, axis: str) -> torch.Tensor:
+    """[6, ..., n, n] cell-centred -> cell edges along ``axis`` ('x': [6, ..., n, n+1]; 'y':
+    [6, ..., n+1, n]), all six tiles resident on one device."""
+    if field.shape[0] != 6:
+        raise ValueError("The leading dimension must hold the six tiles of the cube")
+    rows = ops.cube_edge_rows(field)
+    lo, hi = halos_from_rows(rows, range(6), axis)
+    return ops.interp_center_to_outer(field, lo, hi, 0 if axis == "x" else 1)
+
+
+def _validate_tile_coord(da: DataArray):
+    if "tile" not in da.dims:
+        raise ValueError("The input Dataset must have a `tile` coordinate.")
+    if "tile" in da.coords and set(np.asarray(da.coords["tile"]).tolist()) != {0, 1, 2, 3, 4, 5}:
+        raise ValueError("`tile` coordinate must contain each of [0, 1, 2, 3, 4, 5]")
+    if da.sizes["tile"] != 6:
+        raise ValueError("`tile` coordinate must contain each of [0, 1, 2, 3, 4, 5]")
+
+
+def interp_center_to_outer(da, axis: str, x_center: Hashable = COORD_X_CENTER, x_outer: Hashable = COORD_X_OUTER,
+                           y_center: Hashable = COORD_Y_CENTER, y_outer: Hashable = COORD_Y_OUTER):
+    """``create_fv3_grid(ds, ...).interp(da, axis)`` for a cell-centred array: the result carries the
+    outer dimension name in place of the centre one, with coordinate 0..n (xgcm.py:42-97)."""
+    if axis not in ("x", "y"):
+        raise ValueError(f"axis must be 'x' or 'y', got {axis!r}")
+    d = to_compat(da)
+    _validate_tile_coord(d)
+    for dim in (x_center, y_center):
+        if dim not in d.dims:
+            raise ValueError(f"{dim!r} is not a dimension of the array")
+    outer = [dim for dim in d.dims if dim not in ("tile", y_center, x_center)]
+    order = ["tile"] + outer + [y_center, x_center]
+    t = on_device(d.transpose(*order).data)
+    if "tile" in d.coords:  # tiles in coordinate order
+        perm = np.argsort(np.asarray(d.coords["tile"]))
+        if not np.array_equal(perm, np.arange(6)):
+            t = t[torch.as_tensor(perm, device=t.device)]
+    res = interp_tiles_to_edges(t, axis)
+    new_dim = x_outer if axis == "x" else y_outer
+    old_dim = x_center if axis == "x" else y_center
+    dims = tuple(new_dim if dim == old_dim else dim for dim in order)
+    coords = {k: v for k, v in d.coords.items() if k != old_dim and k != "tile"}
+    coords["tile"] = np.arange(6)
+    coords[new_dim] = np.arange(res.shape[-1 if axis == "x" else -2])
+    out = DataArray(like_input(res, d.data), dims=dims, coords=coords, name=d.name, attrs=d.attrs)
+    out = out.transpose(*[new_dim if dim == old_dim else dim for dim in d.dims])
+    return from_compat(out, da)

@@ -11,8 +11,18 @@ from .. import ops
 from ..thermo import pressure_at_interface, pressure_at_midpoint_log
 from ..xr_compat import DataArray, Dataset, from_compat, to_compat
 from ._device import like_input, on_device
-from .coarsen import block_upsample_like, weighted_block_average
-from .constants import FV_CORE_X_CENTER, FV_CORE_Y_CENTER, RESTART_Z_CENTER, RESTART_Z_OUTER
+import numpy as np
+
+from .coarsen import block_upsample_like, edge_weighted_block_average, weighted_block_average
+from .constants import (
+    FV_CORE_X_CENTER,
+    FV_CORE_X_OUTER,
+    FV_CORE_Y_CENTER,
+    FV_CORE_Y_OUTER,
+    RESTART_Z_CENTER,
+    RESTART_Z_OUTER,
+)
+from .grid import interp_center_to_outer
 
 SURFACE_LEVEL = -1
 
@@ -105,3 +115,37 @@ def regrid_to_area_weighted_pressure(ds, delp, area, toa_pressure: float, coarse
     delp_coarse = weighted_block_average(delp, area, coarsening_factor, x_dim=x_dim, y_dim=y_dim)
     return _regrid_given_delp(ds, delp, delp_coarse, area, toa_pressure, x_dim=x_dim, y_dim=y_dim, z_dim=z_dim,
                               extrapolate=extrapolate)
+
+
+def compute_edge_delp(delp, edge: str, x_dim: str = FV_CORE_X_CENTER, y_dim: str = FV_CORE_Y_CENTER):
+    """Pressure thickness on grid cell edges (coarsen_restarts.py:825-853): ``delp`` interpolated
+    across the cube's faces to the edges the ``edge``-directed wind component lives on; the new
+    staggered dimension keeps the name passed for it, with coordinate 1..n+1 (float32)."""
+    hor_dims = {"x": x_dim, "y": y_dim}
+    interp_dim = "x" if edge == "y" else "y"
+    outer_names = {"x": FV_CORE_X_OUTER, "y": FV_CORE_Y_OUTER}
+    staggered = to_compat(interp_center_to_outer(delp, interp_dim, x_center=FV_CORE_X_CENTER, x_outer=FV_CORE_X_OUTER,
+                                                 y_center=FV_CORE_Y_CENTER, y_outer=FV_CORE_Y_OUTER))
+    d = to_compat(delp)
+    new_dim = outer_names[interp_dim]
+    wanted = hor_dims[interp_dim]
+    if wanted == new_dim:  # (with other names the reference attaches a coordinate that indexes no dimension)
+        staggered = staggered.assign_coords({wanted: np.arange(1, d.sizes[hor_dims[edge]] + 2, dtype=np.float32)})
+    return from_compat(staggered, delp)
+
+
+def regrid_to_edge_weighted_pressure(ds, delp, length, toa_pressure: float, coarsening_factor: int,
+                                     x_dim: str = FV_CORE_X_CENTER, y_dim: str = FV_CORE_Y_OUTER,
+                                     z_dim: str = RESTART_Z_CENTER, edge: str = "x", extrapolate: bool = False):
+    """Vertically regrid edge-valued quantities (D-grid winds) to coarsened pressure levels
+    (regridz.py:81-146).  ``delp`` is interpolated to the cell edges across the cube's faces -- the one
+    step of the coarse-graining path that needs data from neighbouring tiles -- coarsened along the
+    edges with the edge lengths, and the fields are remapped column by column.  Returns (regridded
+    dataset, edge lengths masked wherever the coarse layer is below the fine surface)."""
+    if edge not in ("x", "y"):
+        raise ValueError(f"'edge' most be either 'x' or 'y'; got {edge}.")
+    delp_staggered = compute_edge_delp(delp, edge, x_dim=x_dim, y_dim=y_dim)
+    delp_staggered_coarse = edge_weighted_block_average(delp_staggered, length, coarsening_factor, x_dim=x_dim,
+                                                        y_dim=y_dim, edge=edge)
+    return _regrid_given_delp(ds, delp_staggered, delp_staggered_coarse, length, toa_pressure, x_dim=x_dim,
+                              y_dim=y_dim, z_dim=z_dim, extrapolate=extrapolate)

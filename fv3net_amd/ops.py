@@ -205,6 +205,42 @@ def block_upsample(x: torch.Tensor, factor: int) -> torch.Tensor:
     return out
 
 
+def cube_edge_rows(x: torch.Tensor) -> torch.Tensor:
+    """The four boundary vectors of every square tile of ``x`` [tile, ..., n, n] ->
+    [tile, 4, ..., n]: 0: x = 0, 1: x = n-1 (indexed by y), 2: y = 0, 3: y = n-1 (indexed by x).
+    The one-cell halo the neighbouring cube faces need (xgcm.py:7-34)."""
+    dev = _require_device(x)
+    x = x.contiguous()
+    if x.element_size() not in (4, 8):
+        raise TypeError(f"unsupported dtype {x.dtype}")
+    if x.dim() < 3 or x.shape[-1] != x.shape[-2]:
+        raise ValueError(f"cube faces must be square [tile, ..., n, n], got {tuple(x.shape)}")
+    n_tiles, n = int(x.shape[0]), int(x.shape[-1])
+    mid = tuple(x.shape[1:-2])
+    rows = torch.empty((n_tiles, 4) + mid + (n,), dtype=x.dtype, device=dev)
+    _lib.call("fv3hip_cube_edge_rows", _ptr(x), x.element_size(), n_tiles, _prod(mid), n, _ptr(rows), _stream(dev))
+    return rows
+
+
+def interp_center_to_outer(x: torch.Tensor, lo: torch.Tensor, hi: torch.Tensor, axis: int) -> torch.Tensor:
+    """``0.5 * (left + right)`` from cell centres to the n+1 cell edges along the last (``axis`` = 0,
+    x) or second-to-last (``axis`` = 1, y) dim; ``lo`` / ``hi`` [..., n_edge] hold the neighbours
+    beyond the two ends (regridz.py:123-135)."""
+    dev = _require_device(x)
+    code = _float_code(x)
+    x = x.contiguous()
+    lo = lo.to(dtype=x.dtype).contiguous()
+    hi = hi.to(dtype=x.dtype).contiguous()
+    ny, nx = int(x.shape[-2]), int(x.shape[-1])
+    want = tuple(x.shape[:-2]) + ((ny,) if axis == 0 else (nx,))
+    if tuple(lo.shape) != want or tuple(hi.shape) != want:
+        raise ValueError(f"halo shape must be {want}, got {tuple(lo.shape)} and {tuple(hi.shape)}")
+    out = torch.empty(tuple(x.shape[:-2]) + (ny + (axis == 1), nx + (axis == 0)), dtype=x.dtype, device=dev)
+    _lib.call("fv3hip_interp_center_to_outer", _ptr(x), code, _prod(x.shape[:-2]), ny, nx, int(axis),
+              _ptr(lo), _ptr(hi), _ptr(out), _stream(dev))
+    return out
+
+
 def pressure_at_interface(delp: torch.Tensor, toa_pressure: float, z_axis: int) -> torch.Tensor:
     """``p[0] = toa; p[k+1] = p[k] + delp[k]`` along ``z_axis`` (size nz -> nz + 1), accumulated
     sequentially in delp's dtype (vertically_dependent.py:41-66)."""

@@ -3,10 +3,13 @@
 Every unit of work on this path is independent -- a column for the MLP and the remap, an
 f x f block for the horizontal coarsening -- so ranks never exchange data while computing
 (the reference's MPI ranks are equally independent,
-workflows/prognostic_c48_run/runtime/steppers/machine_learning.py:176-181).  What this module
-provides is the partition (cube tiles / row bands / column ranges over ranks) and the optional
-gather of results to one consumer, on ``torch.distributed`` (backend ``nccl`` = RCCL over xGMI
-on the GPU box, ``gloo`` in CPU tests).
+workflows/prognostic_c48_run/runtime/steppers/machine_learning.py:176-181), with ONE exception:
+the pressure thickness interpolated to the cell edges for the D-grid winds needs the adjacent row
+of the neighbouring cube faces (regridz.py:123-135) -- a one-cell halo, exchanged here as an
+all-gather of every tile's four boundary vectors (C3072: 4 x 79 x 3072 floats = 3.9 MB per tile).
+Besides that this module provides the partition (cube tiles / row bands / column ranges over
+ranks) and the optional gather of results to one consumer, on ``torch.distributed`` (backend
+``nccl`` = RCCL over xGMI on the GPU box, ``gloo`` in CPU tests).
 """
 from typing import Dict, List, Sequence, Tuple
 
@@ -83,3 +86,40 @@ def predict_sharded(model, sources: Dict[str, torch.Tensor], gather: bool = Fals
     if not gather:
         return outs
     return {k: gather_columns(v, n, dst) for k, v in outs.items()}
+
+
+def tiles_of_rank(world_size: int, rank: int, n_tiles: int = 6) -> List[int]:
+    """Whole cube tiles owned by ``rank`` (contiguous, balanced; ranks beyond the tile count own none)."""
+    lo, hi = column_range(n_tiles, world_size, rank)
+    return list(range(lo, hi))
+
+
+def exchange_edge_rows(local_rows: torch.Tensor, n_tiles: int = 6) -> torch.Tensor:
+    """All-gather the boundary vectors of the tiles each rank owns (``local_rows``
+    [n_local, 4, ..., n], from ``ops.cube_edge_rows``; tiles dealt by :func:`tiles_of_rank`) into the
+    full [n_tiles, 4, ..., n] table every rank needs to pad its tiles.  The one exchange step of the
+    coarse-graining path; a no-op without ``torch.distributed``."""
+    rank, size = world()
+    if size == 1:
+        return local_rows
+    counts = [len(tiles_of_rank(size, r, n_tiles)) for r in range(size)]
+    width = max(counts)
+    if local_rows.shape[0] != counts[rank]:
+        raise ValueError(f"rank {rank} owns {counts[rank]} tiles, got rows for {local_rows.shape[0]}")
+    padded = torch.zeros((width,) + tuple(local_rows.shape[1:]), dtype=local_rows.dtype, device=local_rows.device)
+    padded[: counts[rank]] = local_rows
+    bufs = [torch.empty_like(padded) for _ in range(size)]
+    dist.all_gather(bufs, padded.contiguous())
+    return torch.cat([b[:c] for b, c in zip(bufs, counts)], dim=0)
+
+
+def interp_tiles_to_edges_sharded(local: torch.Tensor, axis: str, n_tiles: int = 6) -> torch.Tensor:
+    """``cubedsphere.grid.interp_tiles_to_edges`` for tile-sharded data: ``local`` [n_local, ..., n, n]
+    holds this rank's tiles (:func:`tiles_of_rank`); the halo rows come from one all-gather."""
+    from . import ops
+    from .cubedsphere.grid import halos_from_rows
+
+    rank, size = world()
+    rows = exchange_edge_rows(ops.cube_edge_rows(local), n_tiles)
+    lo, hi = halos_from_rows(rows, tiles_of_rank(size, rank, n_tiles), axis)
+    return ops.interp_center_to_outer(local, lo, hi, 0 if axis == "x" else 1)

@@ -131,6 +131,28 @@ int fv3hip_block_reduce(const void *in, int dtype, int64_t n_outer, int ny, int 
 int fv3hip_block_upsample(const void *in, int elem_size, int64_t n_outer, int ny_in, int nx_in,
                           int factor, void *out, void *stream);
 
+/*
+ * Cell centres -> cell edges across the faces of the cube: the device half of what
+ * xgcm.Grid.interp(delp, axis) does for vcm.cubedsphere.regridz.regrid_to_edge_weighted_pressure and
+ * coarsen_restarts.compute_edge_delp (external/vcm/vcm/cubedsphere/regridz.py:123-135,
+ * coarsen_restarts.py:825-853, connectivity table xgcm.py:7-34).
+ *
+ * fv3hip_cube_edge_rows: in [n_tiles][n_mid][n][n] -> rows [n_tiles][4][n_mid][n], the four
+ * boundary vectors of every (square) tile indexed along the edge: 0: x = 0, 1: x = n-1 (index = y),
+ * 2: y = 0, 3: y = n-1 (index = x).  These are what neighbouring tiles -- on this or another
+ * GPU -- need as their one-cell halo (the only exchange step of the coarse-graining path).
+ * elem_size is 4 or 8 bytes.
+ *
+ * fv3hip_interp_center_to_outer: out = 0.5 * (left + right) along axis (0 = x: [n_outer][ny][nx+1],
+ * 1 = y: [n_outer][ny+1][nx]); at the two ends the outside neighbour comes from lo / hi
+ * [n_outer][ny] (axis 0) or [n_outer][nx] (axis 1), already oriented along this tile's edge.
+ */
+int fv3hip_cube_edge_rows(const void *in, int elem_size, int n_tiles, int64_t n_mid, int n,
+                          void *rows, void *stream);
+int fv3hip_interp_center_to_outer(const void *in, int dtype, int64_t n_outer, int ny, int nx,
+                                  int axis, const void *lo, const void *hi, void *out,
+                                  void *stream);
+
 /* ------------------------------------------------------------------------------------------
  * Vertical: interface pressures and the PPM remap
  * ------------------------------------------------------------------------------------------ */

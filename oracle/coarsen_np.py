@@ -205,3 +205,67 @@ def regrid_to_area_weighted_pressure(fields, delp, area, toa_pressure, factor, m
     pfull = pressure_at_midpoint_log(delp_c_on_f, toa_pressure, z_axis) if extrapolate else None
     masked = mask_weights(area, phalf_c, phalf_f, z_axis, pfull, extrapolate)
     return out, masked
+
+
+# ---------------------------------------------------------------------------------------------
+# Cell centres -> cell edges across the cube, and the edge-weighted pressure-level regrid
+# ---------------------------------------------------------------------------------------------
+# external/vcm/vcm/cubedsphere/xgcm.py:7-34 (FV3_FACE_CONNECTIONS, data): for tile t and axis a,
+# ((left neighbour tile, its axis), (right neighbour tile, its axis)).
+FV3_FACE_CONNECTIONS = {
+    0: {"x": ((4, "y"), (1, "x")), "y": ((5, "y"), (2, "x"))},
+    1: {"x": ((0, "x"), (3, "y")), "y": ((5, "x"), (2, "y"))},
+    2: {"x": ((0, "y"), (3, "x")), "y": ((1, "y"), (4, "x"))},
+    3: {"x": ((2, "x"), (5, "y")), "y": ((1, "x"), (4, "y"))},
+    4: {"x": ((2, "y"), (5, "x")), "y": ((3, "y"), (0, "x"))},
+    5: {"x": ((4, "x"), (1, "y")), "y": ((3, "x"), (0, "y"))},
+}
+
+
+def interp_center_to_outer(a, axis):
+    """What ``xgcm.Grid.interp(da, axis)`` (xgcm 0.6.1, pinned in constraints.txt:316; not in the
+    reference tree) computes for a cell-centred [tile, z, y, x] array on the FV3 cube
+    (regridz.py:123-135): pad each tile with its neighbours' adjacent row -- the left neighbour's
+    LAST line along its connecting axis, the right neighbour's FIRST one; a neighbour connected
+    through its other axis contributes that line transposed and reversed -- then
+    ``0.5 * (left + right)``.  Pinned by the u / v arrays of the reference's pressure-level
+    regression fixtures (tests/test_oracle_coarsen.py), which touch all 12 cube edges."""
+    a = np.asarray(a)
+    outs = []
+    for t in range(6):
+        (ln, la), (rn, ra) = FV3_FACE_CONNECTIONS[t][axis]
+        if axis == "x":
+            left = a[ln][:, :, -1] if la == "x" else a[ln][:, -1, ::-1]
+            right = a[rn][:, :, 0] if ra == "x" else a[rn][:, 0, ::-1]
+            ext = np.concatenate([left[:, :, None], a[t], right[:, :, None]], axis=2)
+            outs.append(0.5 * (ext[:, :, :-1] + ext[:, :, 1:]))
+        else:
+            left = a[ln][:, -1, :] if la == "y" else a[ln][:, ::-1, -1]
+            right = a[rn][:, 0, :] if ra == "y" else a[rn][:, ::-1, 0]
+            ext = np.concatenate([left[:, None, :], a[t], right[:, None, :]], axis=1)
+            outs.append(0.5 * (ext[:, :-1, :] + ext[:, 1:, :]))
+    return np.stack(outs).astype(a.dtype)
+
+
+def regrid_to_edge_weighted_pressure(fields, delp, length, toa_pressure, factor, mappm_fn, edge="x",
+                                     extrapolate=False):
+    """regridz.py:81-146 + 149-197 for edge-valued fields [tile, z, y(+1), x(+1)] with edge
+    lengths ``length`` [tile, y(+1), x(+1)].  Returns (dict of regridded fields, masked lengths)."""
+    z_axis = 1
+    delp_staggered = interp_center_to_outer(delp, "x" if edge == "y" else "y")
+    delp_coarse = edge_weighted_block_average(delp_staggered, length[:, None], factor, edge)
+    delp_c_on_f = block_upsample(delp_coarse, factor)
+    phalf_c = pressure_at_interface(delp_c_on_f, toa_pressure, z_axis)
+    phalf_f = pressure_at_interface(delp_staggered, toa_pressure, z_axis)
+
+    def cols(a):
+        return np.moveaxis(a, z_axis, -1).reshape(-1, a.shape[z_axis])
+
+    out = {}
+    for name, f in fields.items():
+        r = mappm_fn(cols(phalf_f), cols(f), cols(phalf_c))
+        nt, _, ny, nx = f.shape
+        out[name] = np.moveaxis(r.reshape(nt, ny, nx, -1), -1, z_axis)
+    pfull = pressure_at_midpoint_log(delp_c_on_f, toa_pressure, z_axis) if extrapolate else None
+    masked = mask_weights(length, phalf_c, phalf_f, z_axis, pfull, extrapolate)
+    return out, masked

@@ -48,5 +48,7 @@ def plan(tag):
     if tag.startswith("pressure-level"):
         return {"area": {"fv_core.res": ["delp"], "fv_srf_wnd.res": ["u_srf", "v_srf"]},
                 "pressure": {"fv_core.res": ["W", "T", "ua", "va"], "fv_tracer.res": ["cld_amt"] + tracers},
+                # D-grid winds: delp interpolated to the cell edges across the cube's faces, then remapped
+                "pressure_edge_x": {"fv_core.res": ["u"]}, "pressure_edge_y": {"fv_core.res": ["v"]},
                 "extrapolate": "extrapolate" in tag}
     raise KeyError(tag)

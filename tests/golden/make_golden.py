@@ -88,12 +88,12 @@ COVERED = {
         "fv_srf_wnd.res": ["u_srf", "v_srf"],
     },
     "pressure-level-with-agrid-winds": {
-        "fv_core.res": ["delp", "W", "T", "ua", "va"],
+        "fv_core.res": ["delp", "W", "T", "ua", "va", "u", "v"],
         "fv_tracer.res": ["cld_amt", "sphum", "liq_wat", "rainwat", "ice_wat", "snowwat", "graupel", "o3mr", "sgs_tke"],
         "fv_srf_wnd.res": ["u_srf", "v_srf"],
     },
     "pressure-level-extrapolate-with-agrid-winds": {
-        "fv_core.res": ["delp", "W", "T"],
+        "fv_core.res": ["delp", "W", "T", "u", "v"],
         "fv_tracer.res": ["cld_amt", "sphum", "sgs_tke"],
     },
 }

@@ -53,3 +53,50 @@ def test_two_rank_column_sharding(tmp_path):
     ref = _FakeModel().predict({"a": a})
     np.testing.assert_array_equal(np.load(tmp_path / "y.npy"), ref["y"].numpy())
     np.testing.assert_array_equal(np.load(tmp_path / "s.npy"), ref["s"].numpy())
+
+
+def _halo_worker(rank, size, port, out_dir):
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=size)
+    from fv3net_amd import parallel
+    from fv3net_amd.cubedsphere.grid import halos_from_rows
+
+    rng = np.random.default_rng(5)
+    full = torch.from_numpy(rng.uniform(300, 1500, (6, 3, 8, 8)).astype(np.float32))  # same on every rank
+    mine = parallel.tiles_of_rank(size, rank)
+    local = full[mine]
+    # the boundary vectors as ops.cube_edge_rows lays them out (that kernel needs a GPU; the exchange does not)
+    rows = torch.stack([local[..., :, 0], local[..., :, -1], local[..., 0, :], local[..., -1, :]], dim=1)
+    table = parallel.exchange_edge_rows(rows)
+    assert table.shape == (6, 4, 3, 8)
+    for axis in ("x", "y"):
+        lo, hi = halos_from_rows(table, mine, axis)
+        np.save(os.path.join(out_dir, f"lo_{axis}_{rank}.npy"), lo.numpy())
+        np.save(os.path.join(out_dir, f"hi_{axis}_{rank}.npy"), hi.numpy())
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_two_rank_cube_halo_exchange(tmp_path):
+    """Tiles 0-2 on rank 0, 3-5 on rank 1: after the one all-gather every rank pads its tiles
+    exactly as the oracle (pinned by the reference's pressure-level u / v fixtures) does."""
+    from fv3net_amd import parallel
+    from oracle import coarsen_np as onp
+
+    mp.spawn(_halo_worker, args=(2, _free_port(), str(tmp_path)), nprocs=2, join=True)
+    rng = np.random.default_rng(5)
+    full = rng.uniform(300, 1500, (6, 3, 8, 8)).astype(np.float32)
+    for axis in ("x", "y"):
+        ref = onp.interp_center_to_outer(full, axis)  # 0.5 * (neighbour + first/last cell) at the two ends
+        for rank in range(2):
+            mine = parallel.tiles_of_rank(2, rank)
+            lo = np.load(tmp_path / f"lo_{axis}_{rank}.npy")
+            hi = np.load(tmp_path / f"hi_{axis}_{rank}.npy")
+            for i, t in enumerate(mine):
+                first = full[t][:, :, 0] if axis == "x" else full[t][:, 0, :]
+                last = full[t][:, :, -1] if axis == "x" else full[t][:, -1, :]
+                edge0 = ref[t][:, :, 0] if axis == "x" else ref[t][:, 0, :]
+                edge1 = ref[t][:, :, -1] if axis == "x" else ref[t][:, -1, :]
+                np.testing.assert_array_equal(np.float32(0.5) * (lo[i] + first), edge0)
+                np.testing.assert_array_equal(np.float32(0.5) * (last + hi[i]), edge1)

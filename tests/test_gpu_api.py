@@ -182,7 +182,8 @@ def test_coarsen_restarts_regression_fixtures(tag):
     (external/vcm/tests/test_coarsen_restarts.py:108-127), driven through the drop-in API: inputs
     regenerated by the reference's seed rule, outputs compared with the reference's own fixture
     values at xr.testing.assert_allclose's defaults."""
-    from fv3net_amd.cubedsphere import edge_weighted_block_average, regrid_to_area_weighted_pressure, weighted_block_average
+    from fv3net_amd.cubedsphere import (edge_weighted_block_average, regrid_to_area_weighted_pressure,
+                                        regrid_to_edge_weighted_pressure, weighted_block_average)
 
     meta, expected = cases.load()
     inp = cases.inputs(meta)
@@ -229,6 +230,17 @@ def test_coarsen_restarts_regression_fixtures(tag):
                                                                   y_dim=ydim, extrapolate=plan["extrapolate"])
         res = weighted_block_average(regridded, masked_area, f, x_dim="xaxis_1", y_dim=ydim)
         got.update({(category, v): res[v] for v in variables})
+    # D-grid winds on pressure levels (coarsen_restarts.py:497-519,541-557): u with dx along x edges, v with dy
+    for key, length, xdim, ydim, edge in (("pressure_edge_x", "dx", "xaxis_1", "yaxis_1", "x"),
+                                          ("pressure_edge_y", "dy", "xaxis_2", "yaxis_2", "y")):
+        for category, variables in plan.get(key, {}).items():
+            ds = Dataset({v: da(category, v) for v in variables})
+            spacing = grid(length, ydim, xdim)
+            regridded, masked = regrid_to_edge_weighted_pressure(ds, delp_core, spacing, meta["toa_pressure"], f,
+                                                                 x_dim=xdim, y_dim=ydim, edge=edge,
+                                                                 extrapolate=plan["extrapolate"])
+            res = edge_weighted_block_average(regridded, masked, f, x_dim=xdim, y_dim=ydim, edge=edge)
+            got.update({(category, v): res[v] for v in variables})
 
     checked = 0
     for key, (entry, want) in expected.items():
@@ -238,8 +250,8 @@ def test_coarsen_restarts_regression_fixtures(tag):
         res = got[(entry["category"], entry["variable"])].transpose(*dims).values
         assert res.shape == want.shape, key
         assert np.array_equal(np.isnan(res), np.isnan(want)), key
-        if "pressure" in plan and (entry["category"], entry["variable"]) in got and any(
-                entry["variable"] in v for v in plan["pressure"].values()):
+        remapped = [v for k in ("pressure", "pressure_edge_x", "pressure_edge_y") for v in plan.get(k, {}).values()]
+        if remapped and any(entry["variable"] in v for v in remapped):
             # Remapped fields: the interface pressures are rounded to float32 inside mappm, and one
             # float32 ulp of a layer edge moves a layer mean by ~1e-5 x (field contrast / layer
             # thickness in ulps).  The reference itself notes mappm is not reproducible across

@@ -213,3 +213,41 @@ def test_full_size_c384_properties(device):
     lhs = (a.double() * wsum[:, None].double()).sum(dim=(-1, -2))
     rhs = (obj.double() * area[:, None].double()).sum(dim=(-1, -2))
     assert torch.allclose(lhs, rhs, rtol=1e-5, atol=1.0)
+
+
+@pytest.mark.parametrize("axis", ["x", "y"])
+@pytest.mark.parametrize("dt", [np.float32, np.float64])
+def test_cube_interp_center_to_outer_matches_oracle(device, axis, dt):
+    """delp at the cell edges across the cube's faces (regridz.py:123-135, xgcm.py:7-34): the halo
+    rows come from the neighbouring tiles through the connectivity table, reversed where the
+    connection swaps axes.  The oracle is pinned by the reference's pressure-level u / v fixtures."""
+    from fv3net_amd import ops
+    from fv3net_amd.cubedsphere.grid import halos_from_rows, interp_tiles_to_edges
+
+    rng = np.random.default_rng(11)
+    a = rng.uniform(300, 1500, (6, 5, 12, 12)).astype(dt)
+    res = ops.as_numpy(interp_tiles_to_edges(_dev(a, device), axis))
+    ref = onp.interp_center_to_outer(a, axis)
+    assert res.shape == ref.shape and res.dtype == ref.dtype
+    np.testing.assert_array_equal(res, ref)  # 0.5 * (a + b): the same two roundings in the same order
+    # the boundary vectors themselves (what a sharded run exchanges)
+    rows = ops.as_numpy(ops.cube_edge_rows(_dev(a, device)))
+    np.testing.assert_array_equal(rows[:, 0], a[..., :, 0])
+    np.testing.assert_array_equal(rows[:, 1], a[..., :, -1])
+    np.testing.assert_array_equal(rows[:, 2], a[..., 0, :])
+    np.testing.assert_array_equal(rows[:, 3], a[..., -1, :])
+    lo, hi = halos_from_rows(torch.from_numpy(rows), [2, 5], axis)
+    assert lo.shape == (2, 5, 12) and hi.shape == (2, 5, 12)
+
+
+def test_cube_interp_rejects_bad_shapes(device):
+    from fv3net_amd import ops
+    from fv3net_amd.cubedsphere.grid import interp_tiles_to_edges
+
+    with pytest.raises(ValueError):
+        interp_tiles_to_edges(torch.zeros(5, 3, 4, 4, device=device), "x")   # not six tiles
+    with pytest.raises(ValueError):
+        ops.cube_edge_rows(torch.zeros(6, 3, 4, 5, device=device))            # faces must be square
+    with pytest.raises(ValueError):
+        ops.interp_center_to_outer(torch.zeros(6, 3, 4, 4, device=device), torch.zeros(6, 3, 5, device=device),
+                                   torch.zeros(6, 3, 4, device=device), 0)
