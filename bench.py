@@ -125,6 +125,19 @@ def zc_inputs_device(dev, n, seed):
     }
 
 
+def pmc_traffic(kernel_key):
+    """HBM bytes per launch from the committed PMC passes (profiles/r01_pmc_traffic.json: rocprofv3
+    --pmc FETCH_SIZE / WRITE_SIZE in separate runs of this script, FETCH_SIZE corrected as
+    MI355X_MICROARCH.md prescribes for gfx950) -- a recorded measurement of the same launch, not
+    collected live; None where the counters are uncalibrated or the file is absent."""
+    path = os.path.join(os.path.dirname(os.path.abspath(__file__)), "profiles", "r01_pmc_traffic.json")
+    try:
+        with open(path) as f:
+            return json.load(f)["kernels"][kernel_key]["traffic_bytes_per_launch"]
+    except (OSError, KeyError, ValueError):
+        return None
+
+
 def cpu_baseline(spec, budget_s=15.0):
     """The oracle (numpy float32, [sample, feature]) on a bounded sample of the same workload."""
     from oracle import mlp_np
@@ -185,7 +198,8 @@ def secondary_benchmarks(dev, steps):
             out.append({
                 "kernel": "weighted_block_average", "workload": f"{label} f=8, one [6,79,{n},{n}] f32 field, 2-D area weights",
                 "ms": ms, "roofline": {"bound": "hbm", "achieved": alg_bytes / ms / 1e6, "peak": PEAK_HBM_GBPS,
-                                       "unit": "GB/s", "frac": alg_bytes / ms / 1e6 / PEAK_HBM_GBPS, "traffic": None},
+                                       "unit": "GB/s", "frac": alg_bytes / ms / 1e6 / PEAK_HBM_GBPS,
+                                       "traffic": pmc_traffic("wavg_block_kernel<float,float,8> C3072->C384") if n == 3072 else None},
             })
             del obj, area
         except torch.cuda.OutOfMemoryError:
@@ -300,7 +314,7 @@ def main():
                 "peak": PEAK_FP32_MFMA_TFLOPS,
                 "unit": "TFLOP/s",
                 "frac": achieved / PEAK_FP32_MFMA_TFLOPS,
-                "traffic": None,
+                "traffic": pmc_traffic("mlp_fused_kernel<8,false,true>"),
                 "kernel": "mlp_fused_kernel<8,false,true>",
                 "kernel_ms": kernel_ms,
             },
