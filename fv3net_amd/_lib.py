@@ -94,6 +94,19 @@ SIGNATURES = {
         [c_void_p, c_int, c_int64, c_int, c_int, c_int, c_int, c_int, c_int, c_int, c_int, c_void_p, c_void_p],
     ),
     "fv3hip_block_upsample": (c_int, [c_void_p, c_int, c_int64, c_int, c_int, c_int, c_void_p, c_void_p]),
+    "fv3hip_zc_squash": (c_int, [c_void_p, c_int, c_void_p, c_int, c_int64, c_double, c_int, c_void_p, c_void_p, c_void_p]),
+    "fv3hip_zc_infer_cloud": (c_int, [c_void_p, c_void_p, c_int, c_void_p, c_int, c_int64, c_int, c_void_p, c_void_p]),
+    "fv3hip_zc_gscond_conserve": (c_int, [c_void_p, c_void_p, c_void_p, c_int, c_void_p, c_int, c_int, c_void_p, c_int,
+                                          c_int, c_int, c_int64, c_int64, c_int, c_int, c_void_p, c_void_p, c_void_p,
+                                          c_void_p]),
+    "fv3hip_zc_precpd_conserve": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_void_p, c_void_p, c_int,
+                                          c_int64, c_int64, c_int, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p]),
+    "fv3hip_zc_precip_simple": (c_int, [c_void_p, c_void_p, c_void_p, c_int, c_void_p, c_void_p, c_int, c_int64, c_int64,
+                                        c_int, c_void_p, c_void_p]),
+    "fv3hip_zc_class_zero": (c_int, [c_void_p, c_int, c_void_p, c_int, c_int, c_int, c_int64, c_void_p, c_void_p]),
+    "fv3hip_clamp": (c_int, [c_void_p, c_int, c_int64, c_double, c_double, c_int, c_int, c_void_p, c_void_p]),
+    "fv3hip_level_fill": (c_int, [c_void_p, c_int, c_void_p, c_int, c_double, c_int64, c_int64, c_int64, c_int64, c_void_p,
+                                  c_void_p]),
     "fv3hip_cube_edge_rows": (c_int, [c_void_p, c_int, c_int, c_int64, c_int, c_void_p, c_void_p]),
     "fv3hip_interp_center_to_outer": (c_int, [c_void_p, c_int, c_int64, c_int, c_int, c_int, c_void_p, c_void_p,
                                               c_void_p, c_void_p]),

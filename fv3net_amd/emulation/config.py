@@ -1,25 +1,41 @@
-"""Configuration of the online hooks (external/emulation/emulation/config.py:120-324), reduced
-to what the hot path implements: a regressor at ``path`` in the ``HipEmulator`` format.  The
-reference's post-processing options (range / level masks, Zhao-Carr conservation fixes, the
-classifier, the zarr monitor) are not implemented yet and are rejected loudly rather than
+"""Configuration of the online hooks (external/emulation/emulation/config.py:120-324): a regressor
+at ``path`` in the ``HipEmulator`` format plus the reference's post-processing options -- range and
+level masks, cloud squashing and the Zhao-Carr conservation fixes -- composed in the reference's
+order (config.py:175-221) and run on the device.  The classifier model, tensor transforms, the
+online schedule and the zarr monitor are not part of this build and are rejected loudly rather than
 silently ignored."""
 import dataclasses
 import logging
-from typing import Optional
+from typing import Dict, Iterable, Mapping, Optional
 
 import yaml
 
+from . import zhao_carr
 from .hook import MicrophysicsHook
+from .masks import LevelMask, Mask, RangeMask, compose_masks
 from .models import HipEmulator
 
 logger = logging.getLogger("emulation")
 
-_UNIMPLEMENTED = (
-    "classifier_path", "tensor_transform", "ranges", "mask_emulator_levels", "cloud_squash", "gscond_cloud_conservative",
-    "mask_gscond_identical_cloud", "mask_gscond_zero_cloud", "enforce_conservative", "enforce_conservative_phase_dependent",
-    "mask_gscond_zero_cloud_classifier", "mask_gscond_no_tend_classifier", "mask_precpd_zero_cloud_classifier",
-    "enforce_strict_precpd_conservative", "simple_precip_conservative", "online_schedule",
+_UNIMPLEMENTED = ("classifier_path", "tensor_transform", "online_schedule")
+_FLAGS = (
+    "gscond_cloud_conservative", "mask_gscond_identical_cloud", "mask_gscond_zero_cloud", "enforce_conservative",
+    "enforce_conservative_phase_dependent", "mask_gscond_zero_cloud_classifier", "mask_gscond_no_tend_classifier",
+    "mask_precpd_zero_cloud_classifier", "enforce_strict_precpd_conservative", "simple_precip_conservative",
 )
+
+
+@dataclasses.dataclass
+class Range:
+    min: Optional[float] = None
+    max: Optional[float] = None
+
+
+@dataclasses.dataclass
+class LevelSlice:
+    start: Optional[int] = None
+    stop: Optional[int] = None
+    fill_value: Optional[object] = None
 
 
 def do_nothing(state):
@@ -29,20 +45,46 @@ def do_nothing(state):
 @dataclasses.dataclass
 class ModelConfig:
     """``path``: directory holding ``spec.yaml`` + ``weights.npz``.  ``batch_size`` is accepted for
-    compatibility and ignored: the fused kernel takes all columns of a call at once."""
+    compatibility and ignored: the fused kernel takes all columns of a call at once.  The other
+    attributes are the reference's (config.py:62-136)."""
 
     path: Optional[str] = None
+    ranges: Mapping[str, Range] = dataclasses.field(default_factory=dict)
+    mask_emulator_levels: Mapping[str, LevelSlice] = dataclasses.field(default_factory=dict)
+    cloud_squash: Optional[float] = None
+    gscond_cloud_conservative: bool = False
+    mask_gscond_identical_cloud: bool = False
+    mask_gscond_zero_cloud: bool = False
+    enforce_conservative: bool = False
+    enforce_conservative_phase_dependent: bool = False
+    mask_gscond_zero_cloud_classifier: bool = False
+    mask_gscond_no_tend_classifier: bool = False
+    mask_precpd_zero_cloud_classifier: bool = False
+    enforce_strict_precpd_conservative: bool = False
+    simple_precip_conservative: bool = False
     batch_size: int = 512
+
+    def __post_init__(self):
+        if self.enforce_conservative and self.enforce_conservative_phase_dependent:
+            raise ValueError("These options are mutually exclusive.")
+        if self.enforce_strict_precpd_conservative and self.simple_precip_conservative:
+            raise ValueError("Conservative precip flags should not both be true.")
 
     @staticmethod
     def from_dict(d: dict) -> "ModelConfig":
         bad = [k for k in d if k in _UNIMPLEMENTED and d[k] not in (None, False, {}, [])]
         if bad:
             raise NotImplementedError(f"zhao_carr_emulation options not implemented on the device yet: {bad}")
-        unknown = [k for k in d if k not in ("path", "batch_size") and k not in _UNIMPLEMENTED]
+        known = {f.name for f in dataclasses.fields(ModelConfig)} | set(_UNIMPLEMENTED)
+        unknown = [k for k in d if k not in known]
         if unknown:
             raise ValueError(f"unknown ModelConfig keys: {unknown}")
-        return ModelConfig(path=d.get("path"), batch_size=int(d.get("batch_size", 512)))
+        kwargs: Dict[str, object] = {k: bool(d[k]) for k in _FLAGS if k in d}
+        if d.get("cloud_squash") is not None:
+            kwargs["cloud_squash"] = float(d["cloud_squash"])
+        kwargs["ranges"] = {k: Range(**v) for k, v in (d.get("ranges") or {}).items()}
+        kwargs["mask_emulator_levels"] = {k: LevelSlice(**v) for k, v in (d.get("mask_emulator_levels") or {}).items()}
+        return ModelConfig(path=d.get("path"), batch_size=int(d.get("batch_size", 512)), **kwargs)
 
     def build(self) -> MicrophysicsHook:
         if self.path:
@@ -50,7 +92,40 @@ class ModelConfig:
         else:
             def model(x):
                 return x
-        return MicrophysicsHook(model=model)
+        return MicrophysicsHook(model=model, mask=self._build_mask())
+
+    def _build_mask(self) -> Mask:
+        return compose_masks(self._build_masks())
+
+    def _build_masks(self) -> Iterable[Mask]:
+        """The reference's order (config.py:178-221)."""
+        for key, rng in self.ranges.items():
+            yield RangeMask(key, min=rng.min, max=rng.max)
+        if self.gscond_cloud_conservative:
+            yield zhao_carr.infer_gscond_cloud_from_conservation
+        if self.cloud_squash is not None:
+            yield lambda x, y: zhao_carr.squash_gscond(x, y, self.cloud_squash)
+            yield lambda x, y: zhao_carr.squash_precpd(x, y, self.cloud_squash)
+        if self.mask_gscond_identical_cloud:
+            yield zhao_carr.mask_where_fortran_cloud_identical
+        if self.mask_gscond_zero_cloud:
+            yield zhao_carr.mask_where_fortran_cloud_vanishes_gscond
+        if self.mask_gscond_no_tend_classifier:
+            yield zhao_carr.mask_zero_tend_classifier
+        if self.mask_gscond_zero_cloud_classifier:
+            yield zhao_carr.mask_zero_cloud_classifier
+        if self.mask_precpd_zero_cloud_classifier:
+            yield zhao_carr.mask_zero_cloud_classifier_precpd
+        if self.enforce_conservative:
+            yield zhao_carr.enforce_conservative_gscond
+        elif self.enforce_conservative_phase_dependent:
+            yield zhao_carr.enforce_conservative_phase_dependent
+        if self.simple_precip_conservative:
+            yield zhao_carr.conservative_precip_simple
+        elif self.enforce_strict_precpd_conservative:
+            yield zhao_carr.enforce_conservative_precpd
+        for key, sl in self.mask_emulator_levels.items():
+            yield LevelMask(key, start=sl.start, stop=sl.stop, fill_value=sl.fill_value)
 
 
 @dataclasses.dataclass

@@ -296,6 +296,61 @@ int fv3hip_timer_stop(fv3hip_timer_t t, void *stream);
 int fv3hip_timer_elapsed_ms(fv3hip_timer_t t, float *ms); /* synchronises on the stop event */
 int fv3hip_timer_destroy(fv3hip_timer_t t);
 
+/* ------------------------------------------------------------------------------------------
+ * Zhao-Carr emulator post-processing (masks and conservation fixes on the emulator outputs)
+ * ------------------------------------------------------------------------------------------
+ * Replace the numpy / numba functions of external/emulation/emulation/masks.py:23-76 and
+ * external/emulation/emulation/zhao_carr.py:60-344 that ModelConfig._build_masks composes
+ * (external/emulation/emulation/config.py:175-221).  Arrays are contiguous [n0][n1] = [level][sample]
+ * (the Fortran hook's layout) or flat (n); every array carries a dtype code (FV3HIP_F32/F64);
+ * arithmetic and outputs use out_dtype = F64 if any operand is float64 (numpy's promotion), else F32.
+ */
+#define FV3HIP_ZC_NO_MASK 0            /* enforce_conservative_*: the emulator's cloud as is          */
+#define FV3HIP_ZC_FORTRAN_VANISHES 1   /* mask_where_fortran_cloud_vanishes_gscond: aux = state cloud after gscond */
+#define FV3HIP_ZC_FORTRAN_IDENTICAL 2  /* mask_where_fortran_cloud_identical: aux = state cloud after gscond       */
+#define FV3HIP_ZC_CLASS_ZERO_CLOUD 3   /* mask_zero_cloud_classifier: aux = logits [n_class][n0][n1]               */
+#define FV3HIP_ZC_CLASS_ZERO_TEND 4    /* mask_zero_tend_classifier:  aux = logits [n_class][n0][n1]               */
+
+/* squash_gscond / squash_precpd (zhao_carr.py:60-86): cloud < bound -> 0, the removed water goes to qv.
+ * cloud_out keeps cloud's dtype; qv_out has out_dtype. */
+int fv3hip_zc_squash(const void *cloud, int cloud_dtype, const void *humidity, int hum_dtype,
+                     int64_t n, double bound, int out_dtype, void *cloud_out, void *qv_out,
+                     void *stream);
+/* infer_gscond_cloud_from_conservation (zhao_carr.py:80-84). */
+int fv3hip_zc_infer_cloud(const void *cloud_in, const void *qv_in, int state_dtype,
+                          const void *qv_emul, int emul_dtype, int64_t n, int out_dtype,
+                          void *cloud_out, void *stream);
+/* The gscond masks + _update_with_net_condensation (zhao_carr.py:97-246): choose the cloud (mode),
+ * limit the net condensation by the available vapour / liquid, apply it with the liquid latent heat
+ * or (phase_dependent) the ice/water-flag scan along the last axis (zhao_carr.py:114-151). */
+int fv3hip_zc_gscond_conserve(const void *cloud_in, const void *qv_in, const void *t_in,
+                              int state_dtype, const void *cloud_emul, int emul_dtype, int mode,
+                              const void *aux, int aux_dtype, int n_class, int cls, int64_t n0,
+                              int64_t n1, int phase_dependent, int out_dtype, void *cloud_out,
+                              void *qv_out, void *t_out, void *stream);
+/* enforce_conservative_precpd (zhao_carr.py:249-323): strict TOA (last level) to surface budget. */
+int fv3hip_zc_precpd_conserve(const void *cloud_g, const void *qv_g, const void *t_g,
+                              const void *delp, int state_dtype, const void *cloud_p,
+                              const void *qv_p, int emul_dtype, int64_t n0, int64_t n1,
+                              int out_dtype, void *cloud_out, void *qv_out, void *t_out,
+                              void *precip_out, void *stream);
+/* conservative_precip_simple (zhao_carr.py:326-344): precip[n1] from the column water budget. */
+int fv3hip_zc_precip_simple(const void *cloud_g, const void *qv_g, const void *delp,
+                            int state_dtype, const void *cloud_p, const void *qv_p,
+                            int emul_dtype, int64_t n0, int64_t n1, int out_dtype,
+                            void *precip_out, void *stream);
+/* mask_zero_cloud_classifier_precpd (zhao_carr.py:230-237): x -> 0 where class `cls` is hot. */
+int fv3hip_zc_class_zero(const void *x, int dtype, const void *logits, int logits_dtype,
+                         int n_class, int cls, int64_t n, void *out, void *stream);
+/* RangeMask (masks.py:23-41): np.maximum(x, lo) / np.minimum(x, hi), NaN-propagating. */
+int fv3hip_clamp(const void *x, int dtype, int64_t n, double lo, double hi, int has_lo,
+                 int has_hi, void *out, void *stream);
+/* LevelMask (masks.py:44-76): float64 copy of the emulator field with levels [start, stop) taken from
+ * src (or fill_value when src is NULL). */
+int fv3hip_level_fill(const void *emul, int emul_dtype, const void *src, int src_dtype,
+                      double fill_value, int64_t n0, int64_t n1, int64_t start, int64_t stop,
+                      void *out, void *stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -165,8 +165,15 @@ def test_emulation_config(tmp_path):
     gscond, micro, store = get_hooks(str(tmp_path / "missing.yml"))
     state = {"a": np.zeros(3)}
     assert micro(state) is None and gscond(state) is None and store(state) is None and list(state) == ["a"]
-    with pytest.raises(NotImplementedError, match="cloud_squash"):
-        EmulationConfig.from_dict({"model": {"path": "x", "cloud_squash": 1e-6}})
+    with pytest.raises(NotImplementedError, match="classifier_path"):
+        EmulationConfig.from_dict({"model": {"path": "x", "classifier_path": "y"}})
+    cfg = EmulationConfig.from_dict({"model": {"path": "x", "cloud_squash": 1e-6, "enforce_conservative": True,
+                                               "ranges": {"total_precipitation": {"min": 0}},
+                                               "mask_emulator_levels": {"air_temperature_after_precpd": {"start": 74}}}})
+    # the reference's composition order (config.py:178-221): range, squash x2, conservation, level mask
+    assert len(list(cfg.model._build_masks())) == 5
+    with pytest.raises(ValueError, match="mutually exclusive"):
+        EmulationConfig.from_dict({"model": {"enforce_conservative": True, "enforce_conservative_phase_dependent": True}})
     with pytest.raises(ValueError, match="unknown"):
         EmulationConfig.from_dict({"model": {"pth": "x"}})
 
