@@ -296,7 +296,6 @@ __global__ __launch_bounds__(kThreads, 1) void mlp_fused_kernel(const MlpLaunch 
     f32x4 stage[NVH];
     // Buffer loads: the stream's base sits in an SGPR resource descriptor, the chunk offset in an
     // SGPR and the per-thread offset in one loop-invariant VGPR -- no per-load VALU address math.
-    typedef int i32x4 __attribute__((ext_vector_type(4)));
     const __amdgpu_buffer_rsrc_t w_rsrc =
         __builtin_amdgcn_make_buffer_rsrc(const_cast<f32x4 *>(p.w), 0, p.w_bytes, 0x00020000);
     const unsigned int w_voff = (unsigned int)tid * 16u;
@@ -306,19 +305,13 @@ __global__ __launch_bounds__(kThreads, 1) void mlp_fused_kernel(const MlpLaunch 
     // (for a chunk type with fewer than 2*NVH float4s per thread the second half reads on into the
     // stream -- the host pads it by one maximal chunk -- and lands in LDS words nobody reads)
     auto issue_w = [&](int g, int part) {  // global -> registers
-#ifndef MLP_ABLATE_WLOAD
         const int base = (chunk_off(g) + part * NVH * kThreads) * 16;
 #pragma unroll
         for (int i = 0; i < NVH; ++i)
             stage[i] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(w_rsrc, w_voff, base + i * kThreads * 16, 0));
-#endif
     };
     auto commit_w1 = [&](int buf, int part, int i) {  // one staged float4 -> the other LDS buffer
-#ifndef MLP_ABLATE_WCOMMIT
         if (i < NVH) wbuf[buf * CH_MAX + tid + (part * NVH + i) * kThreads] = stage[i];
-#else
-        if (i < NVH) asm volatile("" ::"v"(stage[i]));
-#endif
     };
     // slot s of a chunk of KC slots: its share of staging chunk `gnext` into buffer `buf`.  The last
     // slot stages nothing: it opens with the chunk barrier (see run_slot).
@@ -380,8 +373,6 @@ __global__ __launch_bounds__(kThreads, 1) void mlp_fused_kernel(const MlpLaunch 
     // ---- layer-1 B operand helpers ----
     using Raw = typename std::conditional<SRC64, double, float>::type;
     typedef const Raw __attribute__((address_space(1))) *GRawPtr;
-    typedef float __attribute__((address_space(1))) *GF32Ptr;
-    typedef double __attribute__((address_space(1))) *GF64Ptr;
     Raw xraw[KC_H];
     float xcur[KC_H];
     // one element (k-pair s of a layer-1 chunk): raw load / transform + normalise, both branch-free
@@ -480,14 +471,8 @@ __global__ __launch_bounds__(kThreads, 1) void mlp_fused_kernel(const MlpLaunch 
             for (int q = 0; q < 4; ++q)
                 v[q] = __builtin_amdgcn_logf(v[q] < e.eps ? e.eps : v[q]) * 0.693147180559945f;
         }
-#ifndef MLP_ABLATE_FMATH
         v = v - e.center;  // (1 / std lives in the layer-1 weights)
-#endif
-#ifndef MLP_ABLATE_FWRITE
         *reinterpret_cast<f32x4 *>(xs + (buf * 32 + kk) * kTileSamples + 4 * sg) = v;
-#else
-        asm volatile("" ::"v"(v));
-#endif
     };
     auto bulk_finish1 = [&](int c, int i, int buf, auto with_log) {
         bulk_finish_e(xn_tab[c * 32 + fr + 8 * i], i, buf, with_log);
@@ -610,7 +595,6 @@ __global__ __launch_bounds__(kThreads, 1) void mlp_fused_kernel(const MlpLaunch 
                         // (the last slot runs this after the chunk barrier: xs[xb ^ 1] is complete)
                         b_cur = (s_ + 1 < KC_H) ? xsb[2 * (s_ + 1) * kTileSamples] : xsn[0];
                         // table entries are read a slot before they are used
-#ifndef MLP_ABLATE_BISSUE
                         if (s_ == 0) {
 #pragma unroll
                             for (int i = 0; i < 4; ++i) xa4[i] = xa_g[8 * i];
@@ -619,14 +603,11 @@ __global__ __launch_bounds__(kThreads, 1) void mlp_fused_kernel(const MlpLaunch 
 #pragma unroll
                             for (int i = 0; i < 4; ++i) bulk_issue1(xa4[i], i, nb);
                         }
-#endif
-#ifndef MLP_ABLATE_BFINISH
                         if (s_ == KC_H / 2) {
 #pragma unroll
                             for (int i = 0; i < 4; ++i) xn4[i] = xn_g[8 * i];
                         }
                         if (s_ > KC_H / 2 && s_ <= KC_H / 2 + 4) bulk_finish_e(xn4[s_ - KC_H / 2 - 1], s_ - KC_H / 2 - 1, xb ^ 1, with_log);
-#endif
                         stage_step(s_, KC_H, gnext, par ^ 1);
                     });
                 }
