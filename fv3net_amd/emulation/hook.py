@@ -34,7 +34,22 @@ class MicrophysicsHook:
     def microphysics(self, state: FortranState) -> None:
         """Hook called from Fortran through call_py_fort.  ``state`` holds ``[feature, sample]``
         (or ``[sample]``) arrays plus scalar entries; it is updated in place with the
-        emulator's ``[feature, sample]`` outputs."""
+        emulator's ``[feature, sample]`` outputs.
+
+        With a device-resident model (``HipEmulator``) the state is uploaded once, the network and
+        every mask run on the device, and only the final outputs come back: one PCIe round trip per
+        call instead of one per mask."""
+        if getattr(self.model, "device_resident", False):
+            from ..cubedsphere._device import on_device
+
+            dev_state = {name: on_device(v) if isinstance(v, np.ndarray) else v for name, v in state.items()}
+            inputs = {name: v.t() if v.dim() == 2 else v for name, v in dev_state.items() if hasattr(v, "dim")}
+            predictions = self.model(inputs)
+            model_outputs = {name: (t.t() if t.dim() == 2 else t) for name, t in predictions.items()}
+            model_outputs.update(self.mask(dev_state, model_outputs))
+            state.update({name: (t.cpu().numpy() if hasattr(t, "cpu") else t) for name, t in model_outputs.items()})
+            self._maybe_garbage_collect()
+            return
         inputs = {name: state[name].T for name in state if hasattr(state[name], "T")}
         predictions = self.model(inputs)
         # transpose back to FV3 conventions

@@ -23,6 +23,7 @@ class HipEmulator:
     like the reference's model adapters.  Entries the network does not read (``rank``,
     ``model_time``, unused fields) are ignored."""
 
+    device_resident = True  # MicrophysicsHook keeps the state and the masks on the device around this model
     _SPEC_FILENAME = "spec.yaml"
     _WEIGHTS_FILENAME = "weights.npz"
 

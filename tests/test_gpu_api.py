@@ -422,3 +422,42 @@ def test_microphysics_hook_with_hip_emulator(tmp_path):
         assert got.shape == (want.shape[1], n) and got.flags.c_contiguous  # [feature, sample]
         assert np.max(np.abs(got.T - want)) <= 1e-5 * np.max(np.abs(want)), name
     assert state["rank"] == 3
+
+
+def test_microphysics_hook_keeps_masks_on_the_device(tmp_path):
+    """Network + configured post-processing in one device-resident pass (config.py:137-221): the
+    result equals the oracle network followed by the oracle masks."""
+    import bench
+    from fv3net_amd.emulation import HipEmulator
+    from fv3net_amd.emulation.config import ModelConfig
+    from oracle import emulation_np as E
+
+    from fv3net_amd.mlp import ResidualSpec
+
+    spec = bench.zc_spec(0)
+    # air_temperature_after_precpd = air_temperature_input + temperature_precpd_difference, fused in the kernel
+    spec.residuals = [ResidualSpec("air_temperature_after_precpd", "air_temperature_input", "temperature_precpd_difference")]
+    HipEmulator(spec).dump(str(tmp_path / "emu"))
+    n = 640
+    src_sf = bench.zc_inputs_numpy(np.random.default_rng(7), n)
+    state = {k: np.ascontiguousarray(v.T.astype(np.float64)) for k, v in src_sf.items()}
+    # the Fortran scheme's own answers, which the level mask falls back to
+    state["air_temperature_after_precpd"] = state["air_temperature_input"] + 0.25
+    cfg = ModelConfig.from_dict({
+        "path": str(tmp_path / "emu"),
+        "ranges": {"total_precipitation": {"min": 0.0}},
+        "mask_emulator_levels": {"air_temperature_after_precpd": {"start": 74, "stop": None}},
+    })
+    hook = cfg.build()
+    fortran = {k: (v.copy() if isinstance(v, np.ndarray) else v) for k, v in state.items()}
+    assert hook.microphysics(state) is None
+    truth = mlp_np.forward(spec, {k: v.astype(np.float64) for k, v in src_sf.items()}, dtype=np.float64)
+    want = {k: v.T for k, v in truth.items()}
+    want = E.range_mask(want, "total_precipitation", 0.0, None)
+    want = E.level_mask(fortran, want, "air_temperature_after_precpd", 74, None)
+    for name, ref in want.items():
+        got = state[name]
+        assert got.shape == ref.shape, name
+        assert np.max(np.abs(got - ref)) <= 1e-5 * np.max(np.abs(ref)), name
+    np.testing.assert_array_equal(state["air_temperature_after_precpd"][74:], fortran["air_temperature_after_precpd"][74:])
+    assert state["air_temperature_after_precpd"].dtype == np.float64 and np.all(state["total_precipitation"] >= 0)
