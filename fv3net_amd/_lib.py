@@ -104,6 +104,8 @@ SIGNATURES = {
     "fv3hip_zc_precip_simple": (c_int, [c_void_p, c_void_p, c_void_p, c_int, c_void_p, c_void_p, c_int, c_int64, c_int64,
                                         c_int, c_void_p, c_void_p]),
     "fv3hip_zc_class_zero": (c_int, [c_void_p, c_int, c_void_p, c_int, c_int, c_int, c_int64, c_void_p, c_void_p]),
+    "fv3hip_non_negative_sphum": (c_int, [c_void_p, c_void_p, c_void_p, c_int, c_int64, c_double, c_int, c_void_p, c_void_p,
+                                          c_void_p]),
     "fv3hip_clamp": (c_int, [c_void_p, c_int, c_int64, c_double, c_double, c_int, c_int, c_void_p, c_void_p]),
     "fv3hip_level_fill": (c_int, [c_void_p, c_int, c_void_p, c_int, c_double, c_int64, c_int64, c_int64, c_int64, c_void_p,
                                   c_void_p]),

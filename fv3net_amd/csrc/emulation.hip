@@ -252,6 +252,37 @@ __global__ void class_zero_kernel(const T *x, const void *logits, int ldt, int n
     }
 }
 
+// ---------------------------------------------------------------------------------------
+// Humidity limiters applied to the ML tendencies each timestep
+// (external/vcm/vcm/calc/thermo/non_negative_sphum.py:6-45, local.py:25-28,317-360)
+// ---------------------------------------------------------------------------------------
+constexpr double kHeatCapacity = 1004.0 - 287.05;  // _SPECIFIC_HEAT_CONST_PRESSURE - _RDGAS
+constexpr double kLvFreezing = 2.5e6;              // latent_heat_vaporization(_FREEZING_TEMPERATURE)
+
+template <typename T>
+__global__ void non_negative_sphum_kernel(const T *sphum, const T *q1, const T *q2, int64_t n, T dt, int mse_conserving,
+                                          T *q1_out, T *q2_out)
+{
+    for (int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x) {
+        const T s = sphum[i], b = q2[i];
+        if (!mse_conserving) {
+            // non_negative_sphum: scale both tendencies by -sphum / (dt * dQ2) where the humidity would go negative
+            const T ratio = (-s) / (dt * b);
+            const bool ok = s + b * dt >= (T)0;
+            q2_out[i] = ok ? b : ratio * b;
+            if (q1) q1_out[i] = ok ? q1[i] : ratio * q1[i];
+        } else {
+            // limit the moistening tendency, then re-derive the heating that keeps the MSE tendency
+            const T b_new = (s + b * dt >= (T)0) ? b : -s / dt;
+            q2_out[i] = b_new;
+            if (q1) {
+                const T mse = (T)kHeatCapacity * q1[i] + (T)kLvFreezing * b;
+                q1_out[i] = (mse - (T)kLvFreezing * b_new) / (T)kHeatCapacity;
+            }
+        }
+    }
+}
+
 inline unsigned grid_for(int64_t n)
 {
     int64_t b = ceil_div(n, 256);
@@ -421,4 +452,23 @@ extern "C" int fv3hip_zc_class_zero(const void *x, int dtype, const void *logits
         hipLaunchKernelGGL((class_zero_kernel<float>), dim3(grid_for(n)), dim3(256), 0, st, static_cast<const float *>(x),
                            logits, logits_dtype, n_class, cls, n, static_cast<float *>(out));
     return check_launch("class_zero_kernel");
+}
+
+extern "C" int fv3hip_non_negative_sphum(const void *sphum, const void *q1, const void *q2, int dtype, int64_t n, double dt,
+                                         int mse_conserving, void *q1_out, void *q2_out, void *stream)
+{
+    FV3HIP_REQUIRE(float_code(dtype), "dtype must be F32 or F64");
+    FV3HIP_REQUIRE(n >= 0, "negative extent");
+    if (n == 0) return FV3HIP_OK;
+    FV3HIP_REQUIRE(sphum && q2 && q2_out && (!q1 || q1_out), "null pointer");
+    hipStream_t st = as_stream(stream);
+    if (dtype == FV3HIP_F64)
+        hipLaunchKernelGGL((non_negative_sphum_kernel<double>), dim3(grid_for(n)), dim3(256), 0, st,
+                           static_cast<const double *>(sphum), static_cast<const double *>(q1), static_cast<const double *>(q2),
+                           n, dt, mse_conserving, static_cast<double *>(q1_out), static_cast<double *>(q2_out));
+    else
+        hipLaunchKernelGGL((non_negative_sphum_kernel<float>), dim3(grid_for(n)), dim3(256), 0, st,
+                           static_cast<const float *>(sphum), static_cast<const float *>(q1), static_cast<const float *>(q2), n,
+                           (float)dt, mse_conserving, static_cast<float *>(q1_out), static_cast<float *>(q2_out));
+    return check_launch("non_negative_sphum_kernel");
 }

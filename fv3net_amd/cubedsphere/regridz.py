@@ -7,12 +7,11 @@ Fortran order and calls ``mappm`` per chunk.  Here the arrays stay in whatever l
 """
 from typing import Hashable, Union
 
-from .. import ops
-from ..thermo import pressure_at_interface, pressure_at_midpoint_log
-from ..xr_compat import DataArray, Dataset, from_compat, to_compat
-from ._device import like_input, on_device
 import numpy as np
 
+from .. import ops
+from ..xr_compat import DataArray, Dataset, from_compat, to_compat
+from ._device import like_input, on_device
 from .coarsen import block_upsample_like, edge_weighted_block_average, weighted_block_average
 from .constants import (
     FV_CORE_X_CENTER,
@@ -25,6 +24,18 @@ from .constants import (
 from .grid import interp_center_to_outer
 
 SURFACE_LEVEL = -1
+
+
+def pressure_at_interface(*args, **kwargs):
+    from ..thermo import pressure_at_interface as f  # (thermo imports this package's device helpers)
+
+    return f(*args, **kwargs)
+
+
+def pressure_at_midpoint_log(*args, **kwargs):
+    from ..thermo import pressure_at_midpoint_log as f
+
+    return f(*args, **kwargs)
 
 
 def regrid_vertical(p_in, f_in, p_out, iv: int = 1, kord: int = 1, z_dim_center: str = RESTART_Z_CENTER,

@@ -342,6 +342,18 @@ int fv3hip_zc_precip_simple(const void *cloud_g, const void *qv_g, const void *d
 /* mask_zero_cloud_classifier_precpd (zhao_carr.py:230-237): x -> 0 where class `cls` is hot. */
 int fv3hip_zc_class_zero(const void *x, int dtype, const void *logits, int logits_dtype,
                          int n_class, int cls, int64_t n, void *out, void *stream);
+/*
+ * Replaces vcm.non_negative_sphum and vcm.non_negative_sphum_mse_conserving
+ * (external/vcm/vcm/calc/thermo/non_negative_sphum.py:6-45), applied to the ML tendencies every
+ * timestep (workflows/prognostic_c48_run/runtime/steppers/machine_learning.py:226-237).
+ * mse_conserving = 0: where sphum + dQ2 dt < 0 both tendencies are scaled by -sphum / (dt dQ2);
+ * mse_conserving = 1: dQ2 -> -sphum / dt there, and dQ1 is re-derived so that the moist static
+ * energy tendency (cp - Rd) dQ1 + Lv dQ2 is unchanged.  q1 / q1_out may be NULL.  All arrays: n values
+ * of `dtype` (FV3HIP_F32 / FV3HIP_F64).
+ */
+int fv3hip_non_negative_sphum(const void *sphum, const void *q1, const void *q2, int dtype,
+                              int64_t n, double dt, int mse_conserving, void *q1_out,
+                              void *q2_out, void *stream);
 /* RangeMask (masks.py:23-41): np.maximum(x, lo) / np.minimum(x, hi), NaN-propagating. */
 int fv3hip_clamp(const void *x, int dtype, int64_t n, double lo, double hi, int has_lo,
                  int has_hi, void *out, void *stream);

@@ -269,3 +269,25 @@ def regrid_to_edge_weighted_pressure(fields, delp, length, toa_pressure, factor,
     pfull = pressure_at_midpoint_log(delp_c_on_f, toa_pressure, z_axis) if extrapolate else None
     masked = mask_weights(length, phalf_c, phalf_f, z_axis, pfull, extrapolate)
     return out, masked
+
+
+# ---------------------------------------------------------------------------------------------
+# humidity limiters (external/vcm/vcm/calc/thermo/non_negative_sphum.py:6-45, local.py:317-360)
+# ---------------------------------------------------------------------------------------------
+_HEAT_CAPACITY = 1004 - 287.05
+_LV0 = 2.5e6
+
+
+def non_negative_sphum(sphum, dq1, dq2, dt):
+    with np.errstate(divide="ignore", invalid="ignore"):
+        ratio = (-sphum) / (dt * dq2)
+        ok = sphum + dq2 * dt >= 0
+        return np.where(ok, dq1, ratio * dq1), np.where(ok, dq2, ratio * dq2)
+
+
+def non_negative_sphum_mse_conserving(sphum, q2, dt, q1=None):
+    q2_new = np.where(sphum + q2 * dt >= 0, q2, -sphum / dt)
+    if q1 is None:
+        return q2_new, None
+    mse = _HEAT_CAPACITY * q1 + _LV0 * q2
+    return q2_new, (mse - _LV0 * q2_new) / _HEAT_CAPACITY

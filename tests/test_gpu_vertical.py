@@ -235,3 +235,37 @@ def test_mappm_ill_formed_columns_take_the_sequential_path(device):
     ref = mappm_c.mappm(pe1_all, q, pe2, 1, 1)
     res = ops.as_numpy(ops.mappm(_dev(pe1_all, device), _dev(q, device), _dev(pe2, device)))
     assert _bits_equal(res, ref)
+
+
+@pytest.mark.parametrize("dt_np", [np.float32, np.float64])
+def test_humidity_limiters(device, dt_np):
+    """vcm.non_negative_sphum(_mse_conserving) on the device (non_negative_sphum.py:6-45) against the
+    oracle (pinned by test_non_negative_sphum.py's known answers) and those answers directly."""
+    from fv3net_amd import thermo
+    from fv3net_amd.xr_compat import DataArray
+
+    rng = np.random.default_rng(12)
+    shape = (79, 24, 24)
+    sphum = DataArray((10 ** rng.uniform(-7, -2, shape)).astype(dt_np), dims=["z", "y", "x"])
+    dq2 = DataArray(rng.normal(0, 2e-6, shape).astype(dt_np), dims=["z", "y", "x"])
+    dq1 = DataArray(rng.normal(0, 1e-4, shape).astype(dt_np), dims=["z", "y", "x"])
+    dq2.values[0, 0, 0] = 0.0  # 0 / 0 in the ratio, unused because the humidity stays non-negative
+    rtol = 1e-6 if dt_np == np.float32 else 1e-13
+    q1, q2 = thermo.non_negative_sphum(sphum, dq1, dq2, 900.0)
+    r1, r2 = onp.non_negative_sphum(sphum.values, dq1.values, dq2.values, dt_np(900.0))
+    assert q1.dims == ("z", "y", "x") and q1.values.dtype == dt_np
+    np.testing.assert_allclose(q1.values, r1, rtol=rtol)
+    np.testing.assert_allclose(q2.values, r2, rtol=rtol)
+    # the limited humidity is zero up to the rounding of the ratio (a few ulp of sphum)
+    assert np.all(sphum.values + q2.values * 900.0 >= -(4e-7 if dt_np == np.float32 else 1e-15) * sphum.values)
+    q2m, q1m = thermo.non_negative_sphum_mse_conserving(sphum, dq2, 900.0, q1=dq1)
+    r2m, r1m = onp.non_negative_sphum_mse_conserving(sphum.values, dq2.values, dt_np(900.0), dq1.values)
+    np.testing.assert_allclose(q2m.values, r2m, rtol=rtol)
+    np.testing.assert_allclose(q1m.values, r1m, rtol=1e-4 if dt_np == np.float32 else 1e-12, atol=1e-9)
+    q2_only, none = thermo.non_negative_sphum_mse_conserving(sphum, dq2, 900.0)
+    assert none is None
+    np.testing.assert_array_equal(q2_only.values, q2m.values)
+    # test_non_negative_sphum.py:49-58
+    lim = thermo.update_moisture_tendency_to_ensure_non_negative_humidity(DataArray(np.array([1.0, 2.0]), dims=["x"]),
+                                                                          DataArray(np.array([-3.0, -1.0]), dims=["x"]), 1.0)
+    np.testing.assert_array_equal(lim.values, [-1.0, -1.0])
