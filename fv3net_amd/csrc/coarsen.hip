@@ -499,6 +499,52 @@ __global__ void interp_to_outer_kernel(const T *__restrict__ in, const T *__rest
     }
 }
 
+
+// ---------------------------------------------------------------------------------------
+// Small elementwise vocabulary for the mask arithmetic of the surface-data coarse-graining
+// (external/vcm/vcm/cubedsphere/coarsen_restarts.py:1140-1470: isclose / where / & / products /
+// xr.where / fillna on [tile, (level,) y, x] fields).  Masks are 0 / 1 in the fields' dtype.
+// Operands b and c may be 2-D fields shared by `rep` consecutive outer slices of a.
+// ---------------------------------------------------------------------------------------
+template <typename T>
+__global__ void ew_kernel(int op, const T *__restrict__ a, const T *__restrict__ b, const T *__restrict__ c, T s,
+                          int64_t n, int64_t inner, int64_t b_rep, int64_t c_rep, T *__restrict__ out)
+{
+    const T nan = (T)__builtin_nanf("");
+    for (int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x) {
+        const int64_t o = i / inner, r = i - o * inner;
+        const T x = a[i];
+        const T y = b ? b[(o / b_rep) * inner + r] : (T)0;
+        const T z = c ? c[(o / c_rep) * inner + r] : (T)0;
+        T v;
+        switch (op) {
+            case FV3HIP_EW_MUL: v = x * y; break;
+            case FV3HIP_EW_ISCLOSE: {  // np.isclose(a, b): |a - b| <= atol + rtol |b|, equal infinities close, NaN never
+                const T d = x - y;
+                v = ((x == y) || ((d < 0 ? -d : d) <= (T)1e-8 + (T)1e-5 * (y < 0 ? -y : y))) ? (T)1 : (T)0;
+                if (x != x || y != y) v = (T)0;
+                break;
+            }
+            case FV3HIP_EW_ISCLOSE_S: {
+                const T d = x - s;
+                v = ((x == s) || ((d < 0 ? -d : d) <= (T)1e-8 + (T)1e-5 * (s < 0 ? -s : s))) ? (T)1 : (T)0;
+                if (x != x) v = (T)0;
+                break;
+            }
+            case FV3HIP_EW_WHERE_NAN: v = (y != (T)0) ? x : nan; break;        // a.where(mask b)
+            case FV3HIP_EW_SELECT: v = (z != (T)0) ? x : y; break;             // xr.where(mask c, a, b)
+            case FV3HIP_EW_SELECT_S: v = (y != (T)0) ? s : x; break;           // xr.where(mask b, s, a)
+            case FV3HIP_EW_GT_S: v = (x > s) ? (T)1 : (T)0; break;
+            case FV3HIP_EW_LT_S: v = (x < s) ? (T)1 : (T)0; break;
+            case FV3HIP_EW_FILLNA_S: v = (x != x) ? s : x; break;
+            case FV3HIP_EW_AND: v = (x != (T)0 && y != (T)0) ? (T)1 : (T)0; break;
+            case FV3HIP_EW_MIN_S: v = (x < s) ? x : s; break;                  // a.where(a < s, other=s)
+            default: v = x;
+        }
+        out[i] = v;
+    }
+}
+
 }  // namespace
 }  // namespace fv3hip
 
@@ -624,4 +670,31 @@ extern "C" int fv3hip_interp_center_to_outer(const void *in, int dtype, int64_t 
                            static_cast<const double *>(in), static_cast<const double *>(lo), static_cast<const double *>(hi),
                            static_cast<double *>(out), n_outer, ny, nx, axis);
     return check_launch("interp_to_outer_kernel");
+}
+
+extern "C" int fv3hip_ew(int op, const void *a, const void *b, const void *c, double scalar, int dtype, int64_t n,
+                         int64_t inner, int64_t b_rep, int64_t c_rep, void *out, void *stream)
+{
+    FV3HIP_REQUIRE(dtype == FV3HIP_F32 || dtype == FV3HIP_F64, "dtype must be F32 or F64");
+    FV3HIP_REQUIRE(op >= FV3HIP_EW_MUL && op <= FV3HIP_EW_MIN_S, "unknown elementwise op %d", op);
+    FV3HIP_REQUIRE(n >= 0 && inner >= 1 && b_rep >= 1 && c_rep >= 1, "bad extents");
+    if (n == 0) return FV3HIP_OK;
+    FV3HIP_REQUIRE(a && out, "null pointer");
+    const bool needs_b = op == FV3HIP_EW_MUL || op == FV3HIP_EW_ISCLOSE || op == FV3HIP_EW_WHERE_NAN ||
+                         op == FV3HIP_EW_SELECT || op == FV3HIP_EW_SELECT_S || op == FV3HIP_EW_AND;
+    FV3HIP_REQUIRE(!needs_b || b, "this op needs operand b");
+    FV3HIP_REQUIRE(op != FV3HIP_EW_SELECT || c, "select needs the mask operand c");
+    FV3HIP_REQUIRE(n % inner == 0, "n must be a multiple of inner");
+    int64_t blocks = ceil_div(n, 256);
+    if (blocks > 256 * 64) blocks = 256 * 64;
+    hipStream_t st = as_stream(stream);
+    if (dtype == FV3HIP_F64)
+        hipLaunchKernelGGL((ew_kernel<double>), dim3((unsigned)blocks), dim3(256), 0, st, op, static_cast<const double *>(a),
+                           static_cast<const double *>(b), static_cast<const double *>(c), scalar, n, inner, b_rep, c_rep,
+                           static_cast<double *>(out));
+    else
+        hipLaunchKernelGGL((ew_kernel<float>), dim3((unsigned)blocks), dim3(256), 0, st, op, static_cast<const float *>(a),
+                           static_cast<const float *>(b), static_cast<const float *>(c), (float)scalar, n, inner, b_rep, c_rep,
+                           static_cast<float *>(out));
+    return check_launch("ew_kernel");
 }

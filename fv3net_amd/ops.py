@@ -205,6 +205,38 @@ def block_upsample(x: torch.Tensor, factor: int) -> torch.Tensor:
     return out
 
 
+EW_OPS = {"mul": 0, "isclose": 1, "isclose_s": 2, "where_nan": 3, "select": 4, "select_s": 5, "gt_s": 6, "lt_s": 7,
+          "fillna_s": 8, "and": 9, "min_s": 10}
+
+
+def ew(op: str, a: torch.Tensor, b: Optional[torch.Tensor] = None, c: Optional[torch.Tensor] = None,
+       scalar: float = 0.0) -> torch.Tensor:
+    """One step of the surface-data mask arithmetic (coarsen_restarts.py:1140-1470), see
+    ``fv3hip_ew``: ``b`` / ``c`` have ``a``'s shape, or are [.., y, x] fields shared by the extra
+    (level) axis of ``a`` [.., level, y, x]."""
+    dev = _require_device(a)
+    code = _float_code(a)
+    a = a.contiguous()
+    inner = int(a.shape[-1] * a.shape[-2]) if a.dim() >= 2 else max(int(a.numel()), 1)
+
+    def operand(t):
+        if t is None:
+            return None, 1
+        t = t.to(dtype=a.dtype).contiguous()
+        if tuple(t.shape) == tuple(a.shape):
+            return t, 1
+        if a.dim() >= 3 and tuple(t.shape) == tuple(a.shape[:-3]) + tuple(a.shape[-2:]):
+            return t, int(a.shape[-3])
+        raise ValueError(f"operand shape {tuple(t.shape)} does not match {tuple(a.shape)}")
+
+    b, b_rep = operand(b)
+    c, c_rep = operand(c)
+    out = torch.empty_like(a)
+    _lib.call("fv3hip_ew", EW_OPS[op], _ptr(a), _ptr(b), _ptr(c), float(scalar), code, a.numel(), inner, b_rep, c_rep,
+              _ptr(out), _stream(dev))
+    return out
+
+
 def cube_edge_rows(x: torch.Tensor) -> torch.Tensor:
     """The four boundary vectors of every square tile of ``x`` [tile, ..., n, n] ->
     [tile, 4, ..., n]: 0: x = 0, 1: x = n-1 (indexed by y), 2: y = 0, 3: y = n-1 (indexed by x).

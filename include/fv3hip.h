@@ -132,6 +132,26 @@ int fv3hip_block_upsample(const void *in, int elem_size, int64_t n_outer, int ny
                           int factor, void *out, void *stream);
 
 /*
+ * The mask arithmetic of the 'complex' surface-data coarse-graining
+ * (external/vcm/vcm/cubedsphere/coarsen_restarts.py:1140-1470), one elementwise launch per step.
+ * a, out: n values; b, c: n values, or 2-D fields of `inner` values shared by b_rep / c_rep consecutive
+ * outer slices of a (a = [.., level, y, x], b = [.., y, x]).  Masks are 0 / 1 in the fields' dtype.
+ */
+#define FV3HIP_EW_MUL 0        /* a * b                                              */
+#define FV3HIP_EW_ISCLOSE 1    /* np.isclose(a, b) (rtol 1e-5, atol 1e-8)            */
+#define FV3HIP_EW_ISCLOSE_S 2  /* np.isclose(a, scalar)                              */
+#define FV3HIP_EW_WHERE_NAN 3  /* a.where(b): a where the mask b holds, else NaN     */
+#define FV3HIP_EW_SELECT 4     /* xr.where(c, a, b)                                  */
+#define FV3HIP_EW_SELECT_S 5   /* xr.where(b, scalar, a)                             */
+#define FV3HIP_EW_GT_S 6       /* a > scalar                                         */
+#define FV3HIP_EW_LT_S 7       /* a < scalar                                         */
+#define FV3HIP_EW_FILLNA_S 8   /* a.fillna(scalar)                                   */
+#define FV3HIP_EW_AND 9        /* a & b                                              */
+#define FV3HIP_EW_MIN_S 10     /* a.where(a < scalar, other=scalar)                  */
+int fv3hip_ew(int op, const void *a, const void *b, const void *c, double scalar, int dtype,
+              int64_t n, int64_t inner, int64_t b_rep, int64_t c_rep, void *out, void *stream);
+
+/*
  * Cell centres -> cell edges across the faces of the cube: the device half of what
  * xgcm.Grid.interp(delp, axis) does for vcm.cubedsphere.regridz.regrid_to_edge_weighted_pressure and
  * coarsen_restarts.compute_edge_delp (external/vcm/vcm/cubedsphere/regridz.py:123-135,

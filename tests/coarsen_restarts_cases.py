@@ -39,7 +39,8 @@ def plan(tag):
     if tag.startswith("area-weighted-model-level"):
         return {"area": {"fv_core.res": ["phis", "delp", "DZ", "W", "T"], "fv_tracer.res": ["cld_amt"] + tracers,
                          "fv_srf_wnd.res": ["u_srf", "v_srf"]},
-                "mass": {}, "edge_x": {"fv_core.res": ["u"]}, "edge_y": {"fv_core.res": ["v"]}}
+                "mass": {}, "edge_x": {"fv_core.res": ["u"]}, "edge_y": {"fv_core.res": ["v"]},
+                "sfc_data": True}  # the 'complex' surface-data method; the same for every tag
     if tag.startswith("mass-weighted-model-level"):
         return {"area": {"fv_core.res": ["phis", "delp", "DZ"], "fv_tracer.res": ["cld_amt"],
                          "fv_srf_wnd.res": ["u_srf", "v_srf"]},

@@ -81,6 +81,10 @@ COVERED = {
         "fv_core.res": ["phis", "delp", "DZ", "W", "T", "u", "v"],
         "fv_tracer.res": ["cld_amt", "sphum", "liq_wat", "rainwat", "ice_wat", "snowwat", "graupel", "o3mr", "sgs_tke"],
         "fv_srf_wnd.res": ["u_srf", "v_srf"],
+        # the 'complex' surface-data method (coarsen_restarts.py:1111-1470); identical for every tag
+        "sfc_data": ["slmsk", "vtype", "stype", "tsea", "sheleg", "tg3", "zorl", "alvsf", "alvwf", "alnsf", "alnwf", "facsf",
+                     "facwf", "vfrac", "canopy", "f10m", "t2m", "q2m", "uustar", "ffmm", "ffhh", "hice", "fice", "tisfc",
+                     "tprcp", "srflag", "snwdph", "shdmin", "shdmax", "slope", "snoalb", "sncovr", "stc", "smc", "slc"],
     },
     "mass-weighted-model-level-with-agrid-winds": {
         "fv_core.res": ["phis", "delp", "DZ", "W", "T", "ua", "va", "u", "v"],
@@ -105,7 +109,7 @@ def make_coarsen_restarts():
     meta = {"factor": 2, "toa_pressure": 300.0, "default_range": [-1000, 1000],
             "ranges": {"delp": [3, 5], "area": [0.5, 1], "dx": [0.5, 1], "dy": [0.5, 1]},
             "inputs": {}, "expected": []}
-    for category in ["fv_core.res", "fv_tracer.res", "fv_srf_wnd.res", "grid"]:
+    for category in ["fv_core.res", "fv_tracer.res", "fv_srf_wnd.res", "sfc_data", "grid"]:
         with open(os.path.join(base, "schemas", f"{category}-schema.json")) as f:
             schema = json.load(f)["schema"]
         meta["inputs"][category] = {

@@ -230,6 +230,14 @@ def test_coarsen_restarts_regression_fixtures(tag):
                                                                   y_dim=ydim, extrapolate=plan["extrapolate"])
         res = weighted_block_average(regridded, masked_area, f, x_dim="xaxis_1", y_dim=ydim)
         got.update({(category, v): res[v] for v in variables})
+    if plan.get("sfc_data"):  # the 'complex' surface-data method (coarsen_restarts.py:1111-1470)
+        from fv3net_amd.cubedsphere import coarse_grain_sfc_data
+
+        ds = Dataset({v: DataArray(arr, dims=dims, name=v) for v, (dims, arr) in inp["sfc_data"].items()})
+        res = coarse_grain_sfc_data(ds, grid("area", "yaxis_1", "xaxis_1"), f)
+        for v in res:
+            assert res[v].values.dtype == np.float32, v
+            got[("sfc_data", v)] = res[v].isel({"Time": 0}) if "Time" in res[v].dims else res[v]
     # D-grid winds on pressure levels (coarsen_restarts.py:497-519,541-557): u with dx along x edges, v with dy
     for key, length, xdim, ydim, edge in (("pressure_edge_x", "dx", "xaxis_1", "yaxis_1", "x"),
                                           ("pressure_edge_y", "dy", "xaxis_2", "yaxis_2", "y")):
@@ -260,6 +268,8 @@ def test_coarsen_restarts_regression_fixtures(tag):
             # delp differs from numpy's in the last float32 bit of sum(area) (summation order), so
             # the bar is 1e-5 relative to the field's magnitude.
             np.testing.assert_allclose(res, want, rtol=1e-5, atol=2e-5 * np.nanmax(np.abs(want)), err_msg=key)
+        elif entry["category"] == "sfc_data" and entry["variable"] in ("slmsk", "vtype", "stype", "srflag", "slope"):
+            np.testing.assert_array_equal(res, want.astype(np.float32), err_msg=key)  # block modes: bit-exact index maps
         else:
             np.testing.assert_allclose(res, want, rtol=1e-5, atol=1e-8, err_msg=key)
         checked += 1

@@ -251,3 +251,42 @@ def test_cube_interp_rejects_bad_shapes(device):
     with pytest.raises(ValueError):
         ops.interp_center_to_outer(torch.zeros(6, 3, 4, 4, device=device), torch.zeros(6, 3, 5, device=device),
                                    torch.zeros(6, 3, 4, device=device), 0)
+
+
+def test_sfc_data_complex_with_categorical_fields(device):
+    """The 'complex' surface-data method (coarsen_restarts.py:1111-1470) on fields that look like the
+    real ones -- small-integer categoricals with ties, land / ocean / sea-ice patches, zero
+    fractions -- against the oracle (pinned by the reference's sfc_data fixtures): categorical
+    results bit-exact, means to float32 rounding of float64 sums."""
+    from fv3net_amd.cubedsphere.sfc_data import SFC_DATA_VARIABLES, coarse_grain_sfc_data_tensors
+    from oracle import sfc_data_np
+
+    rng = np.random.default_rng(21)
+    nt, n, f = 6, 24, 4
+    ds = {}
+    for name in SFC_DATA_VARIABLES:
+        shape = (nt, 4, n, n) if name in ("smc", "slc", "stc") else (nt, n, n)
+        ds[name] = rng.uniform(0, 1, shape)
+    ds["slmsk"] = rng.integers(0, 3, (nt, n, n)).astype(np.float64)
+    ds["vtype"] = rng.integers(13, 17, (nt, n, n)).astype(np.float64)   # includes land ice (15)
+    ds["stype"] = rng.integers(1, 17, (nt, n, n)).astype(np.float64)
+    ds["srflag"] = rng.integers(0, 2, (nt, n, n)).astype(np.float64)
+    ds["slope"] = rng.integers(1, 10, (nt, n, n)).astype(np.float64)
+    ds["tsea"] = rng.uniform(260, 290, (nt, n, n))
+    ds["tg3"] = rng.uniform(260, 290, (nt, n, n))
+    ds["vfrac"][rng.random((nt, n, n)) < 0.5] = 0.0
+    ds["fice"][rng.random((nt, n, n)) < 0.7] = 0.0
+    ds["sncovr"][rng.random((nt, n, n)) < 0.8] = 0.0
+    ds["shdmin"] = rng.uniform(0, 0.03, (nt, n, n))
+    area = rng.uniform(0.5, 1.0, (nt, n, n))
+    ref = sfc_data_np.coarse_grain_sfc_data_complex(ds, area, f)
+    res = coarse_grain_sfc_data_tensors({k: _dev(v, device) for k, v in ds.items()}, _dev(area, device), f)
+    assert set(res) == set(ref)
+    for name, want in ref.items():
+        got = res[name].cpu().numpy()
+        assert got.shape == want.shape and got.dtype == np.float32, name
+        assert np.array_equal(np.isnan(got), np.isnan(want)), name
+        if name in ("slmsk", "vtype", "stype", "srflag", "slope"):
+            np.testing.assert_array_equal(got, want, err_msg=name)
+        else:
+            np.testing.assert_allclose(got, want, rtol=2e-7, atol=0, err_msg=name)
