@@ -674,6 +674,59 @@ constexpr size_t kCounterBytes = 256;
 inline int64_t ws_slots(int64_t ncol) { return ncol < kMappmChunk ? ncol : kMappmChunk; }
 inline size_t ws_list_bytes(int64_t ncol) { return ((size_t)ws_slots(ncol) * 4 + 255) & ~(size_t)255; }
 
+
+// ---------------------------------------------------------------------------------------
+// interpolate_2d (external/mappm/mappm/interpolate_2d.f90:1-28), the other routine of the reference's
+// native module: per column, linear interpolation of y(x) onto the points xp.  The search runs over
+// every interval (a later match overwrites an earlier one, as in the Fortran loop); points outside
+// the column's range keep fill_value.  One thread per output point; float64 throughout.
+// ---------------------------------------------------------------------------------------
+__global__ void interpolate_2d_kernel(const double *__restrict__ xp, const double *__restrict__ x,
+                                      const double *__restrict__ y, double *__restrict__ out, double fill_value,
+                                      int64_t n_batch, int64_t n_inner, int n_in, int n_out, int layout)
+{
+    const int64_t ncol = n_batch * n_inner;
+    const int64_t total = ncol * n_out;
+    for (int64_t idx = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; idx < total; idx += (int64_t)gridDim.x * blockDim.x) {
+        int64_t col, base_in, base_out, ks;
+        int j;
+        if (layout == FV3HIP_LAYOUT_LEVEL_COL) {  // [batch][level][inner]: adjacent threads = adjacent columns
+            const int64_t inner = idx % n_inner;
+            const int64_t r = idx / n_inner;
+            j = (int)(r % n_out);
+            const int64_t bt = r / n_out;
+            col = bt * n_inner + inner;
+            ks = n_inner;
+            base_in = bt * (int64_t)n_in * n_inner + inner;
+            base_out = bt * (int64_t)n_out * n_inner + inner;
+        } else {                                   // [column][level]
+            j = (int)(idx % n_out);
+            col = idx / n_out;
+            ks = 1;
+            base_in = col * (int64_t)n_in;
+            base_out = col * (int64_t)n_out;
+        }
+        (void)col;
+        const double p = xp[base_out + (int64_t)j * ks];
+        double r = fill_value;
+        double x0 = x[base_in], y0 = y[base_in];
+        for (int k = 0; k < n_in - 1; ++k) {
+            const double x1 = x[base_in + (int64_t)(k + 1) * ks], y1 = y[base_in + (int64_t)(k + 1) * ks];
+            if (x0 <= p && p < x1) {
+                const double w = (p - x0) / (x1 - x0);
+                r = y0 * (1 - w) + y1 * w;
+            } else if (x0 == p) {
+                r = y0;
+            } else if (x1 == p) {
+                r = y1;
+            }
+            x0 = x1;
+            y0 = y1;
+        }
+        out[base_out + (int64_t)j * ks] = r;
+    }
+}
+
 }  // namespace
 }  // namespace fv3hip
 
@@ -814,4 +867,20 @@ extern "C" int fv3hip_mappm(const void *pe1, const void *q1, const void *pe2, in
         if (rc) return rc;
     }
     return FV3HIP_OK;
+}
+
+extern "C" int fv3hip_interpolate_2d(const void *xp, const void *x, const void *y, int64_t n_batch, int64_t n_inner, int n_in,
+                                     int n_out, double fill_value, int layout, void *out, void *stream)
+{
+    FV3HIP_REQUIRE(layout == FV3HIP_LAYOUT_COL_LEVEL || layout == FV3HIP_LAYOUT_LEVEL_COL, "unknown layout %d", layout);
+    FV3HIP_REQUIRE(n_batch >= 0 && n_inner >= 0 && n_in >= 1 && n_out >= 0, "bad extents");
+    const int64_t total = n_batch * n_inner * n_out;
+    if (total == 0) return FV3HIP_OK;
+    FV3HIP_REQUIRE(xp && x && y && out, "null pointer");
+    int64_t blocks = ceil_div(total, 256);
+    if (blocks > 256 * 64) blocks = 256 * 64;
+    hipLaunchKernelGGL(interpolate_2d_kernel, dim3((unsigned)blocks), dim3(256), 0, as_stream(stream),
+                       static_cast<const double *>(xp), static_cast<const double *>(x), static_cast<const double *>(y),
+                       static_cast<double *>(out), fill_value, n_batch, n_inner, n_in, n_out, layout);
+    return check_launch("interpolate_2d_kernel");
 }

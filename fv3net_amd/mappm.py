@@ -27,3 +27,14 @@ def mappm(p_in, f_in, p_out, i1, i2, iv, kord, ptop):
     sel = slice(lo, hi)
     res = ops.mappm(on_device(p1[sel]), on_device(f1[sel]), on_device(p2[sel]), iv=int(iv), kord=int(kord), z_axis=-1)
     return like_input(res, f_in if isinstance(f_in, torch.Tensor) else np.empty(0))
+
+
+def interpolate_2d(xp, x, y, fill_value=np.nan):
+    """The other routine of the reference's native module (interpolate_2d.f90:1-28; f2py call at
+    external/vcm/vcm/interpolate.py:165-169): ``[m, n]`` arrays, linear interpolation of each row of
+    ``y(x)`` onto the row of ``xp``, ``fill_value`` outside the row's range; float64 ``[m, n_out]``."""
+    a, b, c = (t if isinstance(t, torch.Tensor) else np.asarray(t) for t in (xp, x, y))
+    if a.ndim != 2 or b.ndim != 2 or c.ndim != 2:
+        raise ValueError("interpolate_2d expects 2-d arrays [row, point]")
+    res = ops.interpolate_2d(on_device(a), on_device(b), on_device(c), fill_value=float(fill_value), z_axis=-1)
+    return like_input(res, y if isinstance(y, torch.Tensor) else np.empty(0))

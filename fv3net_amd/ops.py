@@ -205,6 +205,28 @@ def block_upsample(x: torch.Tensor, factor: int) -> torch.Tensor:
     return out
 
 
+def interpolate_2d(xp: torch.Tensor, x: torch.Tensor, y: torch.Tensor, fill_value: float = float("nan"),
+                   z_axis: int = -1) -> torch.Tensor:
+    """``mappm.interpolate_2d`` (interpolate_2d.f90:1-28): linear interpolation of ``y(x)`` onto ``xp``
+    along ``z_axis`` (x, y: n_in points there, xp: n_out), ``fill_value`` outside each column's range.
+    Arrays share all other dims; computed and returned in float64."""
+    dev = _require_device(xp, x, y)
+    z_axis = z_axis % x.dim()
+    if tuple(x.shape) != tuple(y.shape):
+        raise ValueError("x and y must have the same shape")
+    rest = lambda t: tuple(t.shape[:z_axis]) + tuple(t.shape[z_axis + 1:])
+    if rest(xp) != rest(x):
+        raise ValueError("xp must match x in every dimension but the interpolated one")
+    xp, x, y = (t.to(torch.float64).contiguous() for t in (xp, x, y))
+    n_in, n_out = int(x.shape[z_axis]), int(xp.shape[z_axis])
+    n_batch, n_inner = _prod(x.shape[:z_axis]), _prod(x.shape[z_axis + 1:])
+    layout = _lib.LAYOUT_LEVEL_COL if n_inner > 1 else _lib.LAYOUT_COL_LEVEL
+    out = torch.empty_like(xp)
+    _lib.call("fv3hip_interpolate_2d", _ptr(xp), _ptr(x), _ptr(y), n_batch, n_inner, n_in, n_out, float(fill_value), layout,
+              _ptr(out), _stream(dev))
+    return out
+
+
 EW_OPS = {"mul": 0, "isclose": 1, "isclose_s": 2, "where_nan": 3, "select": 4, "select_s": 5, "gt_s": 6, "lt_s": 7,
           "fillna_s": 8, "and": 9, "min_s": 10}
 

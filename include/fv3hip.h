@@ -316,6 +316,17 @@ int fv3hip_timer_stop(fv3hip_timer_t t, void *stream);
 int fv3hip_timer_elapsed_ms(fv3hip_timer_t t, float *ms); /* synchronises on the stop event */
 int fv3hip_timer_destroy(fv3hip_timer_t t);
 
+/*
+ * Replaces mappm.interpolate_2d (external/mappm/mappm/interpolate_2d.f90:1-28; called from
+ * external/vcm/vcm/interpolate.py:165-169): per column, linear interpolation of y(x) (n_in points,
+ * x increasing) onto xp (n_out points); outside the column's range the result is fill_value.
+ * float64.  Layouts as for fv3hip_mappm: COL_LEVEL [ncol][n] (n_batch = ncol, n_inner = 1) or
+ * LEVEL_COL [n_batch][n][n_inner].  Bit-identical to the compiled Fortran.
+ */
+int fv3hip_interpolate_2d(const void *xp, const void *x, const void *y, int64_t n_batch,
+                          int64_t n_inner, int n_in, int n_out, double fill_value, int layout,
+                          void *out, void *stream);
+
 /* ------------------------------------------------------------------------------------------
  * Zhao-Carr emulator post-processing (masks and conservation fixes on the emulator outputs)
  * ------------------------------------------------------------------------------------------

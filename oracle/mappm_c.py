@@ -90,3 +90,39 @@ def reference_mappm(p_in, f_in, p_out, iv=1, kord=1, chunk=256):
         ctypes.byref(ctypes.c_float(0.0)),
     )
     return np.ascontiguousarray(out)
+
+
+
+def interpolate_2d(xp, x, y, fill_value=np.nan):
+    """C restatement of interpolate_2d.f90: [m, n] float64 arrays, returns [m, n_out]."""
+    lib = _load_oracle()
+    lib.fv3_oracle_interpolate_2d.restype = ctypes.c_int
+    lib.fv3_oracle_interpolate_2d.argtypes = [ctypes.c_void_p] * 4 + [ctypes.c_double, ctypes.c_long, ctypes.c_int, ctypes.c_int]
+    a = np.ascontiguousarray(xp, dtype=np.float64)
+    b = np.ascontiguousarray(x, dtype=np.float64)
+    c = np.ascontiguousarray(y, dtype=np.float64)
+    m, n_in = b.shape
+    n_out = a.shape[1]
+    assert a.shape[0] == m and c.shape == b.shape
+    out = np.empty((m, n_out), dtype=np.float64)
+    lib.fv3_oracle_interpolate_2d(_p(a), _p(b), _p(c), _p(out), float(fill_value), m, n_in, n_out)
+    return out
+
+
+def reference_interpolate_2d(xp, x, y, fill_value=np.nan):
+    """The reference's own interpolate_2d.f90 (compiled, never copied): Fortran order real(8)."""
+    global _ref
+    if _ref is None:
+        if not have_reference():
+            raise ImportError(f"{REF_SO} not present (only buildable where /root/reference exists)")
+        _ref = ctypes.CDLL(REF_SO)
+    a = np.asfortranarray(xp, dtype=np.float64)
+    b = np.asfortranarray(x, dtype=np.float64)
+    c = np.asfortranarray(y, dtype=np.float64)
+    m, n_in = b.shape
+    n_out = a.shape[1]
+    out = np.zeros((m, n_out), dtype=np.float64, order="F")
+    fill = ctypes.c_double(float(fill_value))
+    mm, ni, no = ctypes.c_int(m), ctypes.c_int(n_in), ctypes.c_int(n_out)
+    _ref.interpolate_2d_(_p(a), _p(b), _p(c), _p(out), ctypes.byref(fill), ctypes.byref(mm), ctypes.byref(ni), ctypes.byref(no))
+    return np.ascontiguousarray(out)

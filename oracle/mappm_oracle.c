@@ -363,3 +363,31 @@ int fv3_oracle_ppm_profile(const float *pe1, const float *q1, float *al_out, flo
     free(buf);
     return FV3_ORACLE_OK;
 }
+
+
+/* interpolate_2d (external/mappm/mappm/interpolate_2d.f90:1-28): per row i, linear interpolation of
+ * y(x) onto the points xp; the search runs over ALL intervals k (a later match overwrites an earlier
+ * one), points outside [x(1), x(n_in)] keep fill_value.  Row-major [m][n] arrays, double precision. */
+int fv3_oracle_interpolate_2d(const double *xp, const double *x, const double *y, double *y_out, double fill_value,
+                              long m, int n_in, int n_out)
+{
+    for (long i = 0; i < m; ++i) {
+        const double *xi = x + i * n_in, *yi = y + i * n_in;
+        for (int j = 0; j < n_out; ++j) {
+            const double p = xp[i * n_out + j];
+            double r = fill_value;
+            for (int k = 0; k < n_in - 1; ++k) {
+                if (xi[k] <= p && p < xi[k + 1]) {
+                    const double w = (p - xi[k]) / (xi[k + 1] - xi[k]);
+                    r = yi[k] * (1 - w) + yi[k + 1] * w;
+                } else if (xi[k] == p) {
+                    r = yi[k];
+                } else if (xi[k + 1] == p) {
+                    r = yi[k + 1];
+                }
+            }
+            y_out[i * n_out + j] = r;
+        }
+    }
+    return 0;
+}

@@ -76,6 +76,33 @@ def make_mappm():
     print("mappm cases:", n)
 
 
+def make_interpolate_2d():
+    """Random and edge-case rows through the REFERENCE's interpolate_2d.f90 (compiled into
+    oracle/_ref/libmappm_ref.so), with its outputs."""
+    from oracle import mappm_c
+
+    assert mappm_c.have_reference(), "run `make -C oracle ref` first"
+    rng = np.random.default_rng(77)
+    cases = {}
+    for n, (m, n_in, n_out) in enumerate([(40, 79, 30), (16, 5, 9), (8, 2, 7), (12, 33, 1)]):
+        x = np.cumsum(rng.uniform(0.1, 1, (m, n_in)), axis=1)
+        if n_in > 6:
+            x[3, 5] = x[3, 4]          # a repeated collocation point
+        y = rng.normal(0, 1, (m, n_in))
+        xp = rng.uniform(-0.5, x.max() + 0.5, (m, n_out))
+        xp[:, 0] = x[:, 0]
+        if n_out > 2:
+            xp[:, 1] = x[:, -1]
+            xp[:, 2] = x[:, n_in // 2]
+        if n_out > 3:
+            xp[0, 3] = np.nan
+        cases[f"case{n}_xp"], cases[f"case{n}_x"], cases[f"case{n}_y"] = xp, x, y
+        cases[f"case{n}_out"] = mappm_c.reference_interpolate_2d(xp, x, y)
+    cases["n_cases"] = np.array(4)
+    np.savez_compressed(os.path.join(HERE, "interpolate_2d_reference.npz"), **cases)
+    print("interpolate_2d cases: 4")
+
+
 COVERED = {
     "area-weighted-model-level-without-agrid-winds": {
         "fv_core.res": ["phis", "delp", "DZ", "W", "T", "u", "v"],
@@ -146,5 +173,6 @@ def make_normalization():
 
 if __name__ == "__main__":
     make_mappm()
+    make_interpolate_2d()
     make_coarsen_restarts()
     make_normalization()

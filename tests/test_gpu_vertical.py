@@ -269,3 +269,49 @@ def test_humidity_limiters(device, dt_np):
     lim = thermo.update_moisture_tendency_to_ensure_non_negative_humidity(DataArray(np.array([1.0, 2.0]), dims=["x"]),
                                                                           DataArray(np.array([-3.0, -1.0]), dims=["x"]), 1.0)
     np.testing.assert_array_equal(lim.values, [-1.0, -1.0])
+
+
+@pytest.mark.parametrize("layout", ["col_level", "level_col"])
+def test_interpolate_2d_bit_exact(device, layout):
+    """The HIP interpolate_2d against the goldens produced by the reference's compiled Fortran and against
+    the C oracle, bit for bit (NaN fill included), in both memory layouts."""
+    import os
+
+    from fv3net_amd import ops
+    from oracle import mappm_c
+
+    z = np.load(os.path.join(os.path.dirname(__file__), "golden", "interpolate_2d_reference.npz"))
+    for n in range(int(z["n_cases"])):
+        xp, x, y, want = (z[f"case{n}_{k}"] for k in ("xp", "x", "y", "out"))
+        if layout == "col_level":
+            got = ops.as_numpy(ops.interpolate_2d(_dev(xp, device), _dev(x, device), _dev(y, device), z_axis=-1))
+        else:  # [level, column]: the interpolated axis first
+            got = ops.as_numpy(ops.interpolate_2d(_dev(xp.T.copy(), device), _dev(x.T.copy(), device),
+                                                  _dev(y.T.copy(), device), z_axis=0)).T
+        np.testing.assert_array_equal(got, want)
+    rng = np.random.default_rng(3)
+    x = np.cumsum(rng.uniform(0.1, 1, (6, 79, 24, 24)), axis=1)
+    y = rng.normal(0, 1, x.shape)
+    xp = rng.uniform(0, x.max(), (6, 31, 24, 24))
+    got = ops.as_numpy(ops.interpolate_2d(_dev(xp, device), _dev(x, device), _dev(y, device), z_axis=1))
+    cols = lambda a: np.moveaxis(a, 1, -1).reshape(-1, a.shape[1])
+    want = mappm_c.interpolate_2d(cols(xp), cols(x), cols(y)).reshape(6, 24, 24, 31)
+    np.testing.assert_array_equal(got, np.moveaxis(want, -1, 1))
+
+
+def test_interpolate_1d_reference_known_answer(device):
+    """external/vcm/tests/test_interpolate.py:99-106 through the drop-in API."""
+    from fv3net_amd import mappm
+    from fv3net_amd.interpolate import interpolate_1d
+    from fv3net_amd.xr_compat import DataArray
+
+    xp = DataArray(np.array([[0.25, 0.5, 1.0], [0.25, 0.5, 1.0]]), dims=["x", "y_new"])
+    inp = DataArray(np.array([[0, 1], [2, 3]]), dims=["x", "y"])
+    x = DataArray(np.array([[0, 1], [0, 1]]), dims=["x", "y"])
+    ans = interpolate_1d(xp, x, inp)
+    assert ans.dims == ("x", "y_new")
+    np.testing.assert_allclose(ans.values, [[0.25, 0.5, 1.0], [2.25, 2.50, 3.0]])
+    xs = np.arange(10).reshape(1, 10)
+    res = mappm.interpolate_2d(np.arange(12).reshape(1, 12), xs, xs ** 2, fill_value=np.nan)  # test_interpolate.py:120-133
+    np.testing.assert_array_equal(res[:, :10], xs ** 2)
+    assert np.isnan(res[:, -2:]).all() and res.dtype == np.float64
