@@ -592,16 +592,17 @@ __global__ __launch_bounds__(256) void mappm_merge_kernel(
             const bool inside = live && !accum && (p2k >= pL && p2k <= pL1) && (p2k1 <= pL1);
             if (!(part || inside)) break;
             float val;
+            // (p2k1 - pL) / d0 is `esl` of the accumulating branch and `PR` of the inside branch: the
+            // same operations on the same operands, so one division serves whichever branch a lane takes
+            const float delp = p2k1 - pL;
+            const float PR = delp / d0;
             if (part) {
-                const float delp = p2k1 - pL;
-                const float esl = delp / d0;
-                qsum = qsum + delp * (al + 0.5f * esl * (ar - al + a6 * (1.f - r23 * esl)));
+                qsum = qsum + delp * (al + 0.5f * PR * (ar - al + a6 * (1.f - r23 * PR)));
                 dpsum = dpsum + delp;
                 val = qsum / dpsum;
                 accum = false;
             } else {
                 const float PL = (p2k - pL) / d0;
-                const float PR = (p2k1 - pL) / d0;
                 const float TT = r3 * (PR * (PR + PL) + PL * PL);
                 val = al + 0.5f * (a6 + ar - al) * (PR + PL) - a6 * TT;
             }
