@@ -109,6 +109,10 @@ SIGNATURES = {
     "fv3hip_clamp": (c_int, [c_void_p, c_int, c_int64, c_double, c_double, c_int, c_int, c_void_p, c_void_p]),
     "fv3hip_level_fill": (c_int, [c_void_p, c_int, c_void_p, c_int, c_double, c_int64, c_int64, c_int64, c_int64, c_void_p,
                                   c_void_p]),
+    "fv3hip_column_sum": (c_int, [c_void_p, c_int, c_int64, c_int, c_int64, c_double, c_void_p, c_void_p]),
+    "fv3hip_blend_weights": (c_int, [c_void_p, c_void_p, c_void_p, c_int, c_int64, c_int, c_int64, c_void_p, c_void_p]),
+    "fv3hip_hydrostatic_balance": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_int64, c_int, c_int64,
+                                           c_double, c_void_p, c_void_p, c_void_p]),
     "fv3hip_interpolate_2d": (c_int, [c_void_p, c_void_p, c_void_p, c_int64, c_int64, c_int, c_int, c_double, c_int, c_void_p,
                                       c_void_p]),
     "fv3hip_ew": (c_int, [c_int, c_void_p, c_void_p, c_void_p, c_double, c_int, c_int64, c_int64, c_int64, c_int64, c_void_p,

@@ -728,6 +728,72 @@ __global__ void interpolate_2d_kernel(const double *__restrict__ xp, const doubl
     }
 }
 
+
+// ---------------------------------------------------------------------------------------
+// Column helpers of the restart pipelines (external/vcm/vcm/cubedsphere/coarsen_restarts.py:559-676,
+// 990-1017; external/vcm/vcm/calc/thermo/vertically_dependent.py:69-99,182-235).  Arrays are
+// [n_batch][nz][n_inner] (level-major columns, adjacent threads = adjacent columns).
+// ---------------------------------------------------------------------------------------
+// surface_pressure_from_delp: sum over the levels + addend
+template <typename T>
+__global__ void column_sum_kernel(const T *__restrict__ x, T *__restrict__ out, int64_t n_batch, int nz, int64_t n_inner,
+                                  T addend)
+{
+    const int64_t ncol = n_batch * n_inner;
+    for (int64_t c = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; c < ncol; c += (int64_t)gridDim.x * blockDim.x) {
+        const int64_t b = c / n_inner, i = c - b * n_inner;
+        const T *p = x + b * (int64_t)nz * n_inner + i;
+        T acc = 0;
+        for (int k = 0; k < nz; ++k) acc += p[(int64_t)k * n_inner];
+        out[c] = acc + addend;
+    }
+}
+
+// compute_blending_weights: (ps - p) / (ps - pb) where p > pb, else 1
+template <typename T>
+__global__ void blend_weights_kernel(const T *__restrict__ pb, const T *__restrict__ ps, const T *__restrict__ pfull,
+                                     T *__restrict__ out, int64_t n_batch, int nz, int64_t n_inner)
+{
+    const int64_t total = n_batch * nz * n_inner;
+    for (int64_t idx = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; idx < total; idx += (int64_t)gridDim.x * blockDim.x) {
+        const int64_t i = idx % n_inner, b = idx / (n_inner * nz);
+        const T p = pfull[idx], s = ps[b * n_inner + i], q = pb[b * n_inner + i];
+        out[idx] = (p > q) ? (s - p) / (s - q) : (T)1;
+    }
+}
+
+// _impose_hydrostatic_balance: DZ from the hypsometric equation with the virtual temperature, phis such
+// that the model-top height is unchanged
+template <typename T>
+__global__ void hydrostatic_kernel(const T *__restrict__ dz, const T *__restrict__ phis, const T *__restrict__ t,
+                                   const T *__restrict__ q, const T *__restrict__ delp, T *__restrict__ dz_out,
+                                   T *__restrict__ phis_out, int64_t n_batch, int nz, int64_t n_inner, T toa)
+{
+    const T g = (T)9.80665, rd = (T)287.05, rv = (T)461.5;
+    const int64_t ncol = n_batch * n_inner;
+    for (int64_t c = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; c < ncol; c += (int64_t)gridDim.x * blockDim.x) {
+        const int64_t b = c / n_inner, i = c - b * n_inner;
+        const int64_t base = b * (int64_t)nz * n_inner + i;
+        // height of the model top: cumulative sum from the surface upwards of [-dz..., phis / g]
+        T top = phis[c] / g;
+        for (int k = nz - 1; k >= 0; --k) top = top + (-dz[base + (int64_t)k * n_inner]);
+        // new thicknesses
+        T p_hi = toa, lp_hi = log(p_hi), sum = 0;
+        for (int k = 0; k < nz; ++k) {
+            const int64_t o = base + (int64_t)k * n_inner;
+            const T p_lo = p_hi + delp[o];
+            const T lp_lo = log(p_lo);
+            const T tv = t[o] * ((T)1 + (rv / rd - (T)1) * q[o]);
+            const T d = -(lp_lo - lp_hi) * rd * tv / g;
+            dz_out[o] = d;
+            sum += d;
+            p_hi = p_lo;
+            lp_hi = lp_lo;
+        }
+        phis_out[c] = g * (top + sum);
+    }
+}
+
 }  // namespace
 }  // namespace fv3hip
 
@@ -884,4 +950,71 @@ extern "C" int fv3hip_interpolate_2d(const void *xp, const void *x, const void *
                        static_cast<const double *>(xp), static_cast<const double *>(x), static_cast<const double *>(y),
                        static_cast<double *>(out), fill_value, n_batch, n_inner, n_in, n_out, layout);
     return check_launch("interpolate_2d_kernel");
+}
+
+namespace {
+inline unsigned col_grid(int64_t n)
+{
+    int64_t b = ceil_div(n, 256);
+    return (unsigned)(b > 256 * 64 ? 256 * 64 : (b < 1 ? 1 : b));
+}
+}  // namespace
+
+extern "C" int fv3hip_column_sum(const void *x, int dtype, int64_t n_batch, int nz, int64_t n_inner, double addend, void *out,
+                                 void *stream)
+{
+    FV3HIP_REQUIRE(dtype == FV3HIP_F32 || dtype == FV3HIP_F64, "dtype must be F32 or F64");
+    FV3HIP_REQUIRE(n_batch >= 0 && nz >= 0 && n_inner >= 0, "negative extent");
+    if (n_batch * n_inner == 0) return FV3HIP_OK;
+    FV3HIP_REQUIRE(x && out, "null pointer");
+    hipStream_t st = as_stream(stream);
+    if (dtype == FV3HIP_F64)
+        hipLaunchKernelGGL((column_sum_kernel<double>), dim3(col_grid(n_batch * n_inner)), dim3(256), 0, st,
+                           static_cast<const double *>(x), static_cast<double *>(out), n_batch, nz, n_inner, addend);
+    else
+        hipLaunchKernelGGL((column_sum_kernel<float>), dim3(col_grid(n_batch * n_inner)), dim3(256), 0, st,
+                           static_cast<const float *>(x), static_cast<float *>(out), n_batch, nz, n_inner, (float)addend);
+    return check_launch("column_sum_kernel");
+}
+
+extern "C" int fv3hip_blend_weights(const void *blending_pressure, const void *ps_coarse, const void *pfull_coarse, int dtype,
+                                    int64_t n_batch, int nz, int64_t n_inner, void *out, void *stream)
+{
+    FV3HIP_REQUIRE(dtype == FV3HIP_F32 || dtype == FV3HIP_F64, "dtype must be F32 or F64");
+    FV3HIP_REQUIRE(n_batch >= 0 && nz >= 0 && n_inner >= 0, "negative extent");
+    const int64_t total = n_batch * nz * n_inner;
+    if (total == 0) return FV3HIP_OK;
+    FV3HIP_REQUIRE(blending_pressure && ps_coarse && pfull_coarse && out, "null pointer");
+    hipStream_t st = as_stream(stream);
+    if (dtype == FV3HIP_F64)
+        hipLaunchKernelGGL((blend_weights_kernel<double>), dim3(col_grid(total)), dim3(256), 0, st,
+                           static_cast<const double *>(blending_pressure), static_cast<const double *>(ps_coarse),
+                           static_cast<const double *>(pfull_coarse), static_cast<double *>(out), n_batch, nz, n_inner);
+    else
+        hipLaunchKernelGGL((blend_weights_kernel<float>), dim3(col_grid(total)), dim3(256), 0, st,
+                           static_cast<const float *>(blending_pressure), static_cast<const float *>(ps_coarse),
+                           static_cast<const float *>(pfull_coarse), static_cast<float *>(out), n_batch, nz, n_inner);
+    return check_launch("blend_weights_kernel");
+}
+
+extern "C" int fv3hip_hydrostatic_balance(const void *dz, const void *phis, const void *t, const void *q, const void *delp,
+                                          int dtype, int64_t n_batch, int nz, int64_t n_inner, double toa_pressure,
+                                          void *dz_out, void *phis_out, void *stream)
+{
+    FV3HIP_REQUIRE(dtype == FV3HIP_F32 || dtype == FV3HIP_F64, "dtype must be F32 or F64");
+    FV3HIP_REQUIRE(n_batch >= 0 && nz >= 0 && n_inner >= 0, "negative extent");
+    if (n_batch * n_inner == 0) return FV3HIP_OK;
+    FV3HIP_REQUIRE(dz && phis && t && q && delp && dz_out && phis_out, "null pointer");
+    hipStream_t st = as_stream(stream);
+    if (dtype == FV3HIP_F64)
+        hipLaunchKernelGGL((hydrostatic_kernel<double>), dim3(col_grid(n_batch * n_inner)), dim3(256), 0, st,
+                           static_cast<const double *>(dz), static_cast<const double *>(phis), static_cast<const double *>(t),
+                           static_cast<const double *>(q), static_cast<const double *>(delp), static_cast<double *>(dz_out),
+                           static_cast<double *>(phis_out), n_batch, nz, n_inner, toa_pressure);
+    else
+        hipLaunchKernelGGL((hydrostatic_kernel<float>), dim3(col_grid(n_batch * n_inner)), dim3(256), 0, st,
+                           static_cast<const float *>(dz), static_cast<const float *>(phis), static_cast<const float *>(t),
+                           static_cast<const float *>(q), static_cast<const float *>(delp), static_cast<float *>(dz_out),
+                           static_cast<float *>(phis_out), n_batch, nz, n_inner, (float)toa_pressure);
+    return check_launch("hydrostatic_kernel");
 }

@@ -369,8 +369,9 @@ def block_edge_coarsen(obj, coarsening_factor: int, x_dim="xaxis_1", y_dim="yaxi
             return da
         if da.sizes[coarsen_dim] % f:
             raise ValueError(f"Could not coarsen a dimension of size {da.sizes[coarsen_dim]} with window {f}")
-        out = _block_reduce_da(da, fy, fx, f, f, method, x_dim, y_dim, {coarsen_dim: f}, coord_func, require_exact=False)
         down = _coarsen_downsample_coordinate(da, downsample_dim, f, coord_func)
+        bare = da._replace(coords={k: v for k, v in da.coords.items() if k != downsample_dim})
+        out = _block_reduce_da(bare, fy, fx, f, f, method, x_dim, y_dim, {coarsen_dim: f}, coord_func, require_exact=False)
         if down is not None:
             out = out.assign_coords({downsample_dim: down})
         return out

@@ -205,6 +205,57 @@ def block_upsample(x: torch.Tensor, factor: int) -> torch.Tensor:
     return out
 
 
+def _column_view(x: torch.Tensor, z_axis: int):
+    z_axis = z_axis % x.dim()
+    return z_axis, _prod(x.shape[:z_axis]), int(x.shape[z_axis]), _prod(x.shape[z_axis + 1:])
+
+
+def column_sum(x: torch.Tensor, z_axis: int, addend: float = 0.0) -> torch.Tensor:
+    """``x.sum(z_axis) + addend`` (surface_pressure_from_delp, vertically_dependent.py:189-208)."""
+    dev = _require_device(x)
+    code = _float_code(x)
+    x = x.contiguous()
+    z_axis, nb, nz, ni = _column_view(x, z_axis)
+    out = torch.empty(tuple(x.shape[:z_axis]) + tuple(x.shape[z_axis + 1:]), dtype=x.dtype, device=dev)
+    _lib.call("fv3hip_column_sum", _ptr(x), code, nb, nz, ni, float(addend), _ptr(out), _stream(dev))
+    return out
+
+
+def blend_weights(blending_pressure: torch.Tensor, ps_coarse: torch.Tensor, pfull_coarse: torch.Tensor, z_axis: int) -> torch.Tensor:
+    """``(ps - p) / (ps - pb)`` where ``p > pb`` else 1 (coarsen_restarts.py:559-576); ``pfull_coarse`` has
+    the z axis, the other two the same shape without it."""
+    dev = _require_device(blending_pressure, ps_coarse, pfull_coarse)
+    code = _float_code(pfull_coarse)
+    p = pfull_coarse.contiguous()
+    z_axis, nb, nz, ni = _column_view(p, z_axis)
+    pb, ps = blending_pressure.to(p.dtype).contiguous(), ps_coarse.to(p.dtype).contiguous()
+    want = tuple(p.shape[:z_axis]) + tuple(p.shape[z_axis + 1:])
+    if tuple(pb.shape) != want or tuple(ps.shape) != want:
+        raise ValueError(f"blending and surface pressures must have shape {want}")
+    out = torch.empty_like(p)
+    _lib.call("fv3hip_blend_weights", _ptr(pb), _ptr(ps), _ptr(p), code, nb, nz, ni, _ptr(out), _stream(dev))
+    return out
+
+
+def hydrostatic_balance(dz: torch.Tensor, phis: torch.Tensor, t: torch.Tensor, q: torch.Tensor, delp: torch.Tensor,
+                        toa_pressure: float, z_axis: int):
+    """Hydrostatic layer thicknesses and the surface geopotential that keeps the model-top height
+    (coarsen_restarts.py:990-1017).  Returns (dz, phis)."""
+    dev = _require_device(dz, phis, t, q, delp)
+    dt = torch.float64 if any(a.dtype == torch.float64 for a in (dz, phis, t, q, delp)) else torch.float32
+    dz, phis, t, q, delp = (a.to(dt).contiguous() for a in (dz, phis, t, q, delp))
+    z_axis, nb, nz, ni = _column_view(dz, z_axis)
+    for a in (t, q, delp):
+        if tuple(a.shape) != tuple(dz.shape):
+            raise ValueError("DZ, T, sphum and delp must have the same shape")
+    if tuple(phis.shape) != tuple(dz.shape[:z_axis]) + tuple(dz.shape[z_axis + 1:]):
+        raise ValueError("phis must have DZ's shape without the vertical axis")
+    dz_out, phis_out = torch.empty_like(dz), torch.empty_like(phis)
+    _lib.call("fv3hip_hydrostatic_balance", _ptr(dz), _ptr(phis), _ptr(t), _ptr(q), _ptr(delp), _DTYPE_CODE[dt], nb, nz, ni,
+              float(toa_pressure), _ptr(dz_out), _ptr(phis_out), _stream(dev))
+    return dz_out, phis_out
+
+
 def interpolate_2d(xp: torch.Tensor, x: torch.Tensor, y: torch.Tensor, fill_value: float = float("nan"),
                    z_axis: int = -1) -> torch.Tensor:
     """``mappm.interpolate_2d`` (interpolate_2d.f90:1-28): linear interpolation of ``y(x)`` onto ``xp``
@@ -228,7 +279,7 @@ def interpolate_2d(xp: torch.Tensor, x: torch.Tensor, y: torch.Tensor, fill_valu
 
 
 EW_OPS = {"mul": 0, "isclose": 1, "isclose_s": 2, "where_nan": 3, "select": 4, "select_s": 5, "gt_s": 6, "lt_s": 7,
-          "fillna_s": 8, "and": 9, "min_s": 10}
+          "fillna_s": 8, "and": 9, "min_s": 10, "blend": 11, "mul_s": 12}
 
 
 def ew(op: str, a: torch.Tensor, b: Optional[torch.Tensor] = None, c: Optional[torch.Tensor] = None,

@@ -148,6 +148,8 @@ int fv3hip_block_upsample(const void *in, int elem_size, int64_t n_outer, int ny
 #define FV3HIP_EW_FILLNA_S 8   /* a.fillna(scalar)                                   */
 #define FV3HIP_EW_AND 9        /* a & b                                              */
 #define FV3HIP_EW_MIN_S 10     /* a.where(a < scalar, other=scalar)                  */
+#define FV3HIP_EW_BLEND 11     /* coarsen_restarts.blend: a * b + (1 - a) * c         */
+#define FV3HIP_EW_MUL_S 12     /* scalar * a                                          */
 int fv3hip_ew(int op, const void *a, const void *b, const void *c, double scalar, int dtype,
               int64_t n, int64_t inner, int64_t b_rep, int64_t c_rep, void *out, void *stream);
 
@@ -315,6 +317,26 @@ int fv3hip_timer_start(fv3hip_timer_t t, void *stream);
 int fv3hip_timer_stop(fv3hip_timer_t t, void *stream);
 int fv3hip_timer_elapsed_ms(fv3hip_timer_t t, float *ms); /* synchronises on the stop event */
 int fv3hip_timer_destroy(fv3hip_timer_t t);
+
+/*
+ * Column helpers of the restart pipelines coarsen_restarts_on_pressure / _via_blended_method
+ * (external/vcm/vcm/cubedsphere/coarsen_restarts.py:559-676, 990-1017).  Arrays are
+ * [n_batch][nz][n_inner]; per-column results [n_batch][n_inner].
+ *   fv3hip_column_sum          surface_pressure_from_delp (vertically_dependent.py:189-208): sum_k x + addend
+ *   fv3hip_blend_weights       compute_blending_weights (coarsen_restarts.py:559-576)
+ *   fv3hip_hydrostatic_balance _impose_hydrostatic_balance (coarsen_restarts.py:990-1017 with
+ *                              height_at_interface, hydrostatic_dz, dz_and_top_to_phis,
+ *                              vertically_dependent.py:69-99, 182-186, 211-235)
+ */
+int fv3hip_column_sum(const void *x, int dtype, int64_t n_batch, int nz, int64_t n_inner,
+                      double addend, void *out, void *stream);
+int fv3hip_blend_weights(const void *blending_pressure, const void *ps_coarse,
+                         const void *pfull_coarse, int dtype, int64_t n_batch, int nz,
+                         int64_t n_inner, void *out, void *stream);
+int fv3hip_hydrostatic_balance(const void *dz, const void *phis, const void *t, const void *q,
+                               const void *delp, int dtype, int64_t n_batch, int nz,
+                               int64_t n_inner, double toa_pressure, void *dz_out,
+                               void *phis_out, void *stream);
 
 /*
  * Replaces mappm.interpolate_2d (external/mappm/mappm/interpolate_2d.f90:1-28; called from

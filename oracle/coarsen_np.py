@@ -291,3 +291,49 @@ def non_negative_sphum_mse_conserving(sphum, q2, dt, q1=None):
         return q2_new, None
     mse = _HEAT_CAPACITY * q1 + _LV0 * q2
     return q2_new, (mse - _LV0 * q2_new) / _HEAT_CAPACITY
+
+
+# ---------------------------------------------------------------------------------------------
+# blended pressure-level / model-level coarse-graining (coarsen_restarts.py:559-676)
+# ---------------------------------------------------------------------------------------------
+SIGMA_BLEND = 0.9
+
+
+def surface_pressure_from_delp(delp, toa_pressure, z_axis):
+    """vertically_dependent.py:189-208: delp.sum(z) + p_toa."""
+    return np.asarray(delp).sum(axis=z_axis) + toa_pressure
+
+
+def compute_blending_weights(blending_pressure, ps_coarse, pfull_coarse, z_axis):
+    """coarsen_restarts.py:559-576; ``pfull_coarse`` has the z axis, the other two do not."""
+    ps = np.expand_dims(ps_coarse, z_axis)
+    pb = np.expand_dims(blending_pressure, z_axis)
+    with np.errstate(divide="ignore", invalid="ignore"):
+        w = (ps - pfull_coarse) / (ps - pb)
+    return np.where(pfull_coarse > pb, w, 1.0)
+
+
+def blending_weights_agrid(delp, area, toa_pressure, factor):
+    """coarsen_restarts.py:579-622 for delp [tile, z, y, x], area [tile, y, x]."""
+    delp_c = weighted_block_average(delp, area[:, None], factor)
+    pfull_c = pressure_at_midpoint_log(delp_c, toa_pressure, 1)
+    ps = surface_pressure_from_delp(delp, toa_pressure, 1)
+    ps_c = surface_pressure_from_delp(delp_c, toa_pressure, 1)
+    pb = SIGMA_BLEND * block_coarsen(ps, factor, "min")
+    return compute_blending_weights(pb, ps_c, pfull_c, 1)
+
+
+def blending_weights_dgrid(delp, length, toa_pressure, factor, edge):
+    """coarsen_restarts.py:625-661: the same on the cell edges the ``edge`` wind component lives on."""
+    delp_e = interp_center_to_outer(delp, "x" if edge == "y" else "y")
+    delp_ec = edge_weighted_block_average(delp_e, length[:, None], factor, edge)
+    pfull_c = pressure_at_midpoint_log(delp_ec, toa_pressure, 1)
+    ps = surface_pressure_from_delp(delp_e, toa_pressure, 1)
+    ps_c = surface_pressure_from_delp(delp_ec, toa_pressure, 1)
+    pb = SIGMA_BLEND * block_edge_coarsen(ps, factor, edge, "min")
+    return compute_blending_weights(pb, ps_c, pfull_c, 1)
+
+
+def blend(weights, pressure_level, model_level):
+    """coarsen_restarts.py:664-676."""
+    return weights * pressure_level + (1 - weights) * model_level

@@ -103,31 +103,17 @@ def make_interpolate_2d():
     print("interpolate_2d cases: 4")
 
 
-COVERED = {
-    "area-weighted-model-level-without-agrid-winds": {
-        "fv_core.res": ["phis", "delp", "DZ", "W", "T", "u", "v"],
-        "fv_tracer.res": ["cld_amt", "sphum", "liq_wat", "rainwat", "ice_wat", "snowwat", "graupel", "o3mr", "sgs_tke"],
-        "fv_srf_wnd.res": ["u_srf", "v_srf"],
-        # the 'complex' surface-data method (coarsen_restarts.py:1111-1470); identical for every tag
-        "sfc_data": ["slmsk", "vtype", "stype", "tsea", "sheleg", "tg3", "zorl", "alvsf", "alvwf", "alnsf", "alnwf", "facsf",
-                     "facwf", "vfrac", "canopy", "f10m", "t2m", "q2m", "uustar", "ffmm", "ffhh", "hice", "fice", "tisfc",
-                     "tprcp", "srflag", "snwdph", "shdmin", "shdmax", "slope", "snoalb", "sncovr", "stc", "smc", "slc"],
-    },
-    "mass-weighted-model-level-with-agrid-winds": {
-        "fv_core.res": ["phis", "delp", "DZ", "W", "T", "ua", "va", "u", "v"],
-        "fv_tracer.res": ["cld_amt", "sphum", "liq_wat", "rainwat", "ice_wat", "snowwat", "graupel", "o3mr", "sgs_tke"],
-        "fv_srf_wnd.res": ["u_srf", "v_srf"],
-    },
-    "pressure-level-with-agrid-winds": {
-        "fv_core.res": ["delp", "W", "T", "ua", "va", "u", "v"],
-        "fv_tracer.res": ["cld_amt", "sphum", "liq_wat", "rainwat", "ice_wat", "snowwat", "graupel", "o3mr", "sgs_tke"],
-        "fv_srf_wnd.res": ["u_srf", "v_srf"],
-    },
-    "pressure-level-extrapolate-with-agrid-winds": {
-        "fv_core.res": ["delp", "W", "T", "u", "v"],
-        "fv_tracer.res": ["cld_amt", "sphum", "sgs_tke"],
-    },
+# every configuration of the reference's regression test (test_coarsen_restarts.py:32-61): function, kwargs
+CONFIGS = {
+    "mass-weighted-model-level-with-agrid-winds": ("sigma", {"coarsen_agrid_winds": True, "mass_weighted": True}),
+    "area-weighted-model-level-without-agrid-winds": ("sigma", {"coarsen_agrid_winds": False, "mass_weighted": False}),
+    "pressure-level-with-agrid-winds": ("pressure", {"coarsen_agrid_winds": True, "extrapolate": False}),
+    "pressure-level-without-agrid-winds": ("pressure", {"coarsen_agrid_winds": False}),
+    "blended-mass-weighted-with-agrid-winds": ("blended", {"coarsen_agrid_winds": True}),
+    "blended-area-weighted-without-agrid-winds": ("blended", {"coarsen_agrid_winds": False, "mass_weighted": False}),
+    "pressure-level-extrapolate-with-agrid-winds": ("pressure", {"coarsen_agrid_winds": False, "extrapolate": True}),
 }
+CATEGORIES = ["fv_core.res", "fv_tracer.res", "fv_srf_wnd.res", "sfc_data"]
 
 
 def make_coarsen_restarts():
@@ -143,12 +129,20 @@ def make_coarsen_restarts():
             name: {"dims": v["dims"], "shape": v["array"]["shape"], "dtype": v["array"]["dtype"]}
             for name, v in schema["variables"].items()
         }
-    for tag, cats in COVERED.items():
-        for category, variables in cats.items():
+    meta["configs"] = {tag: {"method": m, "kwargs": kw} for tag, (m, kw) in CONFIGS.items()}
+    sfc_seen = None
+    for tag in CONFIGS:
+        for category in CATEGORIES:
             with open(os.path.join(base, "reference", f"{tag}-{category}.json")) as f:
                 ref = json.load(f)
-            for var in variables:
-                entry = ref["data_vars"][var]
+            if category == "sfc_data":  # identical for every configuration: stored once
+                blob = json.dumps({k: v["data"] for k, v in ref["data_vars"].items()}, sort_keys=True)
+                if sfc_seen is None:
+                    sfc_seen = blob
+                else:
+                    assert blob == sfc_seen, tag
+                    continue
+            for var, entry in ref["data_vars"].items():
                 key = f"{tag}|{category}|{var}"
                 arrays[key] = np.array(entry["data"], dtype=np.float64)
                 meta["expected"].append({"key": key, "tag": tag, "category": category, "variable": var,

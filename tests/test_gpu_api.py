@@ -252,8 +252,8 @@ def test_coarsen_restarts_regression_fixtures(tag):
 
     checked = 0
     for key, (entry, want) in expected.items():
-        if entry["tag"] != tag:
-            continue
+        if (entry["tag"] != tag and entry["category"] != "sfc_data") or (entry["category"], entry["variable"]) not in got:
+            continue  # the sfc_data fixtures are the same for every tag and stored once
         want, dims = _squeeze_time(entry["dims"], want)
         res = got[(entry["category"], entry["variable"])].transpose(*dims).values
         assert res.shape == want.shape, key
@@ -274,6 +274,73 @@ def test_coarsen_restarts_regression_fixtures(tag):
             np.testing.assert_allclose(res, want, rtol=1e-5, atol=1e-8, err_msg=key)
         checked += 1
     assert checked >= 6
+
+
+ALL_TAGS = ["area-weighted-model-level-without-agrid-winds", "mass-weighted-model-level-with-agrid-winds",
+            "pressure-level-with-agrid-winds", "pressure-level-without-agrid-winds",
+            "pressure-level-extrapolate-with-agrid-winds", "blended-area-weighted-without-agrid-winds",
+            "blended-mass-weighted-with-agrid-winds"]
+
+
+@pytest.mark.parametrize("keep_time", [False, True])
+@pytest.mark.parametrize("tag", ALL_TAGS)
+def test_coarsen_restarts_pipelines(tag, keep_time):
+    """coarsen_restarts_on_sigma / _on_pressure / _via_blended_method called the way the reference's
+    regression test calls them (external/vcm/tests/test_coarsen_restarts.py:32-61,108-127): every array
+    of every category of every configuration against the reference's fixture values."""
+    from fv3net_amd.cubedsphere import (coarsen_restarts_on_pressure, coarsen_restarts_on_sigma,
+                                        coarsen_restarts_via_blended_method)
+
+    meta, expected = cases.load()
+    inp = cases.inputs(meta)
+    cfg = meta["configs"][tag]
+
+    def dataset(category):
+        out = Dataset()
+        for v, (dims, arr) in inp[category].items():
+            if not keep_time:
+                arr, dims = _squeeze_time(dims, arr)
+            out[v] = DataArray(arr, dims=dims, name=v)
+        return out
+
+    restarts = {c: dataset(c) for c in ("fv_core.res", "fv_tracer.res", "fv_srf_wnd.res", "sfc_data")}
+    before = {c: {v: restarts[c][v].values.copy() for v in restarts[c]} for c in restarts}
+    grid_spec = dataset("grid")
+    if cfg["method"] == "sigma":
+        got = coarsen_restarts_on_sigma(meta["factor"], grid_spec, restarts, **cfg["kwargs"])
+    elif cfg["method"] == "pressure":
+        got = coarsen_restarts_on_pressure(meta["factor"], grid_spec, meta["toa_pressure"], restarts, **cfg["kwargs"])
+    else:
+        got = coarsen_restarts_via_blended_method(meta["factor"], grid_spec, meta["toa_pressure"], restarts, **cfg["kwargs"])
+    assert set(got) == set(restarts)
+    for c in restarts:  # inputs untouched
+        for v in restarts[c]:
+            np.testing.assert_array_equal(restarts[c][v].values, before[c][v])
+
+    remapped = cfg["method"] in ("pressure", "blended")
+    checked = 0
+    for key, (entry, want) in expected.items():
+        if entry["tag"] != tag and entry["category"] != "sfc_data":
+            continue
+        category, var = entry["category"], entry["variable"]
+        res = got[category][var]
+        dims = list(entry["dims"])
+        if not keep_time:
+            want, dims = _squeeze_time(dims, want)
+        assert list(res.dims) == dims, key  # _sync_dimension_order: the input's dimension order
+        res = res.values
+        assert res.shape == want.shape, key
+        assert np.array_equal(np.isnan(res), np.isnan(want)), key
+        if category == "sfc_data" and var in ("slmsk", "vtype", "stype", "srflag", "slope"):
+            np.testing.assert_array_equal(res, want.astype(res.dtype), err_msg=key)  # block modes: bit-exact
+        elif remapped and category in ("fv_core.res", "fv_tracer.res") and var not in ("delp",):
+            # fields that went through mappm (or, for DZ/phis, were rebuilt from them by hydrostatic
+            # balance): see the tolerance note in test_coarsen_restarts_regression_fixtures
+            np.testing.assert_allclose(res, want, rtol=1e-5, atol=2e-5 * np.nanmax(np.abs(want)), err_msg=key)
+        else:
+            np.testing.assert_allclose(res, want, rtol=1e-5, atol=1e-8, err_msg=key)
+        checked += 1
+    assert checked >= 53
 
 
 # ------------------------------------------------------------------------------------------------
