@@ -1,7 +1,9 @@
 """Configuration of the online hooks (external/emulation/emulation/config.py:120-324): a regressor
 at ``path`` in the ``HipEmulator`` format plus the reference's post-processing options -- range and
 level masks, cloud squashing and the Zhao-Carr conservation fixes -- composed in the reference's
-order (config.py:175-221) and run on the device.  The classifier model, tensor transforms, the
+order (config.py:175-221) and run on the device.  ``path`` / ``classifier_path`` name saved "dense" or
+"dense-local" emulators (``models.load_emulator``); their tensor transforms are part of the saved
+model, as they are part of the reference's SavedModel graph.  Config-level tensor transforms, the
 online schedule and the zarr monitor are not part of this build and are rejected loudly rather than
 silently ignored."""
 import dataclasses
@@ -13,11 +15,11 @@ import yaml
 from . import zhao_carr
 from .hook import MicrophysicsHook
 from .masks import LevelMask, Mask, RangeMask, compose_masks
-from .models import HipEmulator
+from .models import combine_classifier_and_regressor, load_emulator
 
 logger = logging.getLogger("emulation")
 
-_UNIMPLEMENTED = ("classifier_path", "tensor_transform", "online_schedule")
+_UNIMPLEMENTED = ("tensor_transform", "online_schedule")
 _FLAGS = (
     "gscond_cloud_conservative", "mask_gscond_identical_cloud", "mask_gscond_zero_cloud", "enforce_conservative",
     "enforce_conservative_phase_dependent", "mask_gscond_zero_cloud_classifier", "mask_gscond_no_tend_classifier",
@@ -49,6 +51,7 @@ class ModelConfig:
     attributes are the reference's (config.py:62-136)."""
 
     path: Optional[str] = None
+    classifier_path: Optional[str] = None
     ranges: Mapping[str, Range] = dataclasses.field(default_factory=dict)
     mask_emulator_levels: Mapping[str, LevelSlice] = dataclasses.field(default_factory=dict)
     cloud_squash: Optional[float] = None
@@ -84,11 +87,13 @@ class ModelConfig:
             kwargs["cloud_squash"] = float(d["cloud_squash"])
         kwargs["ranges"] = {k: Range(**v) for k, v in (d.get("ranges") or {}).items()}
         kwargs["mask_emulator_levels"] = {k: LevelSlice(**v) for k, v in (d.get("mask_emulator_levels") or {}).items()}
-        return ModelConfig(path=d.get("path"), batch_size=int(d.get("batch_size", 512)), **kwargs)
+        return ModelConfig(path=d.get("path"), classifier_path=d.get("classifier_path"), batch_size=int(d.get("batch_size", 512)), **kwargs)
 
     def build(self) -> MicrophysicsHook:
         if self.path:
-            model = HipEmulator.load(self.path)
+            regressor = load_emulator(self.path)
+            classifier = load_emulator(self.classifier_path) if self.classifier_path is not None else None
+            model = combine_classifier_and_regressor(classifier, regressor, self.batch_size)
         else:
             def model(x):
                 return x

@@ -45,7 +45,8 @@ class MicrophysicsHook:
             dev_state = {name: on_device(v) if isinstance(v, np.ndarray) else v for name, v in state.items()}
             inputs = {name: v.t() if v.dim() == 2 else v for name, v in dev_state.items() if hasattr(v, "dim")}
             predictions = self.model(inputs)
-            model_outputs = {name: (t.t() if t.dim() == 2 else t) for name, t in predictions.items()}
+            # numpy's .T: reverse all axes ([sample, z, class] logits -> [class, z, sample])
+            model_outputs = {name: t.permute(*reversed(range(t.dim()))) for name, t in predictions.items()}
             model_outputs.update(self.mask(dev_state, model_outputs))
             state.update({name: (t.cpu().numpy() if hasattr(t, "cpu") else t) for name, t in model_outputs.items()})
             self._maybe_garbage_collect()

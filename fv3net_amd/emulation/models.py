@@ -1,6 +1,8 @@
 """The emulator as a callable on the Fortran state, replacing
 ``emulation.models.ModelWithClassifier`` + ``transform_model``
-(external/emulation/emulation/models.py:14-65) for regressors with the "dense" architecture.
+(external/emulation/emulation/models.py:14-65) for models with the "dense" architecture
+(``HipEmulator``) and the "dense-local" one (``HipLocalEmulator``: the reference's production gscond
+regressor and its classifier).
 
 The reference wraps a Keras model: log / difference transforms forward, ``model.predict`` in
 Python-level mini-batches of ``batch_size`` columns, transforms backward.  Here the transforms,
@@ -15,7 +17,9 @@ import torch
 import yaml
 
 from ..cubedsphere._device import compute_device, on_device
+from ..local_mlp import LocalMlpModel, LocalMlpSpec
 from ..mlp import MlpModel, MlpSpec
+from . import zhao_carr
 
 
 class HipEmulator:
@@ -87,3 +91,163 @@ class HipEmulator:
         with np.load(os.path.join(path, cls._WEIGHTS_FILENAME), allow_pickle=False) as z:
             arrays = {k: z[k] for k in z.files}
         return cls(MlpSpec.from_arrays(meta, arrays))
+
+
+class HipLocalEmulator:
+    """A "dense-local" model (``LocalMlpSpec``) with the interface of ``HipEmulator``: dicts of
+    ``[sample, feature]`` (or ``[sample]``) arrays in and out; multi-channel outputs (classifier logits)
+    come back as ``[sample, feature, channel]`` like the Keras model's."""
+
+    device_resident = True
+    _SPEC_FILENAME = HipEmulator._SPEC_FILENAME
+    _WEIGHTS_FILENAME = HipEmulator._WEIGHTS_FILENAME
+
+    def __init__(self, spec: LocalMlpSpec, inputs_to_ignore: Sequence[str] = ("rank", "model_time")):
+        self.spec = spec
+        self.inputs_to_ignore = tuple(inputs_to_ignore)
+        self._model = None
+
+    @property
+    def model(self) -> LocalMlpModel:
+        if self._model is None:
+            self._model = LocalMlpModel(self.spec, device=compute_device())
+        return self._model
+
+    @property
+    def input_variables(self):
+        return self.spec.sources
+
+    @property
+    def output_variables(self):
+        return self.spec.output_names
+
+    def __call__(self, state: Mapping[str, np.ndarray]) -> Dict[str, np.ndarray]:
+        sources = {}
+        on_gpu = False
+        for name in self.spec.sources:
+            a = state[name]
+            if isinstance(a, torch.Tensor):
+                on_gpu = on_gpu or a.is_cuda
+                t = on_device(a)
+            else:
+                a = np.asarray(a)
+                # [sample, feature] views of call_py_fort's [feature, sample] arrays go up as they are
+                t = on_device(a.T).t() if a.ndim == 2 and a.T.flags.c_contiguous else on_device(a)
+            sources[name] = t.t() if t.dim() == 2 else t
+        outs = self.model.predict(sources)
+        result = {}
+        for name, t in outs.items():
+            t = t.permute(*reversed(range(t.dim())))  # [sample, feature(, channel)] view
+            result[name] = t if on_gpu else t.cpu().numpy()
+        return result
+
+    def dump(self, path: str) -> None:
+        os.makedirs(path, exist_ok=True)
+        meta, arrays = self.spec.to_arrays()
+        np.savez(os.path.join(path, self._WEIGHTS_FILENAME), **arrays)
+        with open(os.path.join(path, self._SPEC_FILENAME), "w") as f:
+            yaml.safe_dump(meta, f)
+
+    @classmethod
+    def load(cls, path: str) -> "HipLocalEmulator":
+        return load_emulator(path, expect=cls)
+
+
+def load_emulator(path: str, expect=None):
+    """Load a saved emulator directory; ``spec.yaml``'s ``architecture`` key ("dense" when absent,
+    "dense-local") selects the class -- the counterpart of ``tf.keras.models.load_model`` in
+    external/emulation/emulation/config.py:39-44."""
+    with open(os.path.join(path, HipEmulator._SPEC_FILENAME)) as f:
+        meta = yaml.safe_load(f)
+    with np.load(os.path.join(path, HipEmulator._WEIGHTS_FILENAME), allow_pickle=False) as z:
+        arrays = {k: z[k] for k in z.files}
+    arch = meta.get("architecture", "dense")
+    if arch == "dense-local":
+        model = HipLocalEmulator(LocalMlpSpec.from_arrays(meta, arrays))
+    elif arch == "dense":
+        model = HipEmulator(MlpSpec.from_arrays(meta, arrays))
+    else:
+        raise NotImplementedError(f"architecture {arch!r} is not implemented on the device (dense, dense-local are)")
+    if expect is not None and not isinstance(model, expect):
+        raise TypeError(f"{path} holds a {type(model).__name__}, not a {expect.__name__}")
+    return model
+
+
+def _get_classify_output(logit_classes, one_hot_axis: int = 0) -> Dict[str, object]:
+    """One-hot decode of the class logits (external/emulation/emulation/zhao_carr.py:193-198): every class
+    whose logit equals the maximum is hot; plus ``nontrivial_tendency``.  Device arrays stay on the device."""
+    names = zhao_carr.CLASS_NAMES  # sorted
+    if isinstance(logit_classes, torch.Tensor) and logit_classes.is_cuda:
+        from .. import _lib
+        from ..ops import _ptr, _require_device, _stream
+
+        moved = torch.movedim(logit_classes, one_hot_axis, 0)  # [class, *plane]
+        # the plane's dims in memory order: a [sample, z] view of [z, sample] memory is used as it lies
+        order = sorted(range(1, moved.dim()), key=lambda d: -moved.stride(d))
+        logits = moved.permute(0, *order)
+        if logits.dtype not in (torch.float32, torch.float64):
+            logits = logits.to(torch.float32)
+        logits = logits.contiguous()
+        n_class = int(logits.shape[0])
+        if n_class != len(names):
+            raise ValueError(f"expected {len(names)} classes along axis {one_hot_axis}, got {n_class}")
+        dev = _require_device(logits)
+        onehot = torch.empty(logits.shape, dtype=torch.uint8, device=dev)
+        both = torch.empty(logits.shape[1:], dtype=torch.uint8, device=dev)
+        _lib.call("fv3hip_classify_onehot", _ptr(logits), _lib.F64 if logits.dtype == torch.float64 else _lib.F32, n_class,
+                  both.numel(), _ptr(onehot), _ptr(both), names.index(zhao_carr.POSITIVE_TENDENCY),
+                  names.index(zhao_carr.NEGATIVE_TENDENCY), _stream(dev))
+        inverse = [order.index(d) for d in range(1, moved.dim())]  # back to the plane's own dim order (views)
+        d = {name: onehot[i].view(torch.bool).permute(*inverse) for i, name in enumerate(names)}
+        d["nontrivial_tendency"] = both.view(torch.bool).permute(*inverse)
+        return d
+    logits = np.asarray(logit_classes)
+    one_hot = logits == np.max(logits, axis=one_hot_axis, keepdims=True)
+    d = {name: np.take(one_hot, i, one_hot_axis) for i, name in enumerate(names)}
+    d["nontrivial_tendency"] = d[zhao_carr.POSITIVE_TENDENCY] | d[zhao_carr.NEGATIVE_TENDENCY]
+    return d
+
+
+class ModelWithClassifier:
+    """``model`` preceded by an optional ``classifier`` whose decoded classes are fed to the model and
+    returned with its outputs (external/emulation/emulation/models.py:14-53).  Both are callables on
+    dicts of ``[sample, feature]`` arrays (``HipEmulator`` / ``HipLocalEmulator``)."""
+
+    def __init__(self, model, classifier=None, class_key: str = "gscond_classes", batch_size: int = 1024,
+                 inputs_to_ignore: Sequence[str] = ("rank", "model_time")):
+        self.model = model
+        self.classifier = classifier
+        self._class_key = class_key
+        self._batch_size = batch_size  # accepted and ignored: a call is one launch over all columns
+        self.inputs_to_ignore = inputs_to_ignore
+
+    @property
+    def device_resident(self) -> bool:
+        return all(getattr(m, "device_resident", False) for m in (self.model, self.classifier) if m is not None)
+
+    def __call__(self, state):
+        state = {k: v for k, v in state.items() if k not in self.inputs_to_ignore}
+        if self.classifier is not None:
+            classifier_outputs = dict(self.classifier(state))
+            classifier_outputs.update(_get_classify_output(classifier_outputs[self._class_key], one_hot_axis=-1))
+        else:
+            classifier_outputs = {}
+        model_outputs = dict(self.model({**classifier_outputs, **state}))
+        model_outputs.update(classifier_outputs)
+        return model_outputs
+
+
+def combine_classifier_and_regressor(classifier, regressor, batch_size: int = 1024) -> ModelWithClassifier:
+    """external/emulation/emulation/models.py (used at config.py:146-148)."""
+    return ModelWithClassifier(regressor, classifier, batch_size=batch_size)
+
+
+def transform_model(model, transform):
+    """external/emulation/emulation/models.py:56-65."""
+
+    def combined(x):
+        x_transformed = transform.forward(x)
+        x_transformed.update(model(x_transformed))
+        return transform.backward(x_transformed)
+
+    return combined

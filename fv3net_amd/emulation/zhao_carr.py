@@ -23,6 +23,7 @@ RHO_WATER = 1000.0
 # sorted(fv3fit.emulation.transforms.zhao_carr.CLASS_NAMES) (transforms/zhao_carr.py:24-36)
 CLASS_NAMES = ["negative_tendency", "positive_tendency", "zero_cloud", "zero_tendency"]
 ZERO_CLOUD, ZERO_TENDENCY = "zero_cloud", "zero_tendency"
+POSITIVE_TENDENCY, NEGATIVE_TENDENCY = "positive_tendency", "negative_tendency"
 
 __all__ = [
     "infer_gscond_cloud_from_conservation", "squash_gscond", "squash_precpd", "mask_where_fortran_cloud_identical",

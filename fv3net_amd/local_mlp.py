@@ -1,0 +1,282 @@
+"""The "dense-local" microphysics emulator: one MLP shared by all levels, applied to every
+(level, column) point -- the architecture of the reference's production gscond regressor and of its
+classifier (projects/microphysics/configs/models/gscond.yaml:28-33, classifier.yaml:24-28;
+external/fv3fit/fv3fit/emulation/layers/architecture.py:518-527: ``combine_sequence_inputs`` ->
+``MLPBlock`` -> ``RNNOutput(share_conv_weights=True)``, i.e. kernel-size-1 convolutions).
+
+``LocalMlpSpec`` describes the saved model's whole graph: the forward tensor transforms the reference
+bakes into the SavedModel (log inputs), the per-level input normalisation (``FieldInput``), the
+network, the per-level output de-normalisation (``FieldOutput``) and the backward transforms
+(``ConditionallyScaledTransform.backward``, ``Difference.backward``).  ``LocalMlpModel`` runs it as
+three device steps: ``fv3hip_local_pack`` per input -> ``fv3hip_mlp_predict`` on the packed
+``[n_inputs][nz * ncol]`` array (a point is a sample) -> ``fv3hip_local_unpack`` per output channel.
+"""
+import dataclasses
+from typing import Dict, List, Mapping, Optional, Tuple
+
+import numpy as np
+import torch
+
+from . import _lib
+from .mlp import InputSpec, MlpModel, MlpSpec, OutputSpec
+from .ops import _ptr, _require_device, _stream
+
+
+@dataclasses.dataclass
+class LocalInput:
+    """One network input: array ``source`` ([nz, ncol], or [ncol] / [1, ncol] broadcast over the levels),
+    optionally ``log(max(x, eps))``, then ``(x - center[z]) / scale[z]``.  ``name`` is the network's
+    input name: inputs are concatenated sorted by it (architecture.py:53-75)."""
+
+    name: str
+    source: str
+    transform: str = "none"  # "none" | "log"
+    eps: float = 0.0
+    center: Optional[np.ndarray] = None  # scalar or [nz]; None = 0
+    scale: Optional[np.ndarray] = None   # scalar or [nz]; None = 1
+
+
+@dataclasses.dataclass
+class ConditionalScale:
+    """ConditionallyScaledTransform.backward (transforms.py:219-224): ``name = y * max(scale(on), min_scale)
+    + center(on)`` with ``scale``/``center`` piecewise constant in ``on`` over ``edges`` (left edges of the bins)."""
+
+    name: str
+    on: str
+    edges: np.ndarray   # [n_bins]
+    scale: np.ndarray   # [n_bins]
+    center: np.ndarray  # [n_bins]
+    min_scale: float = 0.0
+
+
+@dataclasses.dataclass
+class LocalOutput:
+    """One output variable with ``channels`` values per point.  channels == 1: ``[nz, ncol]`` fields,
+    de-normalised per level, optionally un-scaled conditionally and/or added to ``before``
+    (Difference.backward, ``after = before + difference``).  channels > 1 (classifier logits):
+    ``[channels, nz, ncol]``, unscaled."""
+
+    name: str
+    channels: int = 1
+    scale: Optional[np.ndarray] = None   # scalar or [nz]
+    center: Optional[np.ndarray] = None
+    conditional: Optional[ConditionalScale] = None
+    after: Optional[str] = None          # name of the Difference's `after` output
+    before: Optional[str] = None         # source array the difference is added to
+
+
+@dataclasses.dataclass
+class LocalMlpSpec:
+    inputs: List[LocalInput]            # in the network's (sorted-by-name) order
+    hidden_kernels: List[np.ndarray]    # Keras layout [in, out]
+    hidden_biases: List[np.ndarray]
+    outputs: List[LocalOutput]
+    out_kernel: np.ndarray              # [width, sum(channels)]
+    out_bias: np.ndarray
+    architecture = "dense-local"
+
+    @property
+    def sources(self) -> List[str]:
+        seen: List[str] = []
+        names = [i.source for i in self.inputs]
+        for o in self.outputs:
+            if o.conditional is not None:
+                names.append(o.conditional.on)
+            if o.before is not None:
+                names.append(o.before)
+        for n in names:
+            if n not in seen:
+                seen.append(n)
+        return seen
+
+    @property
+    def output_names(self) -> List[str]:
+        names = []
+        for o in self.outputs:
+            names.append(o.name)
+            if o.conditional is not None:
+                names.append(o.conditional.name)
+            if o.after is not None:
+                names.append(o.after)
+        return names
+
+    @property
+    def n_channels(self) -> int:
+        return sum(o.channels for o in self.outputs)
+
+    def validate(self):
+        if [i.name for i in self.inputs] != sorted(i.name for i in self.inputs):
+            raise ValueError("inputs must be listed sorted by their network name (combine_sequence_inputs)")
+        if not self.hidden_kernels or len(self.hidden_kernels) != len(self.hidden_biases):
+            raise ValueError("at least one hidden layer, one bias per kernel")
+        if int(self.hidden_kernels[0].shape[0]) != len(self.inputs):
+            raise ValueError(f"first kernel has {self.hidden_kernels[0].shape[0]} rows, the model has {len(self.inputs)} inputs")
+        w = int(self.hidden_kernels[0].shape[1])
+        if tuple(self.out_kernel.shape) != (w, self.n_channels) or tuple(self.out_bias.shape) != (self.n_channels,):
+            raise ValueError(f"output kernel has shape {self.out_kernel.shape}, expected {(w, self.n_channels)}")
+        for o in self.outputs:
+            if o.channels != 1 and (o.conditional is not None or o.after is not None or o.scale is not None):
+                raise ValueError(f"multi-channel output {o.name!r} must be unscaled")
+            if (o.after is None) != (o.before is None):
+                raise ValueError(f"output {o.name!r}: 'after' and 'before' go together")
+
+    # -- flat (yaml meta, npz arrays) serialisation ------------------------------------------
+    def to_arrays(self) -> Tuple[dict, Dict[str, np.ndarray]]:
+        meta = {
+            "architecture": self.architecture,
+            "inputs": [{"name": i.name, "source": i.source, "transform": i.transform, "eps": float(i.eps)} for i in self.inputs],
+            "outputs": [],
+            "n_hidden": len(self.hidden_kernels),
+        }
+        arrays: Dict[str, np.ndarray] = {}
+        for n, i in enumerate(self.inputs):
+            for key in ("center", "scale"):
+                if getattr(i, key) is not None:
+                    arrays[f"in{n}_{key}"] = np.atleast_1d(np.asarray(getattr(i, key), np.float32))
+        for n, o in enumerate(self.outputs):
+            m = {"name": o.name, "channels": int(o.channels), "after": o.after, "before": o.before}
+            for key in ("center", "scale"):
+                if getattr(o, key) is not None:
+                    arrays[f"out{n}_{key}"] = np.atleast_1d(np.asarray(getattr(o, key), np.float32))
+            if o.conditional is not None:
+                c = o.conditional
+                m["conditional"] = {"name": c.name, "on": c.on, "min_scale": float(c.min_scale)}
+                arrays[f"out{n}_cs_edges"] = np.asarray(c.edges, np.float32)
+                arrays[f"out{n}_cs_scale"] = np.asarray(c.scale, np.float32)
+                arrays[f"out{n}_cs_center"] = np.asarray(c.center, np.float32)
+            meta["outputs"].append(m)
+        for n, (kern, b) in enumerate(zip(self.hidden_kernels, self.hidden_biases)):
+            arrays[f"hidden{n}_kernel"] = np.asarray(kern, np.float32)
+            arrays[f"hidden{n}_bias"] = np.asarray(b, np.float32)
+        arrays["out_kernel"] = np.asarray(self.out_kernel, np.float32)
+        arrays["out_bias"] = np.asarray(self.out_bias, np.float32)
+        return meta, arrays
+
+    @classmethod
+    def from_arrays(cls, meta: Mapping, arrays: Mapping[str, np.ndarray]) -> "LocalMlpSpec":
+        inputs = [LocalInput(name=m["name"], source=m["source"], transform=m.get("transform", "none"), eps=float(m.get("eps", 0.0)),
+                             center=arrays.get(f"in{n}_center"), scale=arrays.get(f"in{n}_scale"))
+                  for n, m in enumerate(meta["inputs"])]
+        outputs = []
+        for n, m in enumerate(meta["outputs"]):
+            cond = None
+            if m.get("conditional"):
+                c = m["conditional"]
+                cond = ConditionalScale(name=c["name"], on=c["on"], min_scale=float(c.get("min_scale", 0.0)),
+                                        edges=np.asarray(arrays[f"out{n}_cs_edges"]), scale=np.asarray(arrays[f"out{n}_cs_scale"]),
+                                        center=np.asarray(arrays[f"out{n}_cs_center"]))
+            outputs.append(LocalOutput(name=m["name"], channels=int(m.get("channels", 1)), scale=arrays.get(f"out{n}_scale"),
+                                       center=arrays.get(f"out{n}_center"), conditional=cond, after=m.get("after"),
+                                       before=m.get("before")))
+        nh = int(meta["n_hidden"])
+        return cls(inputs=inputs, hidden_kernels=[np.asarray(arrays[f"hidden{n}_kernel"]) for n in range(nh)],
+                   hidden_biases=[np.asarray(arrays[f"hidden{n}_bias"]) for n in range(nh)], outputs=outputs,
+                   out_kernel=np.asarray(arrays["out_kernel"]), out_bias=np.asarray(arrays["out_bias"]))
+
+
+def _per_level(values, nz: int, default: float, what: str) -> np.ndarray:
+    if values is None:
+        return np.full(nz, default, np.float32)
+    a = np.atleast_1d(np.asarray(values, np.float32))
+    if a.shape == (1,):
+        return np.full(nz, a[0], np.float32)
+    if a.shape != (nz,):
+        raise ValueError(f"{what} has {a.shape[0]} levels, the state has {nz}")
+    return np.ascontiguousarray(a)
+
+
+class LocalMlpModel:
+    """Device handle of a dense-local emulator."""
+
+    def __init__(self, spec: LocalMlpSpec, device="cuda"):
+        spec.validate()
+        self.spec = spec
+        self.device = torch.device(device)
+        k, c = len(spec.inputs), spec.n_channels
+        self._inner = MlpModel(MlpSpec(
+            inputs=[InputSpec("X", k)], hidden_kernels=spec.hidden_kernels, hidden_biases=spec.hidden_biases,
+            outputs=[OutputSpec("Y", c)], out_kernel=spec.out_kernel, out_bias=spec.out_bias), device=self.device)
+        self.flops_per_point = self._inner.flops_per_sample
+        self._tables: Dict[Tuple[str, int], torch.Tensor] = {}
+
+    def _table(self, key: str, values, nz: Optional[int], default: float = 0.0) -> torch.Tensor:
+        """Small per-level / per-bin float tables, uploaded once per (table, nz)."""
+        ck = (key, -1 if nz is None else nz)
+        if ck not in self._tables:
+            a = np.ascontiguousarray(np.asarray(values, np.float32)) if nz is None else _per_level(values, nz, default, key)
+            self._tables[ck] = torch.from_numpy(a).to(self.device)
+        return self._tables[ck]
+
+    def predict(self, sources: Mapping[str, torch.Tensor]) -> Dict[str, torch.Tensor]:
+        """``sources``: name -> device array ``[nz, ncol]`` (or ``[ncol]`` / ``[1, ncol]``), float32 or float64.
+        Returns name -> float32 ``[nz, ncol]`` (``[channels, nz, ncol]`` for multi-channel outputs)."""
+        spec = self.spec
+        arrs: Dict[str, torch.Tensor] = {}
+        nz = ncol = None
+        for name in spec.sources:
+            t = sources[name]
+            if t.dtype not in (torch.float32, torch.float64):
+                raise TypeError(f"source {name!r} must be float32 or float64, got {t.dtype}")
+            if t.dim() == 1:
+                t = t.unsqueeze(0)
+            if t.dim() != 2:
+                raise ValueError(f"source {name!r} must be [nz, ncol] or [ncol], got shape {tuple(t.shape)}")
+            if ncol is None:
+                ncol = int(t.shape[1])
+            elif int(t.shape[1]) != ncol:
+                raise ValueError("sources differ in their number of columns")
+            if t.shape[0] != 1:
+                if nz is None:
+                    nz = int(t.shape[0])
+                elif int(t.shape[0]) != nz:
+                    raise ValueError("sources differ in their number of levels")
+            arrs[name] = t.contiguous()
+        nz = 1 if nz is None else nz
+        dev = _require_device(*arrs.values())
+        st = _stream(dev)
+        k, c = len(spec.inputs), spec.n_channels
+        x = torch.empty((k, nz * ncol), dtype=torch.float32, device=dev)
+        for n, i in enumerate(spec.inputs):
+            t = arrs[i.source]
+            _lib.call("fv3hip_local_pack", _ptr(t), _lib.F64 if t.dtype == torch.float64 else _lib.F32, int(t.shape[0] != 1),
+                      _lib.TRANSFORM_LOG if i.transform == "log" else _lib.TRANSFORM_NONE, float(i.eps),
+                      _ptr(self._table(f"in{n}_center", i.center, nz, 0.0)), _ptr(self._table(f"in{n}_scale", i.scale, nz, 1.0)),
+                      nz, ncol, _ptr(x[n]), st)
+        y = self._inner.predict({"X": x})["Y"]  # [sum(channels), nz * ncol]
+        del x
+        out: Dict[str, torch.Tensor] = {}
+        row = 0
+        for n, o in enumerate(spec.outputs):
+            rows = y[row:row + o.channels]
+            row += o.channels
+            if o.channels != 1:
+                out[o.name] = rows.reshape(o.channels, nz, ncol)
+                continue
+            for need in ([o.conditional.on] if o.conditional else []) + ([o.before] if o.before else []):
+                if arrs[need].shape[0] != nz:
+                    raise ValueError(f"source {need!r} must have {nz} levels")
+            direct = torch.empty((nz, ncol), dtype=torch.float32, device=dev)
+            cond, unscaled, after = o.conditional, None, None
+            cond_args = [None, 0, None, None, None, 0, 0.0]
+            if cond is not None:
+                unscaled = torch.empty_like(direct)
+                on = arrs[cond.on]
+                cond_args = [_ptr(on), _lib.F64 if on.dtype == torch.float64 else _lib.F32,
+                             _ptr(self._table(f"out{n}_cs_edges", cond.edges, None)),
+                             _ptr(self._table(f"out{n}_cs_scale", cond.scale, None)),
+                             _ptr(self._table(f"out{n}_cs_center", cond.center, None)), int(len(cond.edges)), float(cond.min_scale)]
+            before_args = [None, 0]
+            if o.before is not None:
+                after = torch.empty_like(direct)
+                b = arrs[o.before]
+                before_args = [_ptr(b), _lib.F64 if b.dtype == torch.float64 else _lib.F32]
+            _lib.call("fv3hip_local_unpack", _ptr(rows),
+                      _ptr(self._table(f"out{n}_scale", o.scale, nz, 1.0)) if o.scale is not None else None,
+                      _ptr(self._table(f"out{n}_center", o.center, nz, 0.0)) if o.center is not None else None,
+                      *cond_args, *before_args, nz, ncol, _ptr(direct), _ptr(unscaled), _ptr(after), st)
+            out[o.name] = direct
+            if cond is not None:
+                out[cond.name] = unscaled
+            if o.after is not None:
+                out[o.after] = after
+        return out

@@ -339,6 +339,39 @@ int fv3hip_hydrostatic_balance(const void *dz, const void *phis, const void *t, 
                                void *phis_out, void *stream);
 
 /*
+ * Pre- and post-passes of the "dense-local" emulators (one MLP shared by all levels, a (level, column)
+ * point is one sample of fv3hip_mlp_predict on the packed [n_inputs][nz * ncol] array) and the
+ * classifier decode of emulation.models.ModelWithClassifier.  State arrays are [nz][ncol]
+ * (call_py_fort's [feature, sample]) or, with has_levels = 0, [ncol]; tables are DEVICE float arrays.
+ *   fv3hip_local_pack      one network input row: (t(x) - center[z]) / scale[z], t = identity or
+ *                          log(max(x, eps)); float64 sources are cast to float32 first, as Keras does
+ *                          (fv3fit/emulation/layers/architecture.py:53-75 combine_sequence_inputs,
+ *                          layers/fields.py:6-41 FieldInput, transforms/transforms.py:111-129)
+ *   fv3hip_local_unpack    one network output channel (layers/fields.py:44-66 FieldOutput, then the
+ *                          backward transforms in the reference's order, transforms.py:219-224, 55-58):
+ *                            direct   = yhat * scale[z] + center[z]            (scale/center NULL = 1/0)
+ *                            unscaled = direct * max(cs_scale[b], min_scale) + cs_center[b],
+ *                                       b = max(upper_bound(edges[0..n_bins), cond_on) - 1, 0)
+ *                                       (keras/math.py:5-23 piecewise)          (cond_on NULL = skipped)
+ *                            after    = before + (unscaled or direct)           (before NULL = skipped)
+ *                          any of out_direct / out_unscaled / out_after may be NULL
+ *   fv3hip_classify_onehot logits [n_class][n] -> onehot [n_class][n] (logits == max over classes,
+ *                          ties all hot) and any_of [n] = onehot[cls_a] | onehot[cls_b]
+ *                          (emulation/zhao_carr.py:193-198 _get_classify_output); any_of may be NULL
+ */
+int fv3hip_local_pack(const void *x, int dtype, int has_levels, int transform, double eps,
+                      const float *center, const float *scale, int nz, int64_t ncol, float *out,
+                      void *stream);
+int fv3hip_local_unpack(const float *yhat, const float *scale, const float *center,
+                        const void *cond_on, int cond_dtype, const float *edges,
+                        const float *cs_scale, const float *cs_center, int n_bins,
+                        double min_scale, const void *before, int before_dtype, int nz,
+                        int64_t ncol, float *out_direct, float *out_unscaled, float *out_after,
+                        void *stream);
+int fv3hip_classify_onehot(const void *logits, int dtype, int n_class, int64_t n,
+                           uint8_t *onehot, uint8_t *any_of, int cls_a, int cls_b, void *stream);
+
+/*
  * Replaces mappm.interpolate_2d (external/mappm/mappm/interpolate_2d.f90:1-28; called from
  * external/vcm/vcm/interpolate.py:165-169): per column, linear interpolation of y(x) (n_in points,
  * x increasing) onto xp (n_out points); outside the column's range the result is fill_value.

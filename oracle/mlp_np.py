@@ -101,3 +101,76 @@ def forward(spec, sources, dtype=np.float32):
     for r in getattr(spec, "residuals", []):
         out[r.name] = src[r.source][:, : out[r.output].shape[1]] + out[r.output]
     return out
+
+
+# ------------------------------------------------------------------------------------------------
+# "dense-local" architecture and the transforms the reference bakes into its saved models
+# ------------------------------------------------------------------------------------------------
+def piecewise(x, y, xg):
+    """0th-order interpolation with constant extrapolation (external/fv3fit/fv3fit/keras/math.py:5-23):
+    ``y[max(searchsorted(x, xg, side='right') - 1, 0)]``."""
+    xg = np.asarray(xg)
+    index = np.maximum(np.searchsorted(np.asarray(x), xg.reshape(-1), side="right") - 1, 0)
+    return np.asarray(y)[index].reshape(xg.shape)
+
+
+def conditionally_scaled_backward(y, on, edges, scale, center, min_scale=0.0):
+    """ConditionallyScaledTransform.backward (transforms/transforms.py:209-224) with ``scale``/``center``
+    = ``piecewise(edges[:-1], values, .)`` as ``fit_conditional`` builds them (factories.py:81-93);
+    ``edges`` here are those left bin edges."""
+    limited = np.maximum(piecewise(edges, scale, on), np.float32(min_scale))  # tf.maximum(float32 tensor, python float)
+    return y * limited.astype(y.dtype) + piecewise(edges, center, on).astype(y.dtype)
+
+
+def forward_local(spec, sources, dtype=np.float32):
+    """Evaluate an ``fv3net_amd.local_mlp.LocalMlpSpec``-shaped description (duck-typed).
+
+    Follows layers/architecture.py:53-75 (combine_sequence_inputs: inputs sorted by name, [sample, 1]
+    inputs repeated over the levels, stacked on a last axis), :228-282 (MLPBlock on the last axis),
+    :346-417 (RNNOutput with shared kernel-size-1 convolutions: a Dense on the last axis, squeezed when
+    it has one channel), layers/fields.py:6-66 (per-level normalisation), transforms.py:111-129
+    (log(max(x, eps))), :219-224, :55-58 (backward transforms, reverse order).
+    ``sources``: name -> [sample, nz] (or [sample] / [sample, 1]).  Returns name -> [sample, nz]
+    (``[sample, nz, channels]`` for multi-channel outputs)."""
+    src = {}
+    nz = 1
+    for name, arr in sources.items():
+        a = np.asarray(arr)
+        if a.ndim == 1:
+            a = a[:, None]
+        src[name] = a.astype(np.float32).astype(dtype)  # Keras casts inputs to float32
+        nz = max(nz, a.shape[1])
+    cols = []
+    for i in spec.inputs:
+        x = src[i.source]
+        if i.transform == "log":
+            x = np.log(np.maximum(x, np.asarray(i.eps, np.float32).astype(dtype)))
+        center = np.zeros(1, np.float32) if i.center is None else np.atleast_1d(np.asarray(i.center, np.float32))
+        scale = np.ones(1, np.float32) if i.scale is None else np.atleast_1d(np.asarray(i.scale, np.float32))
+        x = (x - center.astype(dtype)) / scale.astype(dtype)
+        cols.append(np.broadcast_to(x, (x.shape[0], nz))[..., None])
+    h = np.concatenate(cols, axis=-1)  # [sample, nz, n_inputs]
+    for kern, b in zip(spec.hidden_kernels, spec.hidden_biases):
+        h = np.maximum(h @ np.asarray(kern, np.float32).astype(dtype) + np.asarray(b, np.float32).astype(dtype), 0)
+    yhat = h @ np.asarray(spec.out_kernel, np.float32).astype(dtype) + np.asarray(spec.out_bias, np.float32).astype(dtype)
+    out = {}
+    c0 = 0
+    for o in spec.outputs:
+        y = yhat[..., c0:c0 + o.channels]
+        c0 += o.channels
+        if o.channels != 1:
+            out[o.name] = y
+            continue
+        y = y[..., 0]
+        scale = np.ones(1, np.float32) if o.scale is None else np.atleast_1d(np.asarray(o.scale, np.float32))
+        center = np.zeros(1, np.float32) if o.center is None else np.atleast_1d(np.asarray(o.center, np.float32))
+        y = y * scale.astype(dtype) + center.astype(dtype)
+        out[o.name] = y
+        if o.conditional is not None:
+            c = o.conditional
+            y = conditionally_scaled_backward(y, src[c.on], np.asarray(c.edges, np.float32), np.asarray(c.scale, np.float32),
+                                              np.asarray(c.center, np.float32), c.min_scale)
+            out[c.name] = y
+        if o.after is not None:
+            out[o.after] = src[o.before] + y
+    return out

@@ -1,0 +1,183 @@
+"""The "dense-local" emulators, the classifier decode and ModelWithClassifier on the device
+(external/fv3fit/fv3fit/emulation/layers/architecture.py:518-527, external/emulation/emulation/models.py:14-65),
+against the float64 numpy oracle (oracle/mlp_np.py:forward_local; its transform pieces are pinned by the
+reference's known answers in tests/test_oracle_mlp.py; the dense contraction itself is parity-unpinned
+at the TensorFlow boundary like the "dense" architecture's).  Tolerance: 1e-5 of each output's magnitude
+(north star), classes and masks bit-exact."""
+import numpy as np
+import pytest
+import torch
+import yaml
+
+import local_cases as cases
+from oracle import emulation_np as E
+from oracle import mlp_np
+
+pytestmark = pytest.mark.gpu
+
+
+def _dev(st):
+    return {k: torch.from_numpy(v).cuda() for k, v in st.items()}
+
+
+def _check(got, truth, name, tol=1e-5):
+    scale = np.max(np.abs(truth))
+    assert got.shape == truth.shape, name
+    assert np.max(np.abs(got - truth)) <= tol * scale, (name, np.max(np.abs(got - truth)) / scale)
+
+
+@pytest.mark.parametrize("nz,ncol,dtype", [(79, 1024, np.float64), (79, 333, np.float32), (5, 64, np.float64), (1, 97, np.float32)])
+def test_local_regressor_matches_oracle(nz, ncol, dtype):
+    from fv3net_amd.local_mlp import LocalMlpModel
+
+    rng = np.random.default_rng(nz * 1000 + ncol)
+    st = cases.state(rng, nz, ncol, dtype)
+    spec = cases.regressor(rng, st, nz, make=cases.product_makers())
+    model = LocalMlpModel(spec, device="cuda")
+    got = model.predict(_dev(st))
+    truth = mlp_np.forward_local(spec, {k: v.T for k, v in st.items()}, dtype=np.float64)
+    assert list(got) == spec.output_names
+    for name in spec.output_names:
+        assert got[name].dtype == torch.float32
+        _check(got[name].cpu().numpy(), truth[name].T, name)
+    # and no worse than a few times the float32 evaluation of the same graph
+    f32 = mlp_np.forward_local(spec, {k: v.T for k, v in st.items()}, dtype=np.float32)
+    for name in spec.output_names:
+        e_gpu = np.max(np.abs(got[name].cpu().numpy() - truth[name].T))
+        e_f32 = np.max(np.abs(f32[name].T - truth[name].T))
+        assert e_gpu <= 4 * e_f32 + 1e-7 * np.max(np.abs(truth[name])), name
+
+
+def test_conditional_bins_are_exact_at_the_edges():
+    """piecewise(): a value equal to an edge belongs to the bin that starts there; below the first
+    edge and above the last one the end bins are used (keras/math.py:5-23)."""
+    from fv3net_amd.local_mlp import ConditionalScale, LocalInput, LocalMlpModel, LocalMlpSpec, LocalOutput
+
+    edges = np.array([0.0, 1.0, 2.0], np.float32)
+    cond = ConditionalScale("u", "on", edges, scale=np.array([1.0, 2.0, 4.0], np.float32), center=np.array([10.0, 20.0, 30.0], np.float32))
+    spec = LocalMlpSpec(inputs=[LocalInput("x", "x")], hidden_kernels=[np.zeros((1, 32), np.float32)], hidden_biases=[np.zeros(32, np.float32)],
+                        outputs=[LocalOutput("y", conditional=cond)], out_kernel=np.zeros((32, 1), np.float32), out_bias=np.ones(1, np.float32))
+    on = np.array([[-2, 0.0, 0.5, 0.75, 1, 1.5, 2.0, 2.5, np.nextafter(np.float32(1), np.float32(0))]], np.float32)
+    out = LocalMlpModel(spec).predict({"x": torch.zeros(on.shape, device="cuda"), "on": torch.from_numpy(on).cuda()})
+    np.testing.assert_array_equal(out["y"].cpu().numpy(), np.ones_like(on))
+    np.testing.assert_array_equal(out["u"].cpu().numpy(), [[11, 11, 11, 11, 22, 22, 34, 34, 11]])
+
+
+def test_classifier_decode_is_bit_exact():
+    from fv3net_amd.emulation.models import _get_classify_output
+    from fv3net_amd.emulation.zhao_carr import CLASS_NAMES
+
+    rng = np.random.default_rng(0)
+    logits = rng.normal(0, 1, (4, 7, 130)).astype(np.float32)
+    logits[:, 0, :10] = 0.25            # four-way ties: every class hot
+    logits[1, 1, :] = logits[3, 1, :] = 9.0   # two-way ties
+    want = E.classify(logits)
+    got = _get_classify_output(torch.from_numpy(logits).cuda(), one_hot_axis=0)
+    assert set(got) == set(CLASS_NAMES) | {"nontrivial_tendency"}
+    for name in CLASS_NAMES:
+        assert got[name].dtype == torch.bool
+        np.testing.assert_array_equal(got[name].cpu().numpy(), want[name])
+    np.testing.assert_array_equal(got["nontrivial_tendency"].cpu().numpy(), want["positive_tendency"] | want["negative_tendency"])
+    # [sample, z, class] views (what the Keras classifier returns) decode along the last axis
+    view = torch.from_numpy(logits).cuda().permute(2, 1, 0)
+    got_t = _get_classify_output(view, one_hot_axis=-1)
+    for name in CLASS_NAMES:
+        assert tuple(got_t[name].shape) == (130, 7)
+        np.testing.assert_array_equal(got_t[name].cpu().numpy(), want[name].T)
+    # numpy in -> numpy out, same answer (zhao_carr.py:193-198)
+    got_np = _get_classify_output(logits, one_hot_axis=0)
+    for name in CLASS_NAMES:
+        np.testing.assert_array_equal(got_np[name], want[name])
+
+
+def test_model_with_classifier(tmp_path):
+    """external/emulation/tests/test_models.py:7-52 with device models: the outputs hold the regressor's
+    outputs, the logits and every decoded class; a singleton entry in the state is ignored."""
+    from fv3net_amd.emulation.models import HipLocalEmulator, ModelWithClassifier, load_emulator
+    from fv3net_amd.emulation.zhao_carr import CLASS_NAMES
+
+    rng = np.random.default_rng(5)
+    nz, ncol = 19, 200
+    st = cases.state(rng, nz, ncol)
+    reg = HipLocalEmulator(cases.regressor(rng, st, nz, make=cases.product_makers()))
+    cls = HipLocalEmulator(cases.classifier(rng, st, nz, make=cases.product_makers()))
+    reg.dump(str(tmp_path / "reg"))
+    cls.dump(str(tmp_path / "cls"))
+    assert yaml.safe_load(open(tmp_path / "cls" / "spec.yaml"))["architecture"] == "dense-local"
+    reg2, cls2 = load_emulator(str(tmp_path / "reg")), load_emulator(str(tmp_path / "cls"))
+    assert isinstance(reg2, HipLocalEmulator) and reg2.output_variables == reg.output_variables
+
+    model = ModelWithClassifier(reg2, cls2, inputs_to_ignore=["singleton_vector"])
+    x = {k: v.T for k, v in st.items()}  # [sample, feature] views, as the hook passes them
+    x["singleton_vector"] = np.ones([1])
+    out = model(x)
+    assert set(out) >= set(CLASS_NAMES) | {"gscond_classes", "nontrivial_tendency"} | set(reg.output_variables)
+    for v in out.values():
+        assert isinstance(v, np.ndarray)
+    assert out["gscond_classes"].shape == (ncol, nz, 4) and out["zero_cloud"].shape == (ncol, nz)
+    truth_c = mlp_np.forward_local(cls.spec, {k: v.T for k, v in st.items()}, dtype=np.float64)["gscond_classes"]
+    _check(out["gscond_classes"], truth_c, "gscond_classes")
+    want = E.classify(np.moveaxis(out["gscond_classes"], -1, 0))
+    for name in CLASS_NAMES:
+        np.testing.assert_array_equal(out[name], want[name])
+    truth_r = mlp_np.forward_local(reg.spec, {k: v.T for k, v in st.items()}, dtype=np.float64)
+    for name in reg.output_variables:
+        _check(out[name], truth_r[name], name)
+    # without a classifier (test_models.py:38-52)
+    out = ModelWithClassifier(reg2, classifier=None)({k: v.T for k, v in st.items()})
+    assert set(out) == set(reg.output_variables)
+
+
+def test_hook_with_classifier_and_classifier_masks(tmp_path):
+    """The production gscond configuration in miniature (projects/microphysics/configs/gscond-and-precpd.yaml):
+    dense-local regressor + classifier, the two classifier masks and the conservation fix, built from
+    fv3config-style keys; the state is updated in place with [feature, sample] arrays."""
+    from fv3net_amd.emulation.config import ModelConfig
+    from fv3net_amd.emulation.models import HipLocalEmulator
+
+    rng = np.random.default_rng(11)
+    nz, ncol = 23, 320
+    st = cases.state(rng, nz, ncol)
+    reg_spec = cases.regressor(rng, st, nz, make=cases.product_makers())
+    # the hook's masks work on the Fortran names of the gscond outputs
+    reg_spec.outputs[0].after, reg_spec.outputs[1].after = E.QV_G, E.T_G
+    HipLocalEmulator(reg_spec).dump(str(tmp_path / "reg"))
+    cls_spec = cases.classifier(rng, st, nz, make=cases.product_makers())
+    # balance the random classifier so that every class occurs
+    raw = mlp_np.forward_local(cls_spec, {k: v.T for k, v in st.items()}, dtype=np.float64)["gscond_classes"]
+    cls_spec.out_bias = (cls_spec.out_bias - raw.mean(axis=(0, 1))).astype(np.float32)
+    HipLocalEmulator(cls_spec).dump(str(tmp_path / "cls"))
+    cfg = ModelConfig.from_dict({"path": str(tmp_path / "reg"), "classifier_path": str(tmp_path / "cls"),
+                                 "gscond_cloud_conservative": True, "mask_gscond_no_tend_classifier": True,
+                                 "mask_gscond_zero_cloud_classifier": True, "enforce_conservative": True})
+    hook = cfg.build()
+    state = {k: v.copy() for k, v in st.items()}
+    state[E.CLOUD_G] = st[cases.CLOUD_IN] * 1.1
+    state["model_time"] = [2016, 8, 1, 0, 0, 0]
+    state["rank"] = 0
+    before = {k: (v.copy() if isinstance(v, np.ndarray) else v) for k, v in state.items()}
+    hook.microphysics(state)
+
+    # oracle: network (float64 truth), decode, then the masks in the reference's order (config.py:178-221)
+    x = {k: v.T for k, v in st.items()}
+    em = {k: v.T for k, v in mlp_np.forward_local(reg_spec, x, dtype=np.float64).items()}
+    logits = np.moveaxis(mlp_np.forward_local(cls_spec, x, dtype=np.float64)["gscond_classes"], -1, 0).transpose(0, 2, 1)
+    got_logits = state["gscond_classes"]
+    assert got_logits.shape == (4, nz, ncol)
+    _check(got_logits, logits, "gscond_classes")
+    s64 = {k: v for k, v in before.items() if isinstance(v, np.ndarray)}
+    em = {**em, "gscond_classes": got_logits.astype(np.float64)}  # the device's own logits decide the classes
+    em[E.CLOUD_G] = E.infer_gscond_cloud_from_conservation(s64, em)[E.CLOUD_G]
+    em = E.update_with_net_condensation(E.gscond_cloud_choice(s64, em, "class_zero_tend"), s64, em)
+    em = E.update_with_net_condensation(E.gscond_cloud_choice(s64, em, "class_zero_cloud"), s64, em)
+    em = E.update_with_net_condensation(em[E.CLOUD_G], s64, em)
+    for name in (E.CLOUD_G, E.QV_G, E.T_G):
+        assert state[name].shape == (nz, ncol), name
+        _check(state[name], em[name], name)
+    classes = E.classify(got_logits)
+    zero_cloud = classes["zero_cloud"]
+    assert zero_cloud.any() and not zero_cloud.all()
+    assert np.all(state[E.CLOUD_G][zero_cloud & ~classes["zero_tendency"]] == 0.0)
+    np.testing.assert_array_equal(state["zero_cloud"], zero_cloud)
+    for k in st:  # inputs untouched
+        np.testing.assert_array_equal(state[k], before[k])

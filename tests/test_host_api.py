@@ -165,8 +165,9 @@ def test_emulation_config(tmp_path):
     gscond, micro, store = get_hooks(str(tmp_path / "missing.yml"))
     state = {"a": np.zeros(3)}
     assert micro(state) is None and gscond(state) is None and store(state) is None and list(state) == ["a"]
-    with pytest.raises(NotImplementedError, match="classifier_path"):
-        EmulationConfig.from_dict({"model": {"path": "x", "classifier_path": "y"}})
+    with pytest.raises(NotImplementedError, match="online_schedule"):
+        EmulationConfig.from_dict({"model": {"path": "x", "online_schedule": {"period": 3600}}})
+    assert EmulationConfig.from_dict({"model": {"path": "x", "classifier_path": "y"}}).model.classifier_path == "y"
     cfg = EmulationConfig.from_dict({"model": {"path": "x", "cloud_squash": 1e-6, "enforce_conservative": True,
                                                "ranges": {"total_precipitation": {"min": 0}},
                                                "mask_emulator_levels": {"air_temperature_after_precpd": {"start": 74}}}})

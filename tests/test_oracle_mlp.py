@@ -75,3 +75,72 @@ def test_forward_against_torch_cpu(dtype, tol):
         o = spec.outputs[0]
         y = y * torch.from_numpy(o.scale).to(tdt) + torch.from_numpy(o.center).to(tdt)
     np.testing.assert_allclose(got, y.numpy(), rtol=tol, atol=tol)
+
+
+# ------------------------------------------------------------------------------------------------
+# dense-local architecture, piecewise interpolation, conditional scaling
+# ------------------------------------------------------------------------------------------------
+def test_piecewise_known_answers():
+    # external/fv3fit/tests/keras/test_math.py:7-15
+    x = np.array([0.0, 1, 2], np.float32)
+    y = 2.0 * x
+    got = mlp_np.piecewise(x, y, np.array([-2, 0.5, 0.75, 1, 1.5, 2.5], np.float32))
+    np.testing.assert_array_equal(got, y[[0, 0, 0, 1, 1, 2]])
+    assert mlp_np.piecewise(x, y, np.ones((10, 10), np.float32)).shape == (10, 10)  # test_math.py:18-23
+    # external/fv3fit/tests/emulation/test_transform.py:145-153: bins 0,1,2 with bin means [1, 2]; the interpolant is
+    # piecewise(edges[:-1], values, .)
+    got = mlp_np.piecewise(np.array([0.0, 1.0]), np.array([1.0, 2.0]), np.array([-1, 0.0, 1, 3]))
+    np.testing.assert_array_equal(got, [1, 1, 2, 2])
+
+
+@pytest.mark.parametrize("min_scale", [0, 1, 2, 3, 4])
+def test_conditionally_scaled_backward_known_answers(min_scale):
+    # external/fv3fit/tests/emulation/test_transform.py:168-220: scale(.) = 2, center(.) = 0; the forward
+    # transform of `expected * max(scale, min_scale)` is `expected` = 1, and backward undoes it
+    on = np.zeros((3, 4), np.float32)
+    y = np.ones((3, 4), np.float32)
+    got = mlp_np.conditionally_scaled_backward(y, on, np.array([-1.0], np.float32), np.array([2.0], np.float32),
+                                               np.array([0.0], np.float32), min_scale)
+    np.testing.assert_array_almost_equal(got, 1.0 * max(2.0, min_scale))
+
+
+@pytest.mark.parametrize("dtype,tol", [(np.float64, 1e-12), (np.float32, 5e-5)])
+def test_forward_local_against_torch_cpu(dtype, tol):
+    """The dense-local graph against an independent torch-CPU statement: Linear layers on a
+    [sample, z, channel] tensor, Conv1d(kernel_size=1) heads as in RNNOutput(share_conv_weights=True)."""
+    import local_cases
+
+    rng = np.random.default_rng(3)
+    nz, ncol = 9, 40
+    st = local_cases.state(rng, nz, ncol)
+    for spec in (local_cases.regressor(rng, st, nz), local_cases.classifier(rng, st, nz)):
+        got = mlp_np.forward_local(spec, {k: v.T for k, v in st.items()}, dtype=dtype)
+        td = torch.float64 if dtype == np.float64 else torch.float32
+        cols = []
+        for i in spec.inputs:
+            x = torch.from_numpy(np.atleast_2d(st[i.source]).T.astype(np.float32)).to(td)  # [sample, nz or 1]
+            if i.transform == "log":
+                x = torch.log(torch.clamp(x, min=float(np.float32(i.eps))))
+            x = (x - torch.from_numpy(np.atleast_1d(i.center)).to(td)) / torch.tensor(float(i.scale), dtype=td)
+            cols.append(x.expand(ncol, nz).unsqueeze(-1))
+        h = torch.cat(cols, -1)
+        for kern, b in zip(spec.hidden_kernels, spec.hidden_biases):
+            h = torch.relu(torch.nn.functional.linear(h, torch.from_numpy(kern.T.copy()).to(td), torch.from_numpy(b).to(td)))
+        conv_w = torch.from_numpy(spec.out_kernel.T.copy()).to(td).unsqueeze(-1)  # [out_channels, in_channels, 1]
+        y = torch.nn.functional.conv1d(h.transpose(1, 2), conv_w, torch.from_numpy(spec.out_bias).to(td)).transpose(1, 2)
+        c0 = 0
+        for o in spec.outputs:
+            ref = y[..., c0:c0 + o.channels]
+            c0 += o.channels
+            if o.channels != 1:
+                np.testing.assert_allclose(got[o.name], ref.numpy(), rtol=tol, atol=tol)
+                continue
+            ref = ref[..., 0] * torch.from_numpy(o.scale).to(td) + torch.from_numpy(o.center).to(td)
+            np.testing.assert_allclose(got[o.name], ref.numpy(), rtol=tol, atol=tol * float(ref.abs().max()))
+            c = o.conditional
+            t_in = torch.from_numpy(st[c.on].T.astype(np.float32))
+            idx = torch.clamp(torch.searchsorted(torch.from_numpy(c.edges), t_in.contiguous(), right=True) - 1, min=0)
+            ref = ref * torch.clamp(torch.from_numpy(c.scale)[idx], min=c.min_scale).to(td) + torch.from_numpy(c.center)[idx].to(td)
+            np.testing.assert_allclose(got[c.name], ref.numpy(), rtol=tol, atol=tol * float(ref.abs().max()))
+            ref = torch.from_numpy(st[o.before].T.astype(np.float32)).to(td) + ref
+            np.testing.assert_allclose(got[o.after], ref.numpy(), rtol=tol, atol=tol * float(ref.abs().max()))
