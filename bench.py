@@ -233,7 +233,60 @@ def secondary_benchmarks(dev, steps):
             "roofline": {"bound": "hbm", "achieved": alg_bytes / ms / 1e6, "peak": PEAK_HBM_GBPS, "unit": "GB/s",
                          "frac": alg_bytes / ms / 1e6 / PEAK_HBM_GBPS, "traffic": None},
         })
+    out.extend(dense_local_benchmark(dev, steps))
     return out
+
+
+def dense_local_benchmark(dev, steps):
+    """The reference's production gscond emulator (projects/microphysics/configs/models/gscond.yaml: "dense-local",
+    12 inputs at a point -> 2 x 256 -> 2 outputs, temperature-conditional un-scaling + Difference outputs) over one
+    C384 snapshot: 79 x 884 736 points.  MFMA-bound like the headline kernel, plus two HBM-bound passes."""
+    from fv3net_amd.local_mlp import ConditionalScale, LocalInput, LocalMlpModel, LocalMlpSpec, LocalOutput
+
+    rng = np.random.default_rng(0)
+    ncol, width = 6 * 384 * 384, 256
+    g = torch.Generator(device=dev).manual_seed(2)
+    u = lambda lo, hi, shape=(NZ, ncol): torch.rand(shape, device=dev, generator=g) * (hi - lo) + lo
+    qv = torch.pow(10.0, u(-8, -2))
+    t = u(180, 310)
+    st = {
+        "air_temperature_input": t, "specific_humidity_input": qv,
+        "cloud_water_mixing_ratio_input": torch.where(u(0, 1) < 0.7, torch.zeros_like(t), torch.pow(10.0, u(-10, -3))),
+        "pressure_thickness_of_atmospheric_layer": u(300, 1500), "air_temperature_after_last_gscond": t + u(-1, 1),
+        "specific_humidity_after_last_gscond": qv * u(0.9, 1.1), "air_pressure": u(300, 101000),
+        "surface_air_pressure": u(95000, 103000, (ncol,)), "surface_air_pressure_after_last_gscond": u(95000, 103000, (ncol,)),
+    }
+    raw = [(n, n, "none", 0.0) for n in st] + [(k, v[0], "log", v[1]) for k, v in LOG_FIELDS.items()]
+    inputs = [LocalInput(name, source, tr, eps, center=rng.normal(0, 1, NZ).astype(np.float32) if st[source].dim() == 2 else
+                         np.float32(rng.normal()), scale=np.float32(rng.uniform(0.5, 2))) for name, source, tr, eps in sorted(raw)]
+    k = len(inputs)
+    edges = np.linspace(180, 310, 51)[:-1].astype(np.float32)
+    outs = [LocalOutput(f"{v}_gscond_difference_tscaled", scale=rng.uniform(0.5, 2, NZ).astype(np.float32),
+                        center=rng.normal(0, 0.1, NZ).astype(np.float32),
+                        conditional=ConditionalScale(f"{v}_gscond_difference", "air_temperature_input", edges,
+                                                     rng.uniform(0, 2, 50).astype(np.float32), rng.normal(0, 0.1, 50).astype(np.float32), 0.1),
+                        after=f"{src}_after_gscond", before=f"{src}_input")
+            for v, src in (("humidity", "specific_humidity"), ("temperature", "air_temperature"))]
+    spec = LocalMlpSpec(
+        inputs=inputs,
+        hidden_kernels=[(rng.normal(0, 1, (k, width)) / np.sqrt(k)).astype(np.float32),
+                        (rng.normal(0, 1, (width, width)) / np.sqrt(width)).astype(np.float32)],
+        hidden_biases=[rng.normal(0, 0.1, width).astype(np.float32) for _ in range(2)], outputs=outs,
+        out_kernel=(rng.normal(0, 1, (width, 2)) / np.sqrt(width)).astype(np.float32), out_bias=rng.normal(0, 0.1, 2).astype(np.float32))
+    model = LocalMlpModel(spec, device=dev)
+    fn = lambda: model.predict(st)
+    fn()
+    torch.cuda.synchronize(dev)
+    ms = time_kernel(fn, max(3, min(steps, 5)), dev)
+    flops = 2 * (k * width + width * width + width * 2)
+    achieved = flops * NZ * ncol / (ms * 1e-3) / 1e12
+    return [{
+        "kernel": "dense-local emulator (local_pack + mlp_fused_kernel + local_unpack)",
+        "workload": f"C384 gscond regressor: {k} inputs -> 2 x {width} -> 2 outputs at each of 79 x {ncol} points, float32 state",
+        "ms": ms, "columns_per_s": ncol / ms * 1e3, "flops_per_point": flops,
+        "roofline": {"bound": "mfma", "achieved": achieved, "peak": PEAK_FP32_MFMA_TFLOPS, "unit": "TFLOP/s",
+                     "frac": achieved / PEAK_FP32_MFMA_TFLOPS, "traffic": None},
+    }]
 
 
 def main():
