@@ -256,6 +256,35 @@ def hydrostatic_balance(dz: torch.Tensor, phis: torch.Tensor, t: torch.Tensor, q
     return dz_out, phis_out
 
 
+def level_scale(x: torch.Tensor, scale: torch.Tensor, z_axis: int) -> torch.Tensor:
+    """``scale[z] * x`` along ``z_axis`` in float64 (TaperConfig.apply, _shared/config.py:11-24)."""
+    dev = _require_device(x, scale)
+    code = _float_code(x)
+    x = x.contiguous()
+    z_axis, nb, nz, ni = _column_view(x, z_axis)
+    scale = scale.to(torch.float64).contiguous()
+    if tuple(scale.shape) != (nz,):
+        raise ValueError(f"scale must have shape ({nz},), got {tuple(scale.shape)}")
+    out = torch.empty(x.shape, dtype=torch.float64, device=dev)
+    _lib.call("fv3hip_level_scale", _ptr(x), code, _ptr(scale), nb, nz, ni, _ptr(out), _stream(dev))
+    return out
+
+
+def member_reduce(members: Sequence[torch.Tensor], op: str) -> torch.Tensor:
+    """NaN-skipping ``mean`` / ``median`` over same-shaped member arrays (EnsembleModel.predict, models.py:253-260)."""
+    dev = _require_device(*members)
+    dt = torch.float64 if any(m.dtype == torch.float64 for m in members) else torch.float32
+    ms = [m.to(dt).contiguous() for m in members]
+    if any(tuple(m.shape) != tuple(ms[0].shape) for m in ms):
+        raise ValueError("ensemble members differ in shape")
+    if op not in ("mean", "median"):
+        raise NotImplementedError(f"Got reduction {op}: only mean, median supported")
+    out = torch.empty_like(ms[0])
+    ptrs = (ctypes.c_void_p * len(ms))(*[m.data_ptr() for m in ms])
+    _lib.call("fv3hip_member_reduce", ptrs, len(ms), _DTYPE_CODE[dt], _OPS[op], out.numel(), _ptr(out), _stream(dev))
+    return out
+
+
 def interpolate_2d(xp: torch.Tensor, x: torch.Tensor, y: torch.Tensor, fill_value: float = float("nan"),
                    z_axis: int = -1) -> torch.Tensor:
     """``mappm.interpolate_2d`` (interpolate_2d.f90:1-28): linear interpolation of ``y(x)`` onto ``xp``
@@ -279,7 +308,7 @@ def interpolate_2d(xp: torch.Tensor, x: torch.Tensor, y: torch.Tensor, fill_valu
 
 
 EW_OPS = {"mul": 0, "isclose": 1, "isclose_s": 2, "where_nan": 3, "select": 4, "select_s": 5, "gt_s": 6, "lt_s": 7,
-          "fillna_s": 8, "and": 9, "min_s": 10, "blend": 11, "mul_s": 12}
+          "fillna_s": 8, "and": 9, "min_s": 10, "blend": 11, "mul_s": 12, "where_s": 13}
 
 
 def ew(op: str, a: torch.Tensor, b: Optional[torch.Tensor] = None, c: Optional[torch.Tensor] = None,

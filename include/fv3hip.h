@@ -150,6 +150,7 @@ int fv3hip_block_upsample(const void *in, int elem_size, int64_t n_outer, int ny
 #define FV3HIP_EW_MIN_S 10     /* a.where(a < scalar, other=scalar)                  */
 #define FV3HIP_EW_BLEND 11     /* coarsen_restarts.blend: a * b + (1 - a) * c         */
 #define FV3HIP_EW_MUL_S 12     /* scalar * a                                          */
+#define FV3HIP_EW_WHERE_S 13   /* a.where(mask b, other=scalar)                       */
 int fv3hip_ew(int op, const void *a, const void *b, const void *c, double scalar, int dtype,
               int64_t n, int64_t inner, int64_t b_rep, int64_t c_rep, void *out, void *stream);
 
@@ -370,6 +371,22 @@ int fv3hip_local_unpack(const float *yhat, const float *scale, const float *cent
                         void *stream);
 int fv3hip_classify_onehot(const void *logits, int dtype, int n_class, int64_t n,
                            uint8_t *onehot, uint8_t *any_of, int cls_a, int cls_b, void *stream);
+
+/*
+ * Predict-side glue of the fv3fit composite models (external/fv3fit/fv3fit/_shared/models.py:65-107, 223-276,
+ * 442-483), on the prediction arrays right after the network.
+ *   fv3hip_level_scale    TaperConfig.apply (_shared/config.py:11-24 with vcm/calc/calc.py:52-56): x [n_outer][nz][n_inner]
+ *                         of `dtype` times the DEVICE float64 factors scale[nz]; the product is float64, as
+ *                         numpy's float64 * float32 is
+ *   fv3hip_member_reduce  EnsembleModel.predict (models.py:253-260): NaN-skipping mean / median (FV3HIP_OP_MEAN /
+ *                         FV3HIP_OP_MEDIAN) over up to 32 member arrays of n values; `members` is a HOST array of
+ *                         device pointers
+ * SquashedOutputConfig.squash (_shared/config.py:135-142) is fv3hip_ew GT_S followed by WHERE_S.
+ */
+int fv3hip_level_scale(const void *x, int dtype, const double *scale, int64_t n_outer, int nz,
+                       int64_t n_inner, double *out, void *stream);
+int fv3hip_member_reduce(const void *const *members, int n_members, int dtype, int op, int64_t n,
+                         void *out, void *stream);
 
 /*
  * Replaces mappm.interpolate_2d (external/mappm/mappm/interpolate_2d.f90:1-28; called from
