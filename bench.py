@@ -234,6 +234,42 @@ def secondary_benchmarks(dev, steps):
                          "frac": alg_bytes / ms / 1e6 / PEAK_HBM_GBPS, "traffic": None},
         })
     out.extend(dense_local_benchmark(dev, steps))
+    out.extend(streaming_benchmark(dev))
+    return out
+
+
+def streaming_benchmark(dev, n_snapshots=24):
+    """BASELINE configs[3] on one GPU's share: a sequence of C384 tile snapshots (147 456 columns) that start and
+    end in (pinned) host memory, H2D / kernel / D2H of consecutive snapshots overlapped on three HIP streams
+    (fit/streaming.py).  PCIe-inclusive, so never the headline value."""
+    from fv3net_amd.fit.streaming import SnapshotStream
+    from fv3net_amd.mlp import MlpModel
+
+    ncol = 384 * 384
+    model = MlpModel(zc_spec(0), device=dev)
+    out = []
+    for in_dtype in (np.float32, np.float64):
+        stream = SnapshotStream(model, ncol, in_dtype=in_dtype, n_buffers=3)
+        src = zc_inputs_numpy(np.random.default_rng(5), ncol)
+        for slot in range(stream.n_buffers):  # synthetic snapshots already sit in the pinned buffers
+            for k, v in stream.host_inputs(slot).items():
+                v[...] = np.ascontiguousarray(src[k].T)
+        nothing = lambda i, arrays: None
+        stream.run(4, nothing, nothing)
+        torch.cuda.synchronize(dev)
+        t0 = time.perf_counter()
+        stream.run(n_snapshots, nothing, nothing)
+        torch.cuda.synchronize(dev)
+        dt = time.perf_counter() - t0
+        out.append({
+            "kernel": "SnapshotStream (H2D + mlp_fused_kernel + D2H on three streams)",
+            "workload": f"{n_snapshots} C384 tile snapshots of {ncol} columns from/to pinned host memory, {np.dtype(in_dtype).name} "
+                        f"inputs ({stream.bytes_in / 1e6:.0f} MB in, {stream.bytes_out / 1e6:.0f} MB out per snapshot)",
+            "ms": dt / n_snapshots * 1e3, "columns_per_s": ncol * n_snapshots / dt,
+            "pcie_GBps": {"h2d": stream.bytes_in * n_snapshots / dt / 1e9, "d2h": stream.bytes_out * n_snapshots / dt / 1e9},
+            "roofline": {"bound": "pcie", "achieved": None, "peak": None, "unit": "GB/s", "frac": None, "traffic": None},
+        })
+        del stream
     return out
 
 

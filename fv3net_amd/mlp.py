@@ -297,6 +297,7 @@ class MlpModel:
         sources: Mapping[str, torch.Tensor],
         layout: str = "feature_sample",
         out_dtype: torch.dtype = torch.float32,
+        out: Optional[Mapping[str, torch.Tensor]] = None,
     ) -> Dict[str, torch.Tensor]:
         """Run the network on 2-D device arrays.
 
@@ -304,7 +305,8 @@ class MlpModel:
         single-feature variable) -- the model's native [z, (y, x)] arrays and call_py_fort's
         arrays; outputs come back as ``[feature, sample]``.
         ``layout='sample_feature'``: ``[sample, feature]`` in and out (what ``stack`` produces).
-        Arbitrary strides are honoured, nothing is copied.
+        Arbitrary strides are honoured, nothing is copied.  ``out``: preallocated output arrays (all of
+        ``spec.output_names``, float32 or float64 alike) to write into instead of allocating.
         """
         spec = self.spec
         names = spec.sources
@@ -341,10 +343,18 @@ class MlpModel:
         out_list = []
         for name in spec.output_names:
             shape = (nfeat[name], n_samples) if layout == "feature_sample" else (n_samples, nfeat[name])
-            t = torch.empty(shape, dtype=out_dtype, device=dev)
+            if out is not None:
+                t = out[name]
+                if tuple(t.shape) != shape or t.device != dev:
+                    raise ValueError(f"out[{name!r}] must have shape {shape} on {dev}")
+                out_dtype = t.dtype
+            else:
+                t = torch.empty(shape, dtype=out_dtype, device=dev)
             outs[name] = t
             out_list.append(t)
 
+        if len({t.dtype for t in out_list}) > 1 or out_dtype not in (torch.float32, torch.float64):
+            raise TypeError("outputs must all be float32 or all float64")
         n_src, n_out = len(tensors), len(out_list)
         src_ptrs = (ctypes.c_void_p * n_src)(*[t.data_ptr() for t in tensors])
         src_dt = (ctypes.c_int * n_src)(*([src_code] * n_src))
