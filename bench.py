@@ -233,6 +233,21 @@ def secondary_benchmarks(dev, steps):
             "roofline": {"bound": "hbm", "achieved": alg_bytes / ms / 1e6, "peak": PEAK_HBM_GBPS, "unit": "GB/s",
                          "frac": alg_bytes / ms / 1e6 / PEAK_HBM_GBPS, "traffic": None},
         })
+    # the same remap for 4 fields that share their pressures (one fv_core / tracer group of the pipeline)
+    qs = [q] + [torch.rand((6, NZ, n, n), device=dev, generator=g) * 2000 - 1000 for _ in range(3)]
+    pe2 = targets[0][1]
+    fn = lambda: ops.mappm_multi(pe1, qs, pe2, z_axis=1)
+    fn()
+    torch.cuda.synchronize(dev)
+    ms = time_kernel(fn, max(3, min(steps, 10)), dev)
+    alg_bytes = ncol * (160 * 4 + 4 * 158 * 4.0)
+    out.append({
+        "kernel": "mappm_multi (4 fields per sweep)", "workload": "C384 884736 columns x 4 fields sharing pe1/pe2, km=kn=79, "
+        "iv=1 kord=1, coarse-pressure target (config 3)", "ms": ms, "columns_per_s": 4 * ncol / ms * 1e3,
+        "roofline": {"bound": "hbm", "achieved": alg_bytes / ms / 1e6, "peak": PEAK_HBM_GBPS, "unit": "GB/s",
+                     "frac": alg_bytes / ms / 1e6 / PEAK_HBM_GBPS, "traffic": None},
+    })
+    del qs
     out.extend(dense_local_benchmark(dev, steps))
     out.extend(streaming_benchmark(dev))
     return out

@@ -648,6 +648,296 @@ __global__ __launch_bounds__(256) void mappm_merge_kernel(
     if (bad) bad_cols[atomicAdd(n_bad, 1u)] = (unsigned int)lc;  // redone by mappm_fallback_kernel
 }
 
+// ---------------------------------------------------------------------------------------
+// The merge sweep for NF fields that share their source and target pressures (the restart pipelines
+// remap 4 fv_core fields and 9 tracers between the same two pressure grids, regridz.py:163-185): the
+// control flow, the target-interface ring, the pressure loads and every pressure-only term of the
+// reconstruction (the c1/c2/a1/a2 ratios, 2/(d4a+d4c), PR, PL, TT) are computed once per column
+// instead of once per field -- about 7 of the ~10 IEEE divisions per layer.  Per field the operations
+// and their order are those of mappm_merge_kernel (the field loops are unrolled and the compiler
+// merges the identical pressure-only subexpressions), so each field's result is bit-identical to a
+// single-field call.  `bad` depends on the pressures only: one worklist for all NF fields.
+// ---------------------------------------------------------------------------------------
+constexpr int kMaxMultiFields = 4;
+struct MultiFieldPtrs {
+    const void *q1[kMaxMultiFields];
+    float *q2[kMaxMultiFields];
+};
+
+template <typename Tin, int NF>
+__global__ __launch_bounds__(256) void mappm_merge_multi_kernel(
+    const Tin *__restrict__ pe1_, const MultiFieldPtrs fp, const Tin *__restrict__ pe2_, int64_t col0, int64_t col_end,
+    int64_t n_inner, int km, int kn, int iv, int kord, int layout, unsigned int *__restrict__ n_bad,
+    unsigned int *__restrict__ bad_cols)
+{
+    const int64_t lc = blockIdx.x * (int64_t)blockDim.x + threadIdx.x;
+    const int64_t col = col0 + lc;
+    if (col >= col_end) return;
+    const ColumnAddr addr = column_addr(col, n_inner, km, kn, layout);
+    const int64_t ks = addr.ks;
+    const Tin *pp1 = pe1_ + addr.o_pe1, *pp2 = pe2_ + addr.o_pe2;
+    const Tin *pq1[NF];
+    float *pq2[NF];
+#pragma unroll
+    for (int f = 0; f < NF; ++f) {
+        pq1[f] = static_cast<const Tin *>(fp.q1[f]) + addr.o_q1;
+        pq2[f] = fp.q2[f] + addr.o_q2;
+    }
+    auto PE1 = [&](int k) { return (float)pp1[(int64_t)(k - 1) * ks]; };
+    auto Q = [&](int f, int k) { return (float)pq1[f][(int64_t)(k - 1) * ks]; };
+    auto PE2g = [&](int k) { return (float)pp2[(int64_t)(k - 1) * ks]; };
+    auto OUT = [&](int f, int k, float v) { pq2[f][(int64_t)(k - 1) * ks] = v; };
+    __shared__ float ring_lds[16 * 256];
+
+    const int km1 = km - 1;
+    int lmt_int = kord - 3;
+    lmt_int = (lmt_int > 0) ? lmt_int : 0;
+    if (iv == 0) lmt_int = (lmt_int < 2) ? lmt_int : 2;
+    const bool int_recompute_a6 = (kord != 4), int_limit = (kord != 6);
+    const float r3 = 1.f / 3.f, r23 = 2.f / 3.f;
+
+    float pe_a = PE1(1), pe_b = PE1(2), pe_c = PE1(3), pe_d = PE1(4), pe_e = PE1(5);
+    const float pe1_top = pe_a, pe1_bot = PE1(km + 1);
+    float q0[NF], qp1[NF], qp2[NF], qp3[NF], q_top[NF], q_bot[NF];
+#pragma unroll
+    for (int f = 0; f < NF; ++f) {
+        q0[f] = Q(f, 1);
+        qp1[f] = Q(f, 2);
+        qp2[f] = Q(f, 3);
+        qp3[f] = Q(f, 4);
+        q_top[f] = q0[f];
+        q_bot[f] = Q(f, km);
+    }
+    bool bad = !(pe_b >= pe_a) | !(pe_c >= pe_b) | !(pe_d >= pe_c) | !(pe_e >= pe_d);
+    float d0 = pe_b - pe_a, dp1 = pe_c - pe_b, dp2 = pe_d - pe_c, dp3 = pe_e - pe_d;
+
+    auto DCI = [&](float dpa, float dpb, float dpc, float qa, float qb, float qc) {
+        const float d4b = dpa + dpb, d4c = dpb + dpc;
+        const float c1 = (dpa + 0.5f * dpb) / d4c;
+        const float c2 = (dpc + 0.5f * dpb) / d4b;
+        const float df2 = dpb * (c1 * (qc - qb) + c2 * (qb - qa)) / (d4b + dpc);
+        return f_sign(f_min3(fabsf(df2), f_max3(qa, qb, qc) - qb, qb - f_min3(qa, qb, qc)), df2);
+    };
+    auto INT = [&](float dpz, float dpa, float dpb, float dpc, float qa, float qb, float dca, float dcb) {
+        const float d4a = dpz + dpa, d4b = dpa + dpb, d4c = dpb + dpc;
+        const float c1 = (qb - qa) * dpa / d4b;
+        const float a1 = d4a / (d4b + dpa);
+        const float a2 = d4c / (d4b + dpb);
+        return qa + c1 + 2.f / (d4a + d4c) * (dpb * (c1 * (a1 - a2) + a2 * dca) - dpa * a1 * dcb);
+    };
+
+    float al0[NF], al1[NF], al2[NF], dc0[NF], dc1[NF], dc2[NF], ar_km[NF];
+#pragma unroll
+    for (int f = 0; f < NF; ++f) {
+        dc1[f] = DCI(d0, dp1, dp2, q0[f], qp1[f], qp2[f]);                   // dc(2)
+        const float dc_3 = DCI(dp1, dp2, dp3, qp1[f], qp2[f], qp3[f]);       // dc(3)
+        const float al_3 = INT(d0, dp1, dp2, dp3, qp1[f], qp2[f], dc1[f], dc_3);
+        const float d1 = d0, d2 = dp1;
+        const float qm = (d2 * q0[f] + d1 * qp1[f]) / (d1 + d2);
+        const float dq = 2.f * (qp1[f] - q0[f]) / (d1 + d2);
+        const float c1 = 4.f * (al_3 - qm - d2 * dq) / (d2 * (2.f * d2 * d2 + d1 * (d2 + 3.f * d1)));
+        const float c3 = dq - 0.5f * c1 * (d2 * (5.f * d1 + d2) - 3.f * d1 * d1);
+        float a2 = qm - 0.25f * c1 * d1 * d2 * (d2 + 3.f * d1);
+        float a1 = d1 * (2.f * c1 * (d1 * d1) - c3) + a2;
+        a2 = f_max2(a2, f_min2(q0[f], qp1[f]));
+        a2 = f_min2(a2, f_max2(q0[f], qp1[f]));
+        dc0[f] = 0.5f * (a2 - q0[f]);
+        if (iv == 0) {
+            a1 = f_max2(0.f, a1);
+            a2 = f_max2(0.f, a2);
+        } else if (iv == -1) {
+            if (a1 * q0[f] <= 0.f) a1 = 0.f;
+        } else if (iv == 2 || iv == -2) {
+            a1 = q0[f];
+        }
+        al0[f] = a1;
+        al1[f] = a2;
+        al2[f] = 0.f;
+        dc2[f] = 0.f;
+        ar_km[f] = 0.f;
+    }
+
+    constexpr int kRing = 16;
+    float *ring = ring_lds + threadIdx.x;
+    auto RING = [&](int j) -> float & { return ring[(j & (kRing - 1)) * 256]; };
+    int jw = 1;
+    {
+        float tmp[kRing];
+#pragma unroll
+        for (int i = 0; i < kRing; ++i) tmp[i] = PE2g((i + 1 <= kn + 1) ? i + 1 : kn + 1);
+#pragma unroll
+        for (int i = 0; i < kRing; ++i) RING(i + 1) = tmp[i];
+        jw = (kRing < kn + 1 ? kRing : kn + 1) + 1;
+    }
+    int jp = jw;
+    float pv0 = 0.f, pv1 = 0.f;
+    auto PE2 = [&](int j) { return (j < jw) ? RING(j) : PE2g(j); };
+
+    int k = 1;
+    float p2k = PE2(1), p2k1 = PE2(2);
+    bool accum = false;
+    float qsum[NF], dpsum = 0.f;
+#pragma unroll
+    for (int f = 0; f < NF; ++f) qsum[f] = 0.f;
+    auto advance = [&]() {
+        ++k;
+        if (!(p2k1 >= p2k)) bad = true;
+        p2k = p2k1;
+        p2k1 = PE2(k + 1 <= kn + 1 ? k + 1 : kn + 1);
+    };
+    if (!(p2k1 >= p2k)) bad = true;
+    while (k <= kn && !bad && p2k <= pe1_top) {
+#pragma unroll
+        for (int f = 0; f < NF; ++f) OUT(f, k, q_top[f]);
+        advance();
+    }
+    bool live = (k <= kn) && !bad && !(p2k >= pe1_bot);
+
+    float q_in[NF], pe_in = pe_e;
+#pragma unroll
+    for (int f = 0; f < NF; ++f) q_in[f] = 0.f;
+    for (int L = 1; L <= km; ++L) {
+        if (jp > jw) RING(jw) = pv0;
+        if (jp > jw + 1) RING(jw + 1) = pv1;
+        jw = jp;
+        if (L > 1) {
+            if (!(pe_in >= pe_e)) bad = true;
+#pragma unroll
+            for (int f = 0; f < NF; ++f) {
+                q0[f] = qp1[f]; qp1[f] = qp2[f]; qp2[f] = qp3[f]; qp3[f] = q_in[f];
+                al0[f] = al1[f]; al1[f] = al2[f];
+                dc0[f] = dc1[f]; dc1[f] = dc2[f];
+            }
+            d0 = dp1; dp1 = dp2; dp2 = dp3; dp3 = pe_in - pe_e;
+            pe_a = pe_b; pe_b = pe_c; pe_c = pe_d; pe_d = pe_e; pe_e = pe_in;
+        }
+        const int kk = L + 2;
+        if (kk <= km1) {
+#pragma unroll
+            for (int f = 0; f < NF; ++f) {
+                dc2[f] = DCI(dp1, dp2, dp3, qp1[f], qp2[f], qp3[f]);
+                al2[f] = INT(d0, dp1, dp2, dp3, qp1[f], qp2[f], dc1[f], dc2[f]);
+            }
+        } else if (kk == km) {
+#pragma unroll
+            for (int f = 0; f < NF; ++f) {
+                const float d1 = dp2, d2 = dp1;
+                const float qk = qp2[f], qk1 = qp1[f];
+                const float qm = (d2 * qk + d1 * qk1) / (d1 + d2);
+                const float dq = 2.f * (qk1 - qk) / (d1 + d2);
+                const float c1 = (al1[f] - qm - d2 * dq) / (d2 * (2.f * d2 * d2 + d1 * (d2 + 3.f * d1)));
+                const float c3 = dq - 2.0f * c1 * (d2 * (5.f * d1 + d2) - 3.f * d1 * d1);
+                float alk = qm - c1 * d1 * d2 * (d2 + 3.f * d1);
+                float ark = d1 * (8.f * c1 * (d1 * d1) - c3) + alk;
+                alk = f_max2(alk, f_min2(qk, qk1));
+                alk = f_min2(alk, f_max2(qk, qk1));
+                dc2[f] = 0.5f * (qk - alk);
+                if (iv == 0) {
+                    alk = f_max2(0.f, alk);
+                    ark = f_max2(0.f, ark);
+                } else if (iv < 0) {
+                    if (qk * ark <= 0.f) ark = 0.f;
+                }
+                al2[f] = alk;
+                ar_km[f] = ark;
+            }
+        } else {
+#pragma unroll
+            for (int f = 0; f < NF; ++f) {
+                al2[f] = 0.f;
+                dc2[f] = 0.f;
+            }
+        }
+        if (L + 4 <= km) {
+#pragma unroll
+            for (int f = 0; f < NF; ++f) q_in[f] = Q(f, L + 4);
+            pe_in = PE1(L + 5);
+        }
+        if (jp <= kn + 1 && jp < k + kRing) {
+            pv0 = PE2g(jp);
+            ++jp;
+            if (jp <= kn + 1 && jp < k + kRing) {
+                pv1 = PE2g(jp);
+                ++jp;
+            }
+        }
+
+        const bool edge = (L <= 2) | (L >= km1);
+        float al[NF], ar[NF], a6[NF];
+#pragma unroll
+        for (int f = 0; f < NF; ++f) {
+            al[f] = al0[f];
+            ar[f] = (L == km) ? ar_km[f] : al1[f];
+            a6[f] = 0.f;
+            if (edge | int_recompute_a6) a6[f] = 3.f * (2.f * q0[f] - (al[f] + ar[f]));
+            if (edge | int_limit) ppm_limiters1(dc0[f], q0[f], al[f], ar[f], a6[f], edge ? 0 : lmt_int);
+        }
+        const float pL = pe_a, pL1 = pe_b;
+
+        for (;;) {
+            const bool part = live && accum && !(p2k1 > pL1);
+            const bool inside = live && !accum && (p2k >= pL && p2k <= pL1) && (p2k1 <= pL1);
+            if (!(part || inside)) break;
+            const float delp = p2k1 - pL;
+            const float PR = delp / d0;
+            if (part) {
+                dpsum = dpsum + delp;
+#pragma unroll
+                for (int f = 0; f < NF; ++f) {
+                    qsum[f] = qsum[f] + delp * (al[f] + 0.5f * PR * (ar[f] - al[f] + a6[f] * (1.f - r23 * PR)));
+                    OUT(f, k, qsum[f] / dpsum);
+                }
+                accum = false;
+            } else {
+                const float PL = (p2k - pL) / d0;
+                const float TT = r3 * (PR * (PR + PL) + PL * PL);
+#pragma unroll
+                for (int f = 0; f < NF; ++f) OUT(f, k, al[f] + 0.5f * (a6[f] + ar[f] - al[f]) * (PR + PL) - a6[f] * TT);
+            }
+            advance();
+            live = (k <= kn) && !bad && !(p2k >= pe1_bot);
+        }
+        if (live) {
+            if (accum) {
+#pragma unroll
+                for (int f = 0; f < NF; ++f) qsum[f] = qsum[f] + d0 * q0[f];
+                dpsum = dpsum + d0;
+            } else if (p2k >= pL && p2k <= pL1) {
+                const float PL = (p2k - pL) / d0;
+                const float delp = pL1 - p2k;
+                const float TT = r3 * (1.f + PL * (1.f + PL));
+#pragma unroll
+                for (int f = 0; f < NF; ++f)
+                    qsum[f] = delp * (al[f] + 0.5f * (a6[f] + ar[f] - al[f]) * (1.f + PL) - a6[f] * TT);
+                dpsum = delp;
+                accum = true;
+            }
+        }
+    }
+
+    if (k <= kn && !bad && accum) {
+        const float delp = p2k1 - pe1_bot;
+        if (delp > 0.f) {
+#pragma unroll
+            for (int f = 0; f < NF; ++f) qsum[f] = qsum[f] + delp * q_bot[f];
+            dpsum = dpsum + delp;
+        }
+#pragma unroll
+        for (int f = 0; f < NF; ++f) OUT(f, k, qsum[f] / dpsum);
+        advance();
+    }
+    while (k <= kn && !bad) {
+        if (p2k >= pe1_bot) {
+#pragma unroll
+            for (int f = 0; f < NF; ++f) OUT(f, k, q_bot[f]);
+            advance();
+        } else {
+            bad = true;
+        }
+    }
+    if (bad) bad_cols[atomicAdd(n_bad, 1u)] = (unsigned int)lc;
+}
+
 // The columns the merge sweep gave up on (listed by their index inside the chunk), through the
 // sequential routine.  Launched after every merge launch; exits at once when the list is empty.
 template <typename Tin>
@@ -932,6 +1222,81 @@ extern "C" int fv3hip_mappm(const void *pe1, const void *q1, const void *pe2, in
         }
         int rc = check_launch("mappm kernel");
         if (rc) return rc;
+    }
+    return FV3HIP_OK;
+}
+
+namespace {
+template <typename T, int NF>
+void launch_merge_multi(const void *pe1, const MultiFieldPtrs &fp, const void *pe2, int64_t col0, int64_t col_end, int64_t n_inner,
+                        int km, int kn, int iv, int kord, int layout, unsigned int *n_bad, unsigned int *bad_cols, hipStream_t st)
+{
+    const int64_t blocks = ceil_div(col_end - col0, 256);
+    hipLaunchKernelGGL((mappm_merge_multi_kernel<T, NF>), dim3((unsigned)blocks), dim3(256), 0, st, static_cast<const T *>(pe1), fp,
+                       static_cast<const T *>(pe2), col0, col_end, n_inner, km, kn, iv, kord, layout, n_bad, bad_cols);
+}
+}  // namespace
+
+extern "C" int fv3hip_mappm_multi(const void *pe1, const void *const *q1, const void *pe2, int in_dtype, float *const *q2,
+                                  int n_fields, int64_t n_batch, int64_t n_inner, int km, int kn, int iv, int kord, int layout,
+                                  void *workspace, size_t workspace_bytes, void *stream)
+{
+    FV3HIP_REQUIRE(n_fields >= 0, "negative field count");
+    if (n_fields == 0) return FV3HIP_OK;
+    FV3HIP_REQUIRE(q1 && q2, "null pointer");
+    if (kord > 6 || n_fields == 1) {  // kord 7 needs the sequential routine (and kord > 7 is refused there)
+        for (int f = 0; f < n_fields; ++f) {
+            const int rc = fv3hip_mappm(pe1, q1[f], pe2, in_dtype, q2[f], n_batch, n_inner, km, kn, iv, kord, layout, workspace,
+                                        workspace_bytes, stream);
+            if (rc) return rc;
+        }
+        return FV3HIP_OK;
+    }
+    FV3HIP_REQUIRE(in_dtype == FV3HIP_F32 || in_dtype == FV3HIP_F64, "in_dtype must be F32 or F64, got %d", in_dtype);
+    FV3HIP_REQUIRE(layout == FV3HIP_LAYOUT_COL_LEVEL || layout == FV3HIP_LAYOUT_LEVEL_COL, "unknown layout %d", layout);
+    FV3HIP_REQUIRE(n_batch >= 0 && n_inner >= 0 && kn >= 0, "negative extent");
+    FV3HIP_REQUIRE(iv >= -2 && iv <= 2, "iv must be in [-2, 2], got %d", iv);
+    FV3HIP_REQUIRE(km >= 4, "km must be >= 4 (ppm_profile reads a4(2,i,3)), got %d", km);
+    if (layout == FV3HIP_LAYOUT_COL_LEVEL) FV3HIP_REQUIRE(n_inner == 1, "COL_LEVEL layout requires n_inner == 1");
+    const int64_t ncol = n_batch * n_inner;
+    if (ncol == 0 || kn == 0) return FV3HIP_OK;
+    FV3HIP_REQUIRE(pe1 && pe2, "null pointer");
+    for (int f = 0; f < n_fields; ++f) FV3HIP_REQUIRE(q1[f] && q2[f], "null field pointer");
+    FV3HIP_REQUIRE(workspace && workspace_bytes >= fv3hip_mappm_workspace_bytes(ncol, km),
+                   "workspace too small: need %zu bytes, got %zu", fv3hip_mappm_workspace_bytes(ncol, km), workspace_bytes);
+    hipStream_t st = as_stream(stream);
+    const int64_t ws_cols = ws_slots(ncol);
+    unsigned int *n_bad = static_cast<unsigned int *>(workspace);
+    unsigned int *bad_cols = reinterpret_cast<unsigned int *>(static_cast<char *>(workspace) + kCounterBytes);
+    float *planes = reinterpret_cast<float *>(static_cast<char *>(workspace) + kCounterBytes + ws_list_bytes(ncol));
+    for (int64_t col0 = 0; col0 < ncol; col0 += kMappmChunk) {
+        const int64_t col_end = (col0 + kMappmChunk < ncol) ? col0 + kMappmChunk : ncol;
+        const int64_t fb_threads = (col_end - col0 < kFallbackSlots) ? (col_end - col0) : kFallbackSlots;
+        const int64_t fb_blocks = ceil_div(fb_threads, 256);
+        for (int f0 = 0; f0 < n_fields; f0 += kMaxMultiFields) {
+            const int nf = (n_fields - f0 < kMaxMultiFields) ? n_fields - f0 : kMaxMultiFields;
+            MultiFieldPtrs fp;
+            for (int f = 0; f < kMaxMultiFields; ++f) {
+                fp.q1[f] = f < nf ? q1[f0 + f] : nullptr;
+                fp.q2[f] = f < nf ? q2[f0 + f] : nullptr;
+            }
+            FV3HIP_CHECK_HIP(hipMemsetAsync(n_bad, 0, 16, st));
+#define LAUNCH_(T)                                                                                                          \
+    switch (nf) {                                                                                                           \
+        case 1: launch_merge_multi<T, 1>(pe1, fp, pe2, col0, col_end, n_inner, km, kn, iv, kord, layout, n_bad, bad_cols, st); break; \
+        case 2: launch_merge_multi<T, 2>(pe1, fp, pe2, col0, col_end, n_inner, km, kn, iv, kord, layout, n_bad, bad_cols, st); break; \
+        case 3: launch_merge_multi<T, 3>(pe1, fp, pe2, col0, col_end, n_inner, km, kn, iv, kord, layout, n_bad, bad_cols, st); break; \
+        default: launch_merge_multi<T, 4>(pe1, fp, pe2, col0, col_end, n_inner, km, kn, iv, kord, layout, n_bad, bad_cols, st); break; \
+    }                                                                                                                       \
+    for (int f = 0; f < nf; ++f)                                                                                            \
+        hipLaunchKernelGGL((mappm_fallback_kernel<T>), dim3((unsigned)fb_blocks), dim3(256), 0, st, static_cast<const T *>(pe1), \
+                           static_cast<const T *>(fp.q1[f]), static_cast<const T *>(pe2), fp.q2[f], col0, n_inner, km, kn, iv,    \
+                           kord, layout, n_bad, bad_cols, planes, ws_cols)
+            if (in_dtype == FV3HIP_F32) { LAUNCH_(float); } else { LAUNCH_(double); }
+#undef LAUNCH_
+            const int rc = check_launch("mappm multi-field kernel");
+            if (rc) return rc;
+        }
     }
     return FV3HIP_OK;
 }

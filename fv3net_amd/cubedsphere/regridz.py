@@ -43,9 +43,30 @@ def regrid_vertical(p_in, f_in, p_out, iv: int = 1, kord: int = 1, z_dim_center:
     """Vertical regridding with the PPM remap (regridz.py:223-301).  ``p_in``/``p_out`` hold
     interface pressures along ``z_dim_outer``, ``f_in`` layer means along ``z_dim_center``; the
     result has ``f_in``'s dim order and attrs, float32, with ``p_out``'s layers."""
+    return _regrid_vertical_many(p_in, [f_in], p_out, iv, kord, z_dim_center, z_dim_outer)[0]
+
+
+def _regrid_vertical_many(p_in, fields, p_out, iv: int = 1, kord: int = 1, z_dim_center: str = RESTART_Z_CENTER,
+                          z_dim_outer: str = RESTART_Z_OUTER):
+    """``regrid_vertical`` of several fields between the same two pressure grids (what regridz.py:180-185
+    loops over): fields with the same dims share one multi-field remap sweep."""
     if z_dim_center == z_dim_outer:
         raise ValueError("'z_dim_center' and 'z_dim_outer' must not be equal.")
-    pi, fi, po = to_compat(p_in), to_compat(f_in), to_compat(p_out)
+    pi, po = to_compat(p_in), to_compat(p_out)
+    compat = [to_compat(f) for f in fields]
+    groups = {}
+    for n, fi in enumerate(compat):
+        groups.setdefault((fi.dims, tuple(fi.shape)), []).append(n)
+    results = [None] * len(compat)
+    for members in groups.values():
+        outs = _regrid_group(pi, [compat[n] for n in members], po, iv, kord, z_dim_center, z_dim_outer)
+        for n, out in zip(members, outs):
+            results[n] = from_compat(out, fields[n])
+    return results
+
+
+def _regrid_group(pi, group, po, iv, kord, z_dim_center, z_dim_outer):
+    fi = group[0]
     dims_except_z = [d for d in fi.dims if d != z_dim_center]
     # same dim order for all three, the vertical dim where f_in has it
     order_f = list(fi.dims)
@@ -62,10 +83,10 @@ def regrid_vertical(p_in, f_in, p_out, iv: int = 1, kord: int = 1, z_dim_center:
     if fi.sizes[z_dim_center] != pi_t.sizes[z_dim_outer] - 1:
         raise ValueError("f_in must have a vertical dimension one shorter than p_in")
     axis = fi.get_axis_num(z_dim_center)
-    res = ops.mappm(on_device(pi_t.data), on_device(fi.data), on_device(po_t.data), iv=iv, kord=kord, z_axis=axis)
-    coords = {k: v for k, v in fi.coords.items() if k != z_dim_center}
-    out = DataArray(like_input(res, fi.data), dims=fi.dims, coords=coords, name=fi.name, attrs=fi.attrs)
-    return from_compat(out, f_in)
+    res = ops.mappm_multi(on_device(pi_t.data), [on_device(f.data) for f in group], on_device(po_t.data), iv=iv, kord=kord,
+                          z_axis=axis)
+    return [DataArray(like_input(r, f.data), dims=f.dims, coords={k: v for k, v in f.coords.items() if k != z_dim_center},
+                      name=f.name, attrs=f.attrs) for r, f in zip(res, group)]
 
 
 def _mask_weights(weights, pfull_coarse_on_fine, phalf_coarse_on_fine, phalf_fine, dim_center: str = RESTART_Z_CENTER,
@@ -106,8 +127,10 @@ def _regrid_given_delp(ds, delp_fine, delp_coarse, weights, toa_pressure, x_dim:
     d = to_compat(ds)
     if isinstance(d, Dataset):
         regridded = Dataset(attrs=d.attrs)
-        for var in d:
-            regridded[var] = regrid_vertical(phalf_fine, d[var], phalf_coarse_on_fine, z_dim_center=z_dim)
+        names = list(d)
+        for var, out in zip(names, _regrid_vertical_many(phalf_fine, [d[v] for v in names], phalf_coarse_on_fine,
+                                                         z_dim_center=z_dim)):
+            regridded[var] = out
     else:
         regridded = regrid_vertical(phalf_fine, d, phalf_coarse_on_fine, z_dim_center=z_dim)
     pfull_coarse_on_fine = (

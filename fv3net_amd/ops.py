@@ -501,6 +501,49 @@ def mappm(
     return out
 
 
+def mappm_multi(pe1: torch.Tensor, fields: Sequence[torch.Tensor], pe2: torch.Tensor, iv: int = 1, kord: int = 1,
+                z_axis: int = -1) -> list:
+    """``mappm`` of several fields that share ``pe1`` and ``pe2`` (every variable of a dataset in
+    regridz.py:163-185): one sweep per four fields computes the control flow and the pressure-only terms
+    once.  Each result is bit-identical to ``mappm`` on that field."""
+    fields = list(fields)
+    if not fields:
+        return []
+    dev = _require_device(pe1, pe2, *fields)
+    dtypes = {t.dtype for t in (pe1, pe2, *fields)}
+    if len(dtypes) > 1:
+        common = torch.float64 if torch.float64 in dtypes else torch.float32
+        pe1, pe2, fields = pe1.to(common), pe2.to(common), [q.to(common) for q in fields]
+    pe1, pe2, fields = pe1.contiguous(), pe2.contiguous(), [q.contiguous() for q in fields]
+    q1 = fields[0]
+    nd = q1.dim()
+    z_axis = z_axis % nd
+    km, kn = int(q1.shape[z_axis]), int(pe2.shape[z_axis]) - 1
+    if int(pe1.shape[z_axis]) != km + 1:
+        raise ValueError("f_in must have a vertical dimension one shorter than p_in")
+
+    def others(t):
+        return tuple(t.shape[:z_axis]) + tuple(t.shape[z_axis + 1:])
+
+    if any(tuple(q.shape) != tuple(q1.shape) for q in fields) or not (others(pe1) == others(q1) == others(pe2)):
+        raise ValueError("All dimensions except vertical must be same size for p_in, f_in and p_out")
+    n_batch, n_inner = _prod(q1.shape[:z_axis]), _prod(q1.shape[z_axis + 1:])
+    if z_axis == nd - 1:
+        layout, nb, ni = _lib.LAYOUT_COL_LEVEL, n_batch, 1
+    else:
+        layout, nb, ni = _lib.LAYOUT_LEVEL_COL, n_batch, n_inner
+    shape = list(q1.shape)
+    shape[z_axis] = kn
+    outs = [torch.empty(shape, dtype=torch.float32, device=dev) for _ in fields]
+    ws = _workspace(dev, int(_lib.load().fv3hip_mappm_workspace_bytes(nb * ni, km)))
+    n = len(fields)
+    q_ptrs = (ctypes.c_void_p * n)(*[q.data_ptr() for q in fields])
+    o_ptrs = (ctypes.c_void_p * n)(*[o.data_ptr() for o in outs])
+    _lib.call("fv3hip_mappm_multi", _ptr(pe1), q_ptrs, _ptr(pe2), _float_code(q1), o_ptrs, n, nb, ni, km, kn, int(iv), int(kord),
+              layout, _ptr(ws), ws.numel(), _stream(dev))
+    return outs
+
+
 class HipTimer:
     """HIP events recorded on torch's current stream (used by bench.py)."""
 

@@ -228,6 +228,17 @@ int fv3hip_mappm(const void *pe1, const void *q1, const void *pe2, int in_dtype,
                  int64_t n_batch, int64_t n_inner, int km, int kn, int iv, int kord, int layout,
                  void *workspace, size_t workspace_bytes, void *stream);
 
+/*
+ * The same remap for n_fields fields that share pe1 and pe2 (regridz.py:163-185 remaps every variable of a
+ * dataset between the same two pressure grids): q1 / q2 are HOST arrays of n_fields device pointers.  Fields are
+ * processed four at a time in one sweep that computes the control flow and every pressure-only term once;
+ * each field's result is bit-identical to fv3hip_mappm on that field.  Same workspace as fv3hip_mappm.
+ */
+int fv3hip_mappm_multi(const void *pe1, const void *const *q1, const void *pe2, int in_dtype,
+                       float *const *q2, int n_fields, int64_t n_batch, int64_t n_inner, int km,
+                       int kn, int iv, int kord, int layout, void *workspace,
+                       size_t workspace_bytes, void *stream);
+
 /* ------------------------------------------------------------------------------------------
  * Column MLP (fv3fit dense model / Zhao-Carr microphysics emulator)
  * ------------------------------------------------------------------------------------------ */

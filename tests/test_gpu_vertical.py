@@ -237,6 +237,70 @@ def test_mappm_ill_formed_columns_take_the_sequential_path(device):
     assert _bits_equal(res, ref)
 
 
+@pytest.mark.parametrize("n_fields", [1, 2, 3, 4, 5, 9])
+@pytest.mark.parametrize("iv,kord", [(1, 1), (0, 4), (-1, 6), (2, 3), (0, 7)])
+def test_mappm_multi_field_bit_exact(device, n_fields, iv, kord):
+    """Fields that share their pressures go through one sweep (four at a time): every field is
+    bit-identical to the oracle, i.e. to a single-field call -- ill-formed columns, NaNs in one
+    field only, ties and zero-thickness layers included."""
+    from fv3net_amd import ops
+
+    rng = np.random.default_rng(100 * n_fields + kord)
+    ncol, km, kn = 1500, 33, 29
+    pe1, _, pe2 = _columns(rng, ncol, km, kn, ptop2=rng.choice([100.0, 300.0, 500.0]))
+    # integer-valued pressures in part of the batch: ties between interfaces, zero-thickness targets
+    t = slice(0, 300)
+    pe1[t] = np.concatenate([np.full((300, 1), 3.0), 3 + np.cumsum(rng.integers(1, 4, (300, km)), 1)], 1)
+    pe2[t] = np.concatenate([np.full((300, 1), 2.0), 3 + np.cumsum(rng.integers(0, 4, (300, kn)), 1)], 1)
+    bad = rng.choice(np.arange(300, ncol), 60, replace=False)
+    for i, c in enumerate(bad):
+        if i % 3 == 0:
+            pe1[c, 5], pe1[c, 6] = pe1[c, 6], pe1[c, 5]
+        elif i % 3 == 1:
+            pe2[c, rng.integers(0, kn + 1)] = np.nan
+        else:
+            pe2[c] = pe2[c, ::-1].copy()
+    fields = []
+    for f in range(n_fields):
+        q = rng.uniform(-1000, 1000, (ncol, km)).astype(np.float32) * np.float32(10.0 ** (f - 2))
+        if f % 2:
+            q[rng.random((ncol, km)) < 0.02] = np.nan
+        if f == 2:
+            q = np.round(q)  # flat stretches: the dm == 0 branch of the limiter
+        fields.append(np.abs(q) if iv == 0 else q)
+    res = ops.mappm_multi(_dev(pe1, device), [_dev(q, device) for q in fields], _dev(pe2, device), iv=iv, kord=kord)
+    assert len(res) == n_fields
+    for f, q in enumerate(fields):
+        ref = mappm_c.mappm(pe1, q, pe2, iv, kord)
+        assert _bits_equal(ops.as_numpy(res[f]), ref), (f, np.nanmax(np.abs(ops.as_numpy(res[f]) - ref)))
+
+
+def test_mappm_multi_level_col_layout_f64_and_errors(device):
+    from fv3net_amd import ops
+
+    rng = np.random.default_rng(8)
+    nt, km, ny, nx = 2, 79, 12, 16
+    pe1, _, pe2 = _columns(rng, nt * ny * nx, km, km)
+    qs = [rng.uniform(-1, 1, (nt * ny * nx, km)).astype(np.float32) for _ in range(6)]
+
+    def native(a):  # [ncol, lev] -> [tile, lev, y, x]
+        return np.ascontiguousarray(np.moveaxis(a.reshape(nt, ny, nx, -1), -1, 1))
+
+    for cast in (np.float32, np.float64):
+        res = ops.mappm_multi(_dev(native(pe1).astype(cast), device), [_dev(native(q).astype(cast), device) for q in qs],
+                              _dev(native(pe2).astype(cast), device), z_axis=1)
+        for q, r in zip(qs, res):
+            assert r.shape == (nt, km, ny, nx)
+            assert _bits_equal(np.moveaxis(ops.as_numpy(r), 1, -1).reshape(-1, km), mappm_c.mappm(pe1, q, pe2))
+    assert ops.mappm_multi(_dev(pe1, device), [], _dev(pe2, device)) == []
+    with pytest.raises(ValueError, match="same size"):
+        ops.mappm_multi(_dev(pe1, device), [_dev(qs[0], device), _dev(qs[1][:10], device)], _dev(pe2, device))
+    from fv3net_amd._lib import Fv3HipError
+
+    with pytest.raises(Fv3HipError, match="cs_profile"):
+        ops.mappm_multi(_dev(pe1, device), [_dev(qs[0], device), _dev(qs[1], device)], _dev(pe2, device), kord=9)
+
+
 @pytest.mark.parametrize("dt_np", [np.float32, np.float64])
 def test_humidity_limiters(device, dt_np):
     """vcm.non_negative_sphum(_mse_conserving) on the device (non_negative_sphum.py:6-45) against the
