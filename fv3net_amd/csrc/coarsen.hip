@@ -413,6 +413,78 @@ __global__ void block_reduce_kernel(const T *__restrict__ in, T *__restrict__ ou
     }
 }
 
+// median / mode of blocks of at most 64 values (f <= 8): one wavefront per output block, lane i holds
+// element i, and the order statistics come from 64 rounds of a wave-wide broadcast instead of the
+// n^2 strided global loads of the one-thread-per-block kernel.  Same results to the bit, including the
+// tie rules: mode = the most frequent non-NaN value, the smallest on ties, the first in block order among
+// values that compare equal (-0.0 / 0.0); median = NaN if any NaN, else the mean of the two middle order
+// statistics, each taken from the last element in block order that holds that rank.
+template <typename T>
+__global__ __launch_bounds__(256) void block_rank_wave_kernel(const T *__restrict__ in, T *__restrict__ out, int64_t n_outer,
+                                                              int ny, int nx, int by, int bx, int sy, int sx, int nyo,
+                                                              int nxo, int op, int nan_policy)
+{
+    const int64_t total = n_outer * nyo * nxo;
+    const int n = by * bx;
+    const int lane = threadIdx.x & 63;
+    const int64_t wave0 = (blockIdx.x * (int64_t)blockDim.x + threadIdx.x) >> 6;
+    const int64_t n_waves = ((int64_t)gridDim.x * blockDim.x) >> 6;
+    for (int64_t idx = wave0; idx < total; idx += n_waves) {
+        const int X = (int)(idx % nxo);
+        const int64_t t = idx / nxo;
+        const int Y = (int)(t % nyo);
+        const int64_t o = t / nyo;
+        const T *p = in + o * ny * (int64_t)nx + (int64_t)Y * sy * nx + (int64_t)X * sx;
+        const bool present = lane < n;
+        const T v = present ? p[(int64_t)(lane / bx) * nx + (lane % bx)] : (T)0;
+        const bool is_nan = present && nan_of(v);
+        int less = 0, eq = 0;
+        for (int j = 0; j < n; ++j) {
+            const T u = __shfl(v, j, 64);
+            less += (u < v);
+            eq += (u == v);
+        }
+        T result;
+        if (op == FV3HIP_OP_MEDIAN) {
+            const bool any_nan = __ballot(is_nan) != 0ull;
+            const int r1 = (n - 1) / 2, r2 = n / 2;
+            const unsigned long long h1 = __ballot(present && less <= r1 && r1 < less + eq);
+            const unsigned long long h2 = __ballot(present && less <= r2 && r2 < less + eq);
+            const T m1 = __shfl(v, h1 ? 63 - __clzll(h1) : 0, 64), m2 = __shfl(v, h2 ? 63 - __clzll(h2) : 0, 64);
+            if (any_nan) {
+                result = quiet_nan<T>();
+            } else {
+                if constexpr (IsFloat<T>::value)
+                    result = (r1 == r2) ? m1 : (m1 + m2) / (T)2;
+                else
+                    result = m1;
+            }
+        } else {
+            int cnt = (present && !is_nan) ? eq : 0;
+            T best = v;
+            int who = lane;
+#pragma unroll
+            for (int d = 32; d >= 1; d >>= 1) {
+                const int c2 = __shfl_xor(cnt, d, 64);
+                const T v2 = __shfl_xor(best, d, 64);
+                const int w2 = __shfl_xor(who, d, 64);
+                // (cnt desc, value asc, block order asc); a lane with cnt == 0 never wins against cnt > 0
+                const bool take = (c2 > cnt) || (c2 == cnt && c2 > 0 && (v2 < best || (!(best < v2) && w2 < who)));
+                if (take) {
+                    cnt = c2;
+                    best = v2;
+                    who = w2;
+                }
+            }
+            if constexpr (IsFloat<T>::value)
+                result = (cnt > 0) ? best : (nan_policy == FV3HIP_NAN_OMIT ? quiet_nan<T>() : (T)0);
+            else
+                result = best;
+        }
+        if (lane == 0) out[idx] = result;
+    }
+}
+
 template <typename T>
 int launch_block_reduce(const void *in, void *out, int64_t n_outer, int ny, int nx, int by, int bx,
                         int sy, int sx, int op, int nan_policy, hipStream_t stream)
@@ -420,6 +492,14 @@ int launch_block_reduce(const void *in, void *out, int64_t n_outer, int ny, int 
     const int nyo = (ny - by) / sy + 1, nxo = (nx - bx) / sx + 1;
     const int64_t total = n_outer * nyo * nxo;
     if (total <= 0) return FV3HIP_OK;
+    if ((op == FV3HIP_OP_MEDIAN || op == FV3HIP_OP_MODE) && by * bx <= 64) {
+        int64_t wblocks = ceil_div(total, 4);  // one wavefront per output block
+        if (wblocks > 256 * 64) wblocks = 256 * 64;
+        hipLaunchKernelGGL((block_rank_wave_kernel<T>), dim3((unsigned)wblocks), dim3(256), 0, stream,
+                           static_cast<const T *>(in), static_cast<T *>(out), n_outer, ny, nx, by, bx, sy, sx, nyo, nxo, op,
+                           nan_policy);
+        return check_launch("block_rank_wave_kernel");
+    }
     int64_t blocks = ceil_div(total, 256);
     if (blocks > 256 * 64) blocks = 256 * 64;
     hipLaunchKernelGGL((block_reduce_kernel<T>), dim3((unsigned)blocks), dim3(256), 0, stream,

@@ -182,6 +182,40 @@ def test_block_mode(device, policy):
     np.testing.assert_array_equal(res, onp.block_mode(a, 4, policy))
 
 
+@pytest.mark.parametrize("f", [2, 3, 8, 16])
+@pytest.mark.parametrize("dt", [np.float32, np.float64])
+def test_block_mode_and_median_wave_and_serial_kernels(device, f, dt):
+    """Blocks of up to 64 values go through the one-wavefront-per-block kernel, larger ones through the
+    one-thread-per-block kernel: both against the oracle, with many ties, NaNs, all-NaN blocks and
+    zeros of both signs (which compare equal)."""
+    from fv3net_amd import ops
+
+    rng = np.random.default_rng(17 + f)
+    a = rng.integers(0, 5, (3, 4 * f, 6 * f)).astype(dt)
+    a[rng.random(a.shape) < 0.15] = np.nan
+    a[0, :f, :f] = np.nan                       # an all-NaN block
+    a[1, :f, :f] = np.where(rng.random((f, f)) < 0.5, 0.0, -0.0)   # zeros of both signs only
+    for policy in ("propagate", "omit"):
+        res = ops.as_numpy(ops.block_reduce(_dev(a, device), (f, f), op="mode", nan_policy=policy))
+        ref = onp.block_mode(a, f, policy)
+        np.testing.assert_array_equal(res, ref)
+    b = rng.normal(0, 1, (3, 4 * f, 6 * f)).astype(dt)
+    b[2, :f, :f] = np.round(b[2, :f, :f])       # ties among the middle ranks
+    b[0, 0, 0] = np.nan                          # numpy.median: NaN if any NaN
+    res = ops.as_numpy(ops.block_reduce(_dev(b, device), (f, f), op="median"))
+    np.testing.assert_array_equal(res, onp.block_coarsen(b, f, "median"))
+
+
+@pytest.mark.parametrize("dt", [np.int32, np.int64])
+def test_block_mode_integers(device, dt):
+    from fv3net_amd import ops
+
+    rng = np.random.default_rng(23)
+    a = rng.integers(-3, 4, (2, 16, 24)).astype(dt)
+    res = ops.as_numpy(ops.block_reduce(_dev(a, device), (4, 4), op="mode"))
+    np.testing.assert_array_equal(res, onp.block_mode(a.astype(np.float64), 4, "propagate").astype(dt))
+
+
 @pytest.mark.parametrize("shape", [(2, 2), (2, 3), (3, 3), (5, 4, 7)])
 @pytest.mark.parametrize("dt", [np.float32, np.float64, np.int32, np.int64])
 def test_block_upsample(device, shape, dt):
