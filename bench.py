@@ -250,6 +250,62 @@ def secondary_benchmarks(dev, steps):
     del qs
     out.extend(dense_local_benchmark(dev, steps))
     out.extend(streaming_benchmark(dev))
+    out.extend(restart_pipeline_benchmark(dev))
+    return out
+
+
+def restart_pipeline_benchmark(dev, n=384, f=8, reps=3):
+    """BASELINE configs[2] end to end: the three restart coarse-graining pipelines (vcm coarsen_restarts_on_sigma /
+    _on_pressure / _via_blended_method, all four restart categories, 'complex' surface method) C384 -> C48 on float64
+    restarts resident in HBM, through the drop-in Python API.  Wall time of a whole pipeline call."""
+    from fv3net_amd.cubedsphere import (coarsen_restarts_on_pressure, coarsen_restarts_on_sigma,
+                                        coarsen_restarts_via_blended_method)
+    from fv3net_amd.xr_compat import DataArray, Dataset
+
+    g = torch.Generator(device=dev).manual_seed(3)
+    u = lambda lo, hi, *shape: torch.rand(shape, device=dev, generator=g, dtype=torch.float64) * (hi - lo) + lo
+    zc = ["tile", "Time", "zaxis_1", "yaxis_2", "xaxis_1"]
+    core = Dataset({
+        "u": DataArray(u(-30, 30, 6, 1, NZ, n + 1, n), dims=["tile", "Time", "zaxis_1", "yaxis_1", "xaxis_1"]),
+        "v": DataArray(u(-30, 30, 6, 1, NZ, n, n + 1), dims=["tile", "Time", "zaxis_1", "yaxis_2", "xaxis_2"]),
+        **{k: DataArray(u(lo, hi, 6, 1, NZ, n, n), dims=zc) for k, (lo, hi) in
+           {"W": (-1, 1), "T": (200, 300), "delp": (300, 1500), "DZ": (-500, -50), "ua": (-30, 30), "va": (-30, 30)}.items()},
+        "phis": DataArray(u(0, 1e4, 6, 1, n, n), dims=["tile", "Time", "yaxis_2", "xaxis_1"]),
+    })
+    tracers = ["sphum", "liq_wat", "rainwat", "ice_wat", "snowwat", "graupel", "o3mr", "sgs_tke", "cld_amt"]
+    tracer = Dataset({k: DataArray(u(0, 0.02, 6, 1, NZ, n, n), dims=["tile", "Time", "zaxis_1", "yaxis_1", "xaxis_1"]) for k in tracers})
+    srf = Dataset({k: DataArray(u(-10, 10, 6, 1, n, n), dims=["tile", "Time", "yaxis_1", "xaxis_1"]) for k in ("u_srf", "v_srf")})
+    # surface data: the variables, dims and value ranges of the reference's regression schema (tests/golden metadata)
+    with np.load(os.path.join(ROOT, "tests", "golden", "coarsen_restarts_reference.npz")) as z:
+        meta = json.loads(bytes(z["meta_json"]).decode())
+    rng = np.random.default_rng(0)
+    sfc = Dataset()
+    for name, info in meta["inputs"]["sfc_data"].items():
+        lo, hi = meta["ranges"].get(name, meta["default_range"])
+        shape = list(info["shape"][:-2]) + [n, n]
+        sfc[name] = DataArray(torch.from_numpy(rng.uniform(lo, hi, shape).astype(info["dtype"])).to(dev), dims=info["dims"])
+    grid = Dataset({"area": DataArray(u(0.5, 1, 6, n, n).float(), dims=["tile", "grid_yt", "grid_xt"]),
+                    "dx": DataArray(u(0.5, 1, 6, n + 1, n).float(), dims=["tile", "grid_y", "grid_xt"]),
+                    "dy": DataArray(u(0.5, 1, 6, n, n + 1).float(), dims=["tile", "grid_yt", "grid_x"])})
+    restarts = {"fv_core.res": core, "fv_tracer.res": tracer, "fv_srf_wnd.res": srf, "sfc_data": sfc}
+    nbytes = sum(v.data.numel() * v.data.element_size() for ds in restarts.values() for v in ds.values())
+    out = []
+    for label, fn in (("coarsen_restarts_on_sigma", lambda: coarsen_restarts_on_sigma(f, grid, restarts, coarsen_agrid_winds=True)),
+                      ("coarsen_restarts_on_pressure", lambda: coarsen_restarts_on_pressure(f, grid, 300.0, restarts, coarsen_agrid_winds=True)),
+                      ("coarsen_restarts_via_blended_method",
+                       lambda: coarsen_restarts_via_blended_method(f, grid, 300.0, restarts, coarsen_agrid_winds=True))):
+        fn()
+        torch.cuda.synchronize(dev)
+        t0 = time.perf_counter()
+        for _ in range(reps):
+            fn()
+        torch.cuda.synchronize(dev)
+        ms = (time.perf_counter() - t0) / reps * 1e3
+        out.append({"kernel": f"{label} (whole pipeline, Python API)",
+                    "workload": f"C{n}->C{n // f}, 4 restart categories, {nbytes / 1e9:.2f} GB of float64 restarts in HBM",
+                    "ms": ms, "roofline": {"bound": "hbm", "achieved": nbytes / ms / 1e6, "peak": PEAK_HBM_GBPS, "unit": "GB/s",
+                                           "frac": nbytes / ms / 1e6 / PEAK_HBM_GBPS, "traffic": None,
+                                           "note": "input bytes / wall time; the pressure-level pipelines are bound by the VALU-limited remap"}})
     return out
 
 
