@@ -387,13 +387,46 @@ def dense_local_benchmark(dev, steps):
     ms = time_kernel(fn, max(3, min(steps, 5)), dev)
     flops = 2 * (k * width + width * width + width * 2)
     achieved = flops * NZ * ncol / (ms * 1e-3) / 1e12
-    return [{
+    out = [{
         "kernel": "dense-local emulator (local_pack + mlp_fused_kernel + local_unpack)",
         "workload": f"C384 gscond regressor: {k} inputs -> 2 x {width} -> 2 outputs at each of 79 x {ncol} points, float32 state",
         "ms": ms, "columns_per_s": ncol / ms * 1e3, "flops_per_point": flops,
         "roofline": {"bound": "mfma", "achieved": achieved, "peak": PEAK_FP32_MFMA_TFLOPS, "unit": "TFLOP/s",
                      "frac": achieved / PEAK_FP32_MFMA_TFLOPS, "traffic": None},
     }]
+    del model
+    # the production precpd emulator (configs/models/precpd.yaml: "rnn-v1-shared-weights", 2 stacked SimpleRNN(256) over the
+    # 79 levels, 4 outputs): 79 x 2 launches of the fused kernel, the states ping-ponging in HBM
+    from fv3net_amd.local_mlp import RnnLayer, RnnModel, RnnSpec
+
+    layers, fan = [], k
+    for _ in range(2):
+        layers.append(RnnLayer((rng.normal(0, 1, (fan, width)) / np.sqrt(fan)).astype(np.float32),
+                               (rng.normal(0, 0.6, (width, width)) / np.sqrt(width)).astype(np.float32),
+                               rng.normal(0, 0.1, width).astype(np.float32)))
+        fan = width
+    routs = [LocalOutput("total_precipitation", scale=np.float32(1e-3), center=np.float32(1e-4), single_level=True)] + [
+        LocalOutput(f"{v}_precpd_difference", scale=rng.uniform(0.5, 2, NZ).astype(np.float32), center=rng.normal(0, 0.1, NZ).astype(np.float32),
+                    after=f"{src}_after_precpd", before=f"{src}_input", value_limit=lim)
+        for v, src, lim in (("cloud", "cloud_water_mixing_ratio", (None, 0.0)), ("temperature", "air_temperature", (None, 0.0)),
+                            ("humidity", "specific_humidity", (0.0, None)))]
+    rspec = RnnSpec(inputs=inputs, layers=layers, outputs=routs,
+                    out_kernel=(rng.normal(0, 1, (width, 4)) / np.sqrt(width)).astype(np.float32), out_bias=rng.normal(0, 0.1, 4).astype(np.float32))
+    rmodel = RnnModel(rspec, device=dev)
+    fn = lambda: rmodel.predict(st)
+    fn()
+    torch.cuda.synchronize(dev)
+    ms = time_kernel(fn, 2, dev)
+    flops = 2 * (k * width + 3 * width * width + width * 4)  # the recurrences themselves, without the identity output layers
+    achieved = flops * NZ * ncol / (ms * 1e-3) / 1e12
+    out.append({
+        "kernel": "RNN emulator (local_pack + 79 x 2 mlp_fused_kernel launches + local_unpack)",
+        "workload": f"C384 precpd regressor: {k} inputs -> 2 x SimpleRNN({width}) over 79 levels -> 4 outputs, {ncol} columns, float32 state",
+        "ms": ms, "columns_per_s": ncol / ms * 1e3, "flops_per_point": flops,
+        "roofline": {"bound": "mfma", "achieved": achieved, "peak": PEAK_FP32_MFMA_TFLOPS, "unit": "TFLOP/s",
+                     "frac": achieved / PEAK_FP32_MFMA_TFLOPS, "traffic": None},
+    })
+    return out
 
 
 def main():

@@ -118,8 +118,9 @@ SIGNATURES = {
     "fv3hip_level_scale": (c_int, [c_void_p, c_int, c_void_p, c_int64, c_int, c_int64, c_void_p, c_void_p]),
     "fv3hip_member_reduce": (c_int, [c_void_p, c_int, c_int, c_int, c_int64, c_void_p, c_void_p]),
     "fv3hip_local_pack": (c_int, [c_void_p, c_int, c_int, c_int, c_double, c_void_p, c_void_p, c_int, c_int64, c_void_p, c_void_p]),
-    "fv3hip_local_unpack": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_void_p, c_void_p, c_void_p, c_int, c_double,
-                                    c_void_p, c_int, c_int, c_int64, c_void_p, c_void_p, c_void_p, c_void_p]),
+    "fv3hip_local_unpack": (c_int, [c_void_p, c_int64, c_void_p, c_void_p, c_void_p, c_int, c_void_p, c_void_p, c_void_p, c_int,
+                                    c_double, c_void_p, c_int, c_int, c_double, c_double, c_double, c_double, c_int, c_int64,
+                                    c_void_p, c_void_p, c_void_p, c_void_p]),
     "fv3hip_classify_onehot": (c_int, [c_void_p, c_int, c_int, c_int64, c_void_p, c_void_p, c_int, c_int, c_void_p]),
     "fv3hip_interpolate_2d": (c_int, [c_void_p, c_void_p, c_void_p, c_int64, c_int64, c_int, c_int, c_double, c_int, c_void_p,
                                       c_void_p]),

@@ -8,6 +8,7 @@
 //   external/fv3fit/fv3fit/emulation/transforms/transforms.py:192-224  ConditionallyScaledTransform.backward
 //   external/fv3fit/fv3fit/keras/math.py:5-23                       piecewise (0th-order interpolation)
 //   external/fv3fit/fv3fit/emulation/transforms/transforms.py:55-58 Difference.backward
+//   external/fv3fit/fv3fit/emulation/transforms/transforms.py:131-158 LimitValueTransform.backward
 //   external/emulation/emulation/zhao_carr.py:193-198               _get_classify_output
 //
 // The network between them is mlp_fused_kernel on the packed [n_inputs][nz * ncol] array: a
@@ -56,30 +57,45 @@ __device__ __forceinline__ int bin_of(const float *__restrict__ edges, int n, fl
     return lo > 0 ? lo - 1 : 0;
 }
 
+// LimitValueTransform.backward (transforms.py:148-158): keras relu(x, threshold=lower), then (x < upper) * x;
+// NaN stays NaN
+__device__ __forceinline__ float limit_value(float v, int flags, float lo, float hi)
+{
+    if ((flags & 1) && v < lo) v = 0.f;
+    if ((flags & 2) && !(v < hi) && v == v) v = 0.f;
+    return v;
+}
+
 // one network output channel: direct = yhat * scale[z] + center[z];
 // unscaled = direct * max(cs_scale[bin(on)], min_scale) + cs_center[bin(on)]   (when conditional scaling is configured);
-// after = before + (unscaled if configured else direct)                         (when a Difference is configured)
-__global__ void local_unpack_kernel(const float *__restrict__ yhat, const float *__restrict__ scale,
+// the value limits apply to the last of these;
+// after = limit(before + value)                                                 (when a Difference is configured)
+__global__ void local_unpack_kernel(const float *__restrict__ yhat, int64_t yhat_level_stride, const float *__restrict__ scale,
                                     const float *__restrict__ center, const void *__restrict__ cond_on, int cond_dtype,
                                     const float *__restrict__ edges, const float *__restrict__ cs_scale,
                                     const float *__restrict__ cs_center, int n_bins, float min_scale,
-                                    const void *__restrict__ before, int before_dtype, int nz, int64_t ncol,
+                                    const void *__restrict__ before, int before_dtype, int limit_flags, float value_lo,
+                                    float value_hi, float after_lo, float after_hi, int nz, int64_t ncol,
                                     float *__restrict__ out_direct, float *__restrict__ out_unscaled,
                                     float *__restrict__ out_after)
 {
     const int z = blockIdx.y;
     const float s = scale ? scale[z] : 1.f, c = center ? center[z] : 0.f;
-    const int64_t row = (int64_t)z * ncol;
+    const int64_t row = (int64_t)z * ncol, yrow = (int64_t)z * yhat_level_stride;
     for (int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; i < ncol; i += (int64_t)gridDim.x * blockDim.x) {
-        float v = yhat[row + i] * s + c;
-        if (out_direct) out_direct[row + i] = v;
+        float v = yhat[yrow + i] * s + c;
         if (cond_on) {
+            if (out_direct) out_direct[row + i] = v;
             const int b = bin_of(edges, n_bins, ldf(cond_on, cond_dtype, row + i));
             const float sc = cs_scale[b];
             v = v * (sc > min_scale ? sc : min_scale) + cs_center[b];
+            v = limit_value(v, limit_flags, value_lo, value_hi);
             if (out_unscaled) out_unscaled[row + i] = v;
+        } else {
+            v = limit_value(v, limit_flags, value_lo, value_hi);
+            if (out_direct) out_direct[row + i] = v;
         }
-        if (before) out_after[row + i] = ldf(before, before_dtype, row + i) + v;
+        if (before) out_after[row + i] = limit_value(ldf(before, before_dtype, row + i) + v, limit_flags >> 2, after_lo, after_hi);
     }
 }
 
@@ -132,11 +148,15 @@ extern "C" int fv3hip_local_pack(const void *x, int dtype, int has_levels, int t
     return check_launch("local_pack_kernel");
 }
 
-extern "C" int fv3hip_local_unpack(const float *yhat, const float *scale, const float *center, const void *cond_on,
-                                   int cond_dtype, const float *edges, const float *cs_scale, const float *cs_center,
-                                   int n_bins, double min_scale, const void *before, int before_dtype, int nz, int64_t ncol,
-                                   float *out_direct, float *out_unscaled, float *out_after, void *stream)
+extern "C" int fv3hip_local_unpack(const float *yhat, int64_t yhat_level_stride, const float *scale, const float *center,
+                                   const void *cond_on, int cond_dtype, const float *edges, const float *cs_scale,
+                                   const float *cs_center, int n_bins, double min_scale, const void *before, int before_dtype,
+                                   int limit_flags, double value_lower, double value_upper, double after_lower,
+                                   double after_upper, int nz, int64_t ncol, float *out_direct, float *out_unscaled,
+                                   float *out_after, void *stream)
 {
+    FV3HIP_REQUIRE(limit_flags >= 0 && limit_flags < 16, "limit_flags is a 4-bit mask");
+    FV3HIP_REQUIRE(yhat_level_stride >= ncol || nz <= 1, "yhat_level_stride must be at least ncol");
     FV3HIP_REQUIRE(nz >= 0 && nz <= 65535 && ncol >= 0, "bad extent");
     if (nz == 0 || ncol == 0) return FV3HIP_OK;
     FV3HIP_REQUIRE(yhat, "null pointer");
@@ -149,8 +169,9 @@ extern "C" int fv3hip_local_unpack(const float *yhat, const float *scale, const 
         FV3HIP_REQUIRE(out_after, "a Difference needs its output array");
     }
     FV3HIP_REQUIRE(out_direct || out_unscaled || out_after, "no output requested");
-    hipLaunchKernelGGL(local_unpack_kernel, level_grid(nz, ncol), dim3(256), 0, as_stream(stream), yhat, scale, center, cond_on,
-                       cond_dtype, edges, cs_scale, cs_center, n_bins, (float)min_scale, before, before_dtype, nz, ncol,
+    hipLaunchKernelGGL(local_unpack_kernel, level_grid(nz, ncol), dim3(256), 0, as_stream(stream), yhat, yhat_level_stride, scale,
+                       center, cond_on, cond_dtype, edges, cs_scale, cs_center, n_bins, (float)min_scale, before, before_dtype,
+                       limit_flags, (float)value_lower, (float)value_upper, (float)after_lower, (float)after_upper, nz, ncol,
                        out_direct, out_unscaled, out_after);
     return check_launch("local_unpack_kernel");
 }

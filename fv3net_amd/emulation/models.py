@@ -17,7 +17,7 @@ import torch
 import yaml
 
 from ..cubedsphere._device import compute_device, on_device
-from ..local_mlp import LocalMlpModel, LocalMlpSpec
+from ..local_mlp import LocalMlpModel, LocalMlpSpec, RnnModel, RnnSpec
 from ..mlp import MlpModel, MlpSpec
 from . import zhao_carr
 
@@ -94,23 +94,25 @@ class HipEmulator:
 
 
 class HipLocalEmulator:
-    """A "dense-local" model (``LocalMlpSpec``) with the interface of ``HipEmulator``: dicts of
-    ``[sample, feature]`` (or ``[sample]``) arrays in and out; multi-channel outputs (classifier logits)
-    come back as ``[sample, feature, channel]`` like the Keras model's."""
+    """A "dense-local" (``LocalMlpSpec``) or RNN (``RnnSpec``: "rnn-v1-shared-weights", the production precpd
+    architecture) model with the interface of ``HipEmulator``: dicts of ``[sample, feature]`` (or ``[sample]``)
+    arrays in and out; multi-channel outputs (classifier logits) come back as ``[sample, feature, channel]``
+    like the Keras model's."""
 
     device_resident = True
     _SPEC_FILENAME = HipEmulator._SPEC_FILENAME
     _WEIGHTS_FILENAME = HipEmulator._WEIGHTS_FILENAME
 
-    def __init__(self, spec: LocalMlpSpec, inputs_to_ignore: Sequence[str] = ("rank", "model_time")):
+    def __init__(self, spec, inputs_to_ignore: Sequence[str] = ("rank", "model_time")):
         self.spec = spec
         self.inputs_to_ignore = tuple(inputs_to_ignore)
         self._model = None
 
     @property
-    def model(self) -> LocalMlpModel:
+    def model(self):
         if self._model is None:
-            self._model = LocalMlpModel(self.spec, device=compute_device())
+            cls = RnnModel if isinstance(self.spec, RnnSpec) else LocalMlpModel
+            self._model = cls(self.spec, device=compute_device())
         return self._model
 
     @property
@@ -164,10 +166,13 @@ def load_emulator(path: str, expect=None):
     arch = meta.get("architecture", "dense")
     if arch == "dense-local":
         model = HipLocalEmulator(LocalMlpSpec.from_arrays(meta, arrays))
+    elif arch in ("rnn-v1-shared-weights", "rnn-v1"):  # (both build Conv1D heads, architecture.py:483-506)
+        model = HipLocalEmulator(RnnSpec.from_arrays(meta, arrays))
     elif arch == "dense":
         model = HipEmulator(MlpSpec.from_arrays(meta, arrays))
     else:
-        raise NotImplementedError(f"architecture {arch!r} is not implemented on the device (dense, dense-local are)")
+        raise NotImplementedError(f"architecture {arch!r} is not implemented on the device "
+                                  "(dense, dense-local, rnn-v1-shared-weights are)")
     if expect is not None and not isinstance(model, expect):
         raise TypeError(f"{path} holds a {type(model).__name__}, not a {expect.__name__}")
     return model

@@ -63,6 +63,11 @@ class LocalOutput:
     conditional: Optional[ConditionalScale] = None
     after: Optional[str] = None          # name of the Difference's `after` output
     before: Optional[str] = None         # source array the difference is added to
+    # LimitValueTransform.backward (transforms.py:131-158) on the value the Difference adds (the conditionally
+    # un-scaled one if configured, else the output itself) and on `after`: (lower, upper), None = no bound
+    value_limit: Tuple[Optional[float], Optional[float]] = (None, None)
+    after_limit: Tuple[Optional[float], Optional[float]] = (None, None)
+    single_level: bool = False           # RNN architectures: a [1, ncol] output read off the last (surface) step
 
 
 @dataclasses.dataclass
@@ -134,7 +139,9 @@ class LocalMlpSpec:
                 if getattr(i, key) is not None:
                     arrays[f"in{n}_{key}"] = np.atleast_1d(np.asarray(getattr(i, key), np.float32))
         for n, o in enumerate(self.outputs):
-            m = {"name": o.name, "channels": int(o.channels), "after": o.after, "before": o.before}
+            m = {"name": o.name, "channels": int(o.channels), "after": o.after, "before": o.before,
+                 "value_limit": [None if v is None else float(v) for v in o.value_limit],
+                 "after_limit": [None if v is None else float(v) for v in o.after_limit], "single_level": bool(o.single_level)}
             for key in ("center", "scale"):
                 if getattr(o, key) is not None:
                     arrays[f"out{n}_{key}"] = np.atleast_1d(np.asarray(getattr(o, key), np.float32))
@@ -167,11 +174,87 @@ class LocalMlpSpec:
                                         center=np.asarray(arrays[f"out{n}_cs_center"]))
             outputs.append(LocalOutput(name=m["name"], channels=int(m.get("channels", 1)), scale=arrays.get(f"out{n}_scale"),
                                        center=arrays.get(f"out{n}_center"), conditional=cond, after=m.get("after"),
-                                       before=m.get("before")))
+                                       before=m.get("before"), value_limit=tuple(m.get("value_limit") or (None, None)),
+                                       after_limit=tuple(m.get("after_limit") or (None, None)),
+                                       single_level=bool(m.get("single_level", False))))
         nh = int(meta["n_hidden"])
         return cls(inputs=inputs, hidden_kernels=[np.asarray(arrays[f"hidden{n}_kernel"]) for n in range(nh)],
                    hidden_biases=[np.asarray(arrays[f"hidden{n}_bias"]) for n in range(nh)], outputs=outputs,
                    out_kernel=np.asarray(arrays["out_kernel"]), out_bias=np.asarray(arrays["out_bias"]))
+
+
+@dataclasses.dataclass
+class RnnLayer:
+    """One ``tf.keras.layers.SimpleRNN(channels, activation='relu', return_sequences=True)``:
+    ``h_t = relu(x_t @ kernel + h_{t-1} @ recurrent_kernel + bias)``, ``h_{-1} = 0``."""
+
+    kernel: np.ndarray            # [in, channels]
+    recurrent_kernel: np.ndarray  # [channels, channels]
+    bias: np.ndarray              # [channels]
+
+
+@dataclasses.dataclass
+class RnnSpec:
+    """The "rnn-v1-shared-weights" / "rnn-v1" architecture -- the reference's production precpd emulator
+    (projects/microphysics/configs/models/precpd.yaml:36-41; architecture.py:149-226 ``RNNBlock``: stacked
+    SimpleRNNs that recurse over the levels from the model top (last index) to the surface (index 0), then
+    ``RNNOutput`` kernel-size-1 convolutions; single-level outputs are read off the surface step,
+    architecture.py:403-407).  Inputs and outputs are described as for ``LocalMlpSpec``."""
+
+    inputs: List[LocalInput]
+    layers: List[RnnLayer]
+    outputs: List[LocalOutput]
+    out_kernel: np.ndarray   # [channels, sum(output channels)]
+    out_bias: np.ndarray
+    architecture = "rnn-v1-shared-weights"
+
+    sources = LocalMlpSpec.sources
+    output_names = LocalMlpSpec.output_names
+    n_channels = LocalMlpSpec.n_channels
+
+    def validate(self):
+        if [i.name for i in self.inputs] != sorted(i.name for i in self.inputs):
+            raise ValueError("inputs must be listed sorted by their network name (combine_sequence_inputs)")
+        if not self.layers:
+            raise ValueError("at least one recurrent layer")
+        fan = len(self.inputs)
+        for n, layer in enumerate(self.layers):
+            ch = int(layer.kernel.shape[1])
+            if tuple(layer.kernel.shape) != (fan, ch) or tuple(layer.recurrent_kernel.shape) != (ch, ch) or tuple(layer.bias.shape) != (ch,):
+                raise ValueError(f"recurrent layer {n}: kernel {layer.kernel.shape}, recurrent kernel {layer.recurrent_kernel.shape}, "
+                                 f"bias {layer.bias.shape} do not fit {fan} inputs")
+            fan = ch
+        if tuple(self.out_kernel.shape) != (fan, self.n_channels) or tuple(self.out_bias.shape) != (self.n_channels,):
+            raise ValueError(f"output kernel has shape {self.out_kernel.shape}, expected {(fan, self.n_channels)}")
+        for o in self.outputs:
+            if o.channels != 1:
+                raise ValueError("multi-channel outputs are not supported by the RNN architectures here")
+            if (o.after is None) != (o.before is None):
+                raise ValueError(f"output {o.name!r}: 'after' and 'before' go together")
+            if o.single_level and (o.conditional is not None or o.after is not None):
+                raise ValueError(f"single-level output {o.name!r} cannot carry level-wise transforms")
+
+    def to_arrays(self) -> Tuple[dict, Dict[str, np.ndarray]]:
+        shell = LocalMlpSpec(self.inputs, [np.zeros((len(self.inputs), 1), np.float32)], [np.zeros(1, np.float32)], self.outputs,
+                             self.out_kernel, self.out_bias)
+        meta, arrays = shell.to_arrays()
+        for key in ("hidden0_kernel", "hidden0_bias"):
+            del arrays[key]
+        meta["architecture"] = self.architecture
+        meta["n_hidden"] = 0
+        meta["n_rnn"] = len(self.layers)
+        for n, layer in enumerate(self.layers):
+            arrays[f"rnn{n}_kernel"] = np.asarray(layer.kernel, np.float32)
+            arrays[f"rnn{n}_recurrent_kernel"] = np.asarray(layer.recurrent_kernel, np.float32)
+            arrays[f"rnn{n}_bias"] = np.asarray(layer.bias, np.float32)
+        return meta, arrays
+
+    @classmethod
+    def from_arrays(cls, meta: Mapping, arrays: Mapping[str, np.ndarray]) -> "RnnSpec":
+        shell = LocalMlpSpec.from_arrays({**meta, "n_hidden": 0}, arrays)
+        layers = [RnnLayer(np.asarray(arrays[f"rnn{n}_kernel"]), np.asarray(arrays[f"rnn{n}_recurrent_kernel"]),
+                           np.asarray(arrays[f"rnn{n}_bias"])) for n in range(int(meta["n_rnn"]))]
+        return cls(inputs=shell.inputs, layers=layers, outputs=shell.outputs, out_kernel=shell.out_kernel, out_bias=shell.out_bias)
 
 
 def _per_level(values, nz: int, default: float, what: str) -> np.ndarray:
@@ -185,18 +268,17 @@ def _per_level(values, nz: int, default: float, what: str) -> np.ndarray:
     return np.ascontiguousarray(a)
 
 
-class LocalMlpModel:
-    """Device handle of a dense-local emulator."""
+def _dt(t: torch.Tensor) -> int:
+    return _lib.F64 if t.dtype == torch.float64 else _lib.F32
 
-    def __init__(self, spec: LocalMlpSpec, device="cuda"):
+
+class _PointModel:
+    """What the dense-local and the RNN models share: source checks, the pack pass, the unpack pass."""
+
+    def __init__(self, spec, device):
         spec.validate()
         self.spec = spec
         self.device = torch.device(device)
-        k, c = len(spec.inputs), spec.n_channels
-        self._inner = MlpModel(MlpSpec(
-            inputs=[InputSpec("X", k)], hidden_kernels=spec.hidden_kernels, hidden_biases=spec.hidden_biases,
-            outputs=[OutputSpec("Y", c)], out_kernel=spec.out_kernel, out_bias=spec.out_bias), device=self.device)
-        self.flops_per_point = self._inner.flops_per_sample
         self._tables: Dict[Tuple[str, int], torch.Tensor] = {}
 
     def _table(self, key: str, values, nz: Optional[int], default: float = 0.0) -> torch.Tensor:
@@ -207,13 +289,10 @@ class LocalMlpModel:
             self._tables[ck] = torch.from_numpy(a).to(self.device)
         return self._tables[ck]
 
-    def predict(self, sources: Mapping[str, torch.Tensor]) -> Dict[str, torch.Tensor]:
-        """``sources``: name -> device array ``[nz, ncol]`` (or ``[ncol]`` / ``[1, ncol]``), float32 or float64.
-        Returns name -> float32 ``[nz, ncol]`` (``[channels, nz, ncol]`` for multi-channel outputs)."""
-        spec = self.spec
+    def _gather(self, sources: Mapping[str, torch.Tensor]):
         arrs: Dict[str, torch.Tensor] = {}
         nz = ncol = None
-        for name in spec.sources:
+        for name in self.spec.sources:
             t = sources[name]
             if t.dtype not in (torch.float32, torch.float64):
                 raise TypeError(f"source {name!r} must be float32 or float64, got {t.dtype}")
@@ -232,51 +311,132 @@ class LocalMlpModel:
                     raise ValueError("sources differ in their number of levels")
             arrs[name] = t.contiguous()
         nz = 1 if nz is None else nz
-        dev = _require_device(*arrs.values())
-        st = _stream(dev)
-        k, c = len(spec.inputs), spec.n_channels
-        x = torch.empty((k, nz * ncol), dtype=torch.float32, device=dev)
-        for n, i in enumerate(spec.inputs):
+        for o in self.spec.outputs:
+            for need in ([o.conditional.on] if o.conditional else []) + ([o.before] if o.before else []):
+                if arrs[need].shape[0] != nz:
+                    raise ValueError(f"source {need!r} must have {nz} levels")
+        return arrs, nz, ncol, _require_device(*arrs.values())
+
+    def _pack(self, arrs, nz: int, ncol: int, dev) -> torch.Tensor:
+        x = torch.empty((len(self.spec.inputs), nz * ncol), dtype=torch.float32, device=dev)
+        for n, i in enumerate(self.spec.inputs):
             t = arrs[i.source]
-            _lib.call("fv3hip_local_pack", _ptr(t), _lib.F64 if t.dtype == torch.float64 else _lib.F32, int(t.shape[0] != 1),
+            _lib.call("fv3hip_local_pack", _ptr(t), _dt(t), int(t.shape[0] != 1),
                       _lib.TRANSFORM_LOG if i.transform == "log" else _lib.TRANSFORM_NONE, float(i.eps),
                       _ptr(self._table(f"in{n}_center", i.center, nz, 0.0)), _ptr(self._table(f"in{n}_scale", i.scale, nz, 1.0)),
-                      nz, ncol, _ptr(x[n]), st)
+                      nz, ncol, _ptr(x[n]), _stream(dev))
+        return x
+
+    def _unpack_one(self, n: int, o: LocalOutput, rows: torch.Tensor, level_stride: int, arrs, nz: int, ncol: int, dev,
+                    out: Dict[str, torch.Tensor]) -> None:
+        """Output ``o`` (index ``n``) from its network rows (level z at ``rows + z * level_stride``)."""
+        direct = torch.empty((nz, ncol), dtype=torch.float32, device=dev)
+        cond, unscaled, after = o.conditional, None, None
+        cond_args = [None, 0, None, None, None, 0, 0.0]
+        if cond is not None:
+            unscaled = torch.empty_like(direct)
+            on = arrs[cond.on]
+            cond_args = [_ptr(on), _dt(on), _ptr(self._table(f"out{n}_cs_edges", cond.edges, None)),
+                         _ptr(self._table(f"out{n}_cs_scale", cond.scale, None)),
+                         _ptr(self._table(f"out{n}_cs_center", cond.center, None)), int(len(cond.edges)), float(cond.min_scale)]
+        before_args = [None, 0]
+        if o.before is not None:
+            after = torch.empty_like(direct)
+            before_args = [_ptr(arrs[o.before]), _dt(arrs[o.before])]
+        bounds = list(o.value_limit) + list(o.after_limit)
+        flags = sum(1 << b for b, v in enumerate(bounds) if v is not None)
+        _lib.call("fv3hip_local_unpack", _ptr(rows), int(level_stride),
+                  _ptr(self._table(f"out{n}_scale", o.scale, nz, 1.0)) if o.scale is not None else None,
+                  _ptr(self._table(f"out{n}_center", o.center, nz, 0.0)) if o.center is not None else None,
+                  *cond_args, *before_args, flags, *[0.0 if v is None else float(v) for v in bounds], nz, ncol,
+                  _ptr(direct), _ptr(unscaled), _ptr(after), _stream(dev))
+        out[o.name] = direct
+        if cond is not None:
+            out[cond.name] = unscaled
+        if o.after is not None:
+            out[o.after] = after
+
+
+class LocalMlpModel(_PointModel):
+    """Device handle of a dense-local emulator."""
+
+    def __init__(self, spec: LocalMlpSpec, device="cuda"):
+        super().__init__(spec, device)
+        k, c = len(spec.inputs), spec.n_channels
+        self._inner = MlpModel(MlpSpec(
+            inputs=[InputSpec("X", k)], hidden_kernels=spec.hidden_kernels, hidden_biases=spec.hidden_biases,
+            outputs=[OutputSpec("Y", c)], out_kernel=spec.out_kernel, out_bias=spec.out_bias), device=self.device)
+        self.flops_per_point = self._inner.flops_per_sample
+
+    def predict(self, sources: Mapping[str, torch.Tensor]) -> Dict[str, torch.Tensor]:
+        """``sources``: name -> device array ``[nz, ncol]`` (or ``[ncol]`` / ``[1, ncol]``), float32 or float64.
+        Returns name -> float32 ``[nz, ncol]`` (``[channels, nz, ncol]`` for multi-channel outputs)."""
+        arrs, nz, ncol, dev = self._gather(sources)
+        x = self._pack(arrs, nz, ncol, dev)
         y = self._inner.predict({"X": x})["Y"]  # [sum(channels), nz * ncol]
         del x
         out: Dict[str, torch.Tensor] = {}
         row = 0
-        for n, o in enumerate(spec.outputs):
+        for n, o in enumerate(self.spec.outputs):
             rows = y[row:row + o.channels]
             row += o.channels
             if o.channels != 1:
                 out[o.name] = rows.reshape(o.channels, nz, ncol)
-                continue
-            for need in ([o.conditional.on] if o.conditional else []) + ([o.before] if o.before else []):
-                if arrs[need].shape[0] != nz:
-                    raise ValueError(f"source {need!r} must have {nz} levels")
-            direct = torch.empty((nz, ncol), dtype=torch.float32, device=dev)
-            cond, unscaled, after = o.conditional, None, None
-            cond_args = [None, 0, None, None, None, 0, 0.0]
-            if cond is not None:
-                unscaled = torch.empty_like(direct)
-                on = arrs[cond.on]
-                cond_args = [_ptr(on), _lib.F64 if on.dtype == torch.float64 else _lib.F32,
-                             _ptr(self._table(f"out{n}_cs_edges", cond.edges, None)),
-                             _ptr(self._table(f"out{n}_cs_scale", cond.scale, None)),
-                             _ptr(self._table(f"out{n}_cs_center", cond.center, None)), int(len(cond.edges)), float(cond.min_scale)]
-            before_args = [None, 0]
-            if o.before is not None:
-                after = torch.empty_like(direct)
-                b = arrs[o.before]
-                before_args = [_ptr(b), _lib.F64 if b.dtype == torch.float64 else _lib.F32]
-            _lib.call("fv3hip_local_unpack", _ptr(rows),
-                      _ptr(self._table(f"out{n}_scale", o.scale, nz, 1.0)) if o.scale is not None else None,
-                      _ptr(self._table(f"out{n}_center", o.center, nz, 0.0)) if o.center is not None else None,
-                      *cond_args, *before_args, nz, ncol, _ptr(direct), _ptr(unscaled), _ptr(after), st)
-            out[o.name] = direct
-            if cond is not None:
-                out[cond.name] = unscaled
-            if o.after is not None:
-                out[o.after] = after
+            else:
+                self._unpack_one(n, o, rows, ncol, arrs, nz, ncol, dev, out)
+        return out
+
+
+class RnnModel(_PointModel):
+    """Device handle of an RNN emulator.  Every SimpleRNN step of every layer is one launch of the fused MLP
+    kernel over all columns: hidden layer = the cell, ``relu([x_t, h_{t-1}] @ [kernel; recurrent_kernel] + bias)``,
+    output layer = the identity (the new state) -- for the last layer stacked with the output convolutions,
+    whose rows go straight into the level's slice of the output array.  79 levels x depth launches per call,
+    each with ``ncol`` samples; the states ping-pong between two buffers per layer."""
+
+    def __init__(self, spec: RnnSpec, device="cuda"):
+        super().__init__(spec, device)
+        self._cells: List[MlpModel] = []
+        c = spec.n_channels
+        for n, layer in enumerate(spec.layers):
+            fan, ch = int(layer.kernel.shape[0]), int(layer.kernel.shape[1])
+            last = n == len(spec.layers) - 1
+            eye = np.eye(ch, dtype=np.float32)
+            outputs = [OutputSpec("h", ch)] + ([OutputSpec("y", c)] if last else [])
+            out_kernel = np.concatenate([eye, np.asarray(spec.out_kernel, np.float32)], axis=1) if last else eye
+            out_bias = np.concatenate([np.zeros(ch, np.float32), np.asarray(spec.out_bias, np.float32)]) if last else np.zeros(ch, np.float32)
+            self._cells.append(MlpModel(MlpSpec(
+                inputs=[InputSpec("in", fan), InputSpec("rec", ch)],
+                hidden_kernels=[np.concatenate([layer.kernel, layer.recurrent_kernel], axis=0).astype(np.float32)],
+                hidden_biases=[np.asarray(layer.bias, np.float32)], outputs=outputs, out_kernel=out_kernel, out_bias=out_bias),
+                device=self.device))
+        self.flops_per_point = sum(m.flops_per_sample for m in self._cells)
+
+    def predict(self, sources: Mapping[str, torch.Tensor]) -> Dict[str, torch.Tensor]:
+        """As ``LocalMlpModel.predict``; single-level outputs come back as ``[1, ncol]``."""
+        spec = self.spec
+        arrs, nz, ncol, dev = self._gather(sources)
+        x = self._pack(arrs, nz, ncol, dev).view(len(spec.inputs), nz, ncol)
+        c = spec.n_channels
+        y = torch.empty((c, nz, ncol), dtype=torch.float32, device=dev)
+        states = []
+        for m in self._cells:
+            ch = m.spec.width
+            states.append([torch.zeros((ch, ncol), dtype=torch.float32, device=dev), torch.empty((ch, ncol), dtype=torch.float32, device=dev)])
+        for step, z in enumerate(range(nz - 1, -1, -1)):  # from the model top (last index) to the surface
+            cur, nxt = step & 1, (step & 1) ^ 1
+            below = x[:, z]
+            for n, m in enumerate(self._cells):
+                outs = {"h": states[n][nxt]}
+                if n == len(self._cells) - 1:
+                    outs["y"] = y[:, z]
+                m.predict({"in": below, "rec": states[n][cur]}, out=outs)
+                below = states[n][nxt]
+        del x, states
+        out: Dict[str, torch.Tensor] = {}
+        for n, o in enumerate(spec.outputs):
+            if o.single_level:  # the surface step holds the whole column's information (architecture.py:403-407)
+                self._unpack_one(n, o, y[n, 0], ncol, arrs, 1, ncol, dev, out)
+            else:
+                self._unpack_one(n, o, y[n], ncol, arrs, nz, ncol, dev, out)
         return out

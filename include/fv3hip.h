@@ -365,8 +365,12 @@ int fv3hip_hydrostatic_balance(const void *dz, const void *phis, const void *t, 
  *                            unscaled = direct * max(cs_scale[b], min_scale) + cs_center[b],
  *                                       b = max(upper_bound(edges[0..n_bins), cond_on) - 1, 0)
  *                                       (keras/math.py:5-23 piecewise)          (cond_on NULL = skipped)
- *                            after    = before + (unscaled or direct)           (before NULL = skipped)
- *                          any of out_direct / out_unscaled / out_after may be NULL
+ *                            LimitValueTransform.backward (transforms.py:131-158) on the last of these:
+ *                                       x < value_lower -> 0 (limit_flags bit 0), x >= value_upper -> 0 (bit 1)
+ *                            after    = before + that value, limited likewise with after_lower / after_upper
+ *                                       (bits 2, 3)                             (before NULL = skipped)
+ *                          level z of yhat starts at yhat + z * yhat_level_stride; any of out_direct /
+ *                          out_unscaled / out_after may be NULL
  *   fv3hip_classify_onehot logits [n_class][n] -> onehot [n_class][n] (logits == max over classes,
  *                          ties all hot) and any_of [n] = onehot[cls_a] | onehot[cls_b]
  *                          (emulation/zhao_carr.py:193-198 _get_classify_output); any_of may be NULL
@@ -374,12 +378,13 @@ int fv3hip_hydrostatic_balance(const void *dz, const void *phis, const void *t, 
 int fv3hip_local_pack(const void *x, int dtype, int has_levels, int transform, double eps,
                       const float *center, const float *scale, int nz, int64_t ncol, float *out,
                       void *stream);
-int fv3hip_local_unpack(const float *yhat, const float *scale, const float *center,
-                        const void *cond_on, int cond_dtype, const float *edges,
-                        const float *cs_scale, const float *cs_center, int n_bins,
-                        double min_scale, const void *before, int before_dtype, int nz,
-                        int64_t ncol, float *out_direct, float *out_unscaled, float *out_after,
-                        void *stream);
+int fv3hip_local_unpack(const float *yhat, int64_t yhat_level_stride, const float *scale,
+                        const float *center, const void *cond_on, int cond_dtype,
+                        const float *edges, const float *cs_scale, const float *cs_center,
+                        int n_bins, double min_scale, const void *before, int before_dtype,
+                        int limit_flags, double value_lower, double value_upper,
+                        double after_lower, double after_upper, int nz, int64_t ncol,
+                        float *out_direct, float *out_unscaled, float *out_after, void *stream);
 int fv3hip_classify_onehot(const void *logits, int dtype, int n_class, int64_t n,
                            uint8_t *onehot, uint8_t *any_of, int cls_a, int cls_b, void *stream);
 

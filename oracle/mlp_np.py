@@ -122,16 +122,18 @@ def conditionally_scaled_backward(y, on, edges, scale, center, min_scale=0.0):
     return y * limited.astype(y.dtype) + piecewise(edges, center, on).astype(y.dtype)
 
 
-def forward_local(spec, sources, dtype=np.float32):
-    """Evaluate an ``fv3net_amd.local_mlp.LocalMlpSpec``-shaped description (duck-typed).
+def limit_value_backward(x, lower=None, upper=None):
+    """LimitValueTransform.backward (transforms/transforms.py:148-158): ``relu(x, threshold=lower)`` (x where
+    x >= lower, else 0), then ``cast(x < upper) * x``."""
+    if lower is not None:
+        x = np.where(x < np.asarray(lower, x.dtype), np.zeros((), x.dtype), x)
+    if upper is not None:
+        x = np.where(~(x < np.asarray(upper, x.dtype)) & ~np.isnan(x), np.zeros((), x.dtype), x)
+    return x
 
-    Follows layers/architecture.py:53-75 (combine_sequence_inputs: inputs sorted by name, [sample, 1]
-    inputs repeated over the levels, stacked on a last axis), :228-282 (MLPBlock on the last axis),
-    :346-417 (RNNOutput with shared kernel-size-1 convolutions: a Dense on the last axis, squeezed when
-    it has one channel), layers/fields.py:6-66 (per-level normalisation), transforms.py:111-129
-    (log(max(x, eps))), :219-224, :55-58 (backward transforms, reverse order).
-    ``sources``: name -> [sample, nz] (or [sample] / [sample, 1]).  Returns name -> [sample, nz]
-    (``[sample, nz, channels]`` for multi-channel outputs)."""
+
+def _local_inputs(spec, sources, dtype):
+    """layers/architecture.py:53-75 + layers/fields.py:6-41 + transforms.py:111-129: [sample, nz, n_inputs]."""
     src = {}
     nz = 1
     for name, arr in sources.items():
@@ -149,10 +151,13 @@ def forward_local(spec, sources, dtype=np.float32):
         scale = np.ones(1, np.float32) if i.scale is None else np.atleast_1d(np.asarray(i.scale, np.float32))
         x = (x - center.astype(dtype)) / scale.astype(dtype)
         cols.append(np.broadcast_to(x, (x.shape[0], nz))[..., None])
-    h = np.concatenate(cols, axis=-1)  # [sample, nz, n_inputs]
-    for kern, b in zip(spec.hidden_kernels, spec.hidden_biases):
-        h = np.maximum(h @ np.asarray(kern, np.float32).astype(dtype) + np.asarray(b, np.float32).astype(dtype), 0)
-    yhat = h @ np.asarray(spec.out_kernel, np.float32).astype(dtype) + np.asarray(spec.out_bias, np.float32).astype(dtype)
+    return np.concatenate(cols, axis=-1), src
+
+
+def _local_outputs(spec, yhat, src, dtype):
+    """layers/fields.py:44-66, then the backward transforms in reverse order of the training config:
+    conditional un-scaling (transforms.py:219-224), value limits (:148-158), differences (:55-58), limits on
+    the ``after`` values."""
     out = {}
     c0 = 0
     for o in spec.outputs:
@@ -162,15 +167,62 @@ def forward_local(spec, sources, dtype=np.float32):
             out[o.name] = y
             continue
         y = y[..., 0]
+        if getattr(o, "single_level", False):
+            y = y[:, 0:1]  # rnn_outputs[..., 0:1, :] (architecture.py:403-407)
         scale = np.ones(1, np.float32) if o.scale is None else np.atleast_1d(np.asarray(o.scale, np.float32))
         center = np.zeros(1, np.float32) if o.center is None else np.atleast_1d(np.asarray(o.center, np.float32))
         y = y * scale.astype(dtype) + center.astype(dtype)
-        out[o.name] = y
+        value_limit = getattr(o, "value_limit", (None, None))
+        after_limit = getattr(o, "after_limit", (None, None))
         if o.conditional is not None:
+            out[o.name] = y
             c = o.conditional
             y = conditionally_scaled_backward(y, src[c.on], np.asarray(c.edges, np.float32), np.asarray(c.scale, np.float32),
                                               np.asarray(c.center, np.float32), c.min_scale)
+            y = limit_value_backward(y, *value_limit)
             out[c.name] = y
+        else:
+            y = limit_value_backward(y, *value_limit)
+            out[o.name] = y
         if o.after is not None:
-            out[o.after] = src[o.before] + y
+            out[o.after] = limit_value_backward(src[o.before] + y, *after_limit)
     return out
+
+
+def forward_local(spec, sources, dtype=np.float32):
+    """Evaluate an ``fv3net_amd.local_mlp.LocalMlpSpec``-shaped description (duck-typed).
+
+    Follows layers/architecture.py:53-75 (combine_sequence_inputs: inputs sorted by name, [sample, 1]
+    inputs repeated over the levels, stacked on a last axis), :228-282 (MLPBlock on the last axis),
+    :346-417 (RNNOutput with shared kernel-size-1 convolutions: a Dense on the last axis, squeezed when
+    it has one channel), layers/fields.py:6-66 (per-level normalisation), transforms.py:111-129
+    (log(max(x, eps))), :219-224, :55-58 (backward transforms, reverse order).
+    ``sources``: name -> [sample, nz] (or [sample] / [sample, 1]).  Returns name -> [sample, nz]
+    (``[sample, nz, channels]`` for multi-channel outputs)."""
+    h, src = _local_inputs(spec, sources, dtype)  # [sample, nz, n_inputs]
+    for kern, b in zip(spec.hidden_kernels, spec.hidden_biases):
+        h = np.maximum(h @ np.asarray(kern, np.float32).astype(dtype) + np.asarray(b, np.float32).astype(dtype), 0)
+    yhat = h @ np.asarray(spec.out_kernel, np.float32).astype(dtype) + np.asarray(spec.out_bias, np.float32).astype(dtype)
+    return _local_outputs(spec, yhat, src, dtype)
+
+
+def forward_rnn(spec, sources, dtype=np.float32):
+    """Evaluate an ``fv3net_amd.local_mlp.RnnSpec``-shaped description: layers/architecture.py:149-226 (RNNBlock:
+    the level axis reversed, stacked ``SimpleRNN(channels, activation='relu', return_sequences=True)`` --
+    ``h_t = relu(x_t W + h_{t-1} U + b)``, zero initial state, Keras 2.8 -- and reversed back) and :346-417
+    (RNNOutput; outputs of feature length 1 read level 0)."""
+    seq, src = _local_inputs(spec, sources, dtype)
+    seq = seq[:, ::-1, :]
+    for layer in spec.layers:
+        w = np.asarray(layer.kernel, np.float32).astype(dtype)
+        u = np.asarray(layer.recurrent_kernel, np.float32).astype(dtype)
+        b = np.asarray(layer.bias, np.float32).astype(dtype)
+        state = np.zeros((seq.shape[0], w.shape[1]), dtype)
+        steps = []
+        for t in range(seq.shape[1]):
+            state = np.maximum(seq[:, t] @ w + state @ u + b, 0)
+            steps.append(state)
+        seq = np.stack(steps, axis=1)
+    rnn_out = seq[:, ::-1, :]
+    yhat = rnn_out @ np.asarray(spec.out_kernel, np.float32).astype(dtype) + np.asarray(spec.out_bias, np.float32).astype(dtype)
+    return _local_outputs(spec, yhat, src, dtype)

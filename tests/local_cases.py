@@ -79,7 +79,35 @@ def classifier(rng, st, nz, width=64, depth=2, make=None):
     return m.spec(inputs=inputs, hidden_kernels=hk, hidden_biases=hb, outputs=outs, out_kernel=ok, out_bias=ob)
 
 
-def product_makers():
-    from fv3net_amd.local_mlp import ConditionalScale, LocalInput, LocalMlpSpec, LocalOutput
+def precpd_rnn(rng, st, nz, channels=64, depth=2, make=None):
+    """The production precpd model in miniature (projects/microphysics/configs/models/precpd.yaml): stacked
+    SimpleRNNs over the levels, a single-level output (total_precipitation), limited differences added to the
+    after-gscond state, the cloud limited to be non-negative."""
+    m = make or NS(input=NS, output=NS, cond=NS, spec=NS, rnn_spec=NS, rnn_layer=NS)
+    inputs = _inputs(rng, st, nz, m.input)
+    layers, fan = [], len(inputs)
+    for _ in range(depth):
+        layers.append(m.rnn_layer(kernel=(rng.normal(0, 1, (fan, channels)) / np.sqrt(fan)).astype(np.float32),
+                                  recurrent_kernel=(rng.normal(0, 0.6, (channels, channels)) / np.sqrt(channels)).astype(np.float32),
+                                  bias=rng.normal(0, 0.1, channels).astype(np.float32)))
+        fan = channels
+    common = dict(channels=1, conditional=None)
+    outs = [
+        m.output(name="total_precipitation", scale=np.float32(1e-3), center=np.float32(2e-4), after=None, before=None,
+                 value_limit=(None, None), after_limit=(None, None), single_level=True, **common),
+        m.output(name="cloud_precpd_difference", scale=(1e-4 * rng.uniform(0.5, 2, nz)).astype(np.float32),
+                 center=rng.normal(0, 1e-5, nz).astype(np.float32), after="cloud_water_mixing_ratio_after_precpd",
+                 before=CLOUD_IN, value_limit=(None, 0.0), after_limit=(0.0, None), single_level=False, **common),
+        m.output(name="humidity_precpd_difference", scale=(1e-4 * rng.uniform(0.5, 2, nz)).astype(np.float32),
+                 center=rng.normal(0, 1e-5, nz).astype(np.float32), after="specific_humidity_after_precpd", before=QV_IN,
+                 value_limit=(0.0, None), after_limit=(None, None), single_level=False, **common),
+    ]
+    return m.rnn_spec(inputs=inputs, layers=layers, outputs=outs,
+                      out_kernel=(rng.normal(0, 1, (channels, 3)) / np.sqrt(channels)).astype(np.float32),
+                      out_bias=rng.normal(0, 0.1, 3).astype(np.float32))
 
-    return NS(input=LocalInput, output=LocalOutput, cond=ConditionalScale, spec=LocalMlpSpec)
+
+def product_makers():
+    from fv3net_amd.local_mlp import ConditionalScale, LocalInput, LocalMlpSpec, LocalOutput, RnnLayer, RnnSpec
+
+    return NS(input=LocalInput, output=LocalOutput, cond=ConditionalScale, spec=LocalMlpSpec, rnn_spec=RnnSpec, rnn_layer=RnnLayer)

@@ -181,3 +181,34 @@ def test_hook_with_classifier_and_classifier_masks(tmp_path):
     np.testing.assert_array_equal(state["zero_cloud"], zero_cloud)
     for k in st:  # inputs untouched
         np.testing.assert_array_equal(state[k], before[k])
+
+
+@pytest.mark.parametrize("nz,ncol,dtype,channels", [(79, 256, np.float64, 256), (17, 333, np.float32, 64), (5, 64, np.float64, 32)])
+def test_rnn_emulator_matches_oracle(nz, ncol, dtype, channels, tmp_path):
+    """The production precpd architecture (stacked SimpleRNNs over the levels, surface-step single-level output,
+    limited differences): every level step of every layer is one launch of the fused MLP kernel."""
+    from fv3net_amd.emulation.models import HipLocalEmulator, load_emulator
+    from fv3net_amd.local_mlp import RnnModel
+
+    rng = np.random.default_rng(nz + ncol)
+    st = cases.state(rng, nz, ncol, dtype)
+    spec = cases.precpd_rnn(rng, st, nz, channels=channels, make=cases.product_makers())
+    got = RnnModel(spec, device="cuda").predict(_dev(st))
+    truth = mlp_np.forward_rnn(spec, {k: v.T for k, v in st.items()}, dtype=np.float64)
+    assert list(got) == spec.output_names
+    f32 = mlp_np.forward_rnn(spec, {k: v.T for k, v in st.items()}, dtype=np.float32)
+    for name in spec.output_names:
+        g, t = got[name].cpu().numpy(), truth[name].T
+        assert g.shape == t.shape == ((1, ncol) if name == "total_precipitation" else (nz, ncol)), name
+        scale = np.max(np.abs(t))
+        # the recurrence compounds rounding over nz steps: no worse than a few times the float32 CPU evaluation
+        e_gpu, e_f32 = np.max(np.abs(g - t)), np.max(np.abs(f32[name].T - t))
+        assert e_gpu <= 1e-5 * scale + 4 * e_f32, (name, e_gpu / scale, e_f32 / scale)
+    assert (got["cloud_water_mixing_ratio_after_precpd"] >= 0).all() and (got["cloud_precpd_difference"] <= 0).all()
+    # dump / load round trip through the emulator directory format
+    HipLocalEmulator(spec).dump(str(tmp_path / "precpd"))
+    loaded = load_emulator(str(tmp_path / "precpd"))
+    assert yaml.safe_load(open(tmp_path / "precpd" / "spec.yaml"))["architecture"] == "rnn-v1-shared-weights"
+    out = loaded({k: v.T for k, v in st.items()})
+    for name in spec.output_names:
+        np.testing.assert_array_equal(out[name].T, got[name].cpu().numpy())

@@ -144,3 +144,54 @@ def test_forward_local_against_torch_cpu(dtype, tol):
             np.testing.assert_allclose(got[c.name], ref.numpy(), rtol=tol, atol=tol * float(ref.abs().max()))
             ref = torch.from_numpy(st[o.before].T.astype(np.float32)).to(td) + ref
             np.testing.assert_allclose(got[o.after], ref.numpy(), rtol=tol, atol=tol * float(ref.abs().max()))
+
+
+def test_limit_value_backward_known_answers():
+    # external/fv3fit/fv3fit/emulation/transforms/transforms.py:131-158 (keras relu with a threshold, then the upper mask)
+    x = np.array([-2.0, -1.0, 0.0, 1.0, 2.0, np.nan], np.float32)
+    np.testing.assert_array_equal(mlp_np.limit_value_backward(x, 0.0, None), [0, 0, 0, 1, 2, np.nan])
+    np.testing.assert_array_equal(mlp_np.limit_value_backward(x, None, 0.0), [-2, -1, 0, 0, 0, np.nan])
+    np.testing.assert_array_equal(mlp_np.limit_value_backward(x, -1.0, 2.0), [0, -1, 0, 1, 0, np.nan])
+
+
+@pytest.mark.parametrize("dtype,tol", [(np.float64, 1e-12), (np.float32, 5e-5)])
+def test_forward_rnn_against_torch_cpu(dtype, tol):
+    """RNNBlock against torch.nn.RNN(nonlinearity='relu') -- the same recurrence as Keras' SimpleRNN -- run from
+    the last level to the first, two stacked layers, Conv1d(kernel_size=1) heads."""
+    import local_cases
+
+    rng = np.random.default_rng(9)
+    nz, ncol, ch = 11, 30, 16
+    st = local_cases.state(rng, nz, ncol)
+    spec = local_cases.precpd_rnn(rng, st, nz, channels=ch)
+    got = mlp_np.forward_rnn(spec, {k: v.T for k, v in st.items()}, dtype=dtype)
+    td = torch.float64 if dtype == np.float64 else torch.float32
+    cols = []
+    for i in spec.inputs:
+        x = torch.from_numpy(np.atleast_2d(st[i.source]).T.astype(np.float32)).to(td)
+        if i.transform == "log":
+            x = torch.log(torch.clamp(x, min=float(np.float32(i.eps))))
+        x = (x - torch.from_numpy(np.atleast_1d(i.center)).to(td)) / torch.tensor(float(i.scale), dtype=td)
+        cols.append(x.expand(ncol, nz).unsqueeze(-1))
+    seq = torch.flip(torch.cat(cols, -1), dims=[1])
+    for layer in spec.layers:
+        rnn = torch.nn.RNN(layer.kernel.shape[0], ch, nonlinearity="relu", batch_first=True).to(td)
+        with torch.no_grad():
+            rnn.weight_ih_l0.copy_(torch.from_numpy(layer.kernel.T.copy()))
+            rnn.weight_hh_l0.copy_(torch.from_numpy(layer.recurrent_kernel.T.copy()))
+            rnn.bias_ih_l0.copy_(torch.from_numpy(layer.bias))
+            rnn.bias_hh_l0.zero_()
+            seq, _ = rnn(seq)
+    h = torch.flip(seq, dims=[1])
+    y = (h @ torch.from_numpy(spec.out_kernel).to(td) + torch.from_numpy(spec.out_bias).to(td)).detach()
+    o = spec.outputs
+    ref = y[:, 0:1, 0] * float(o[0].scale) + float(o[0].center)
+    np.testing.assert_allclose(got["total_precipitation"], ref.numpy(), rtol=tol, atol=tol * float(ref.abs().max()))
+    assert got["total_precipitation"].shape == (ncol, 1)
+    d = y[..., 1] * torch.from_numpy(o[1].scale).to(td) + torch.from_numpy(o[1].center).to(td)
+    d = torch.where(d < 0, d, torch.zeros_like(d))
+    np.testing.assert_allclose(got["cloud_precpd_difference"], d.numpy(), rtol=tol, atol=tol * float(d.abs().max()))
+    after = torch.relu(torch.from_numpy(st[local_cases.CLOUD_IN].T.astype(np.float32)).to(td) + d)
+    np.testing.assert_allclose(got["cloud_water_mixing_ratio_after_precpd"], after.numpy(), rtol=tol, atol=tol * float(after.abs().max()))
+    assert (got["cloud_water_mixing_ratio_after_precpd"] >= 0).all() and (got["cloud_precpd_difference"] <= 0).all()
+    assert (got["humidity_precpd_difference"] >= 0).all()
