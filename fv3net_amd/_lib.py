@@ -72,6 +72,7 @@ class MlpDesc(ctypes.Structure):
         ("n_residual", c_int),
         ("res_source", POINTER(c_int)),
         ("res_output", POINTER(c_int)),
+        ("hidden_output", c_int),
     ]
 
 

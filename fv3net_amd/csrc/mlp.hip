@@ -127,6 +127,7 @@ struct MlpLaunch {
     int n_chunks1;      // layer-1 chunks of 16 k-pairs
     int n_hidden;
     int n_otiles;       // 32-feature output tiles (= output-type chunks per sample tile)
+    int n_hout_tiles;   // leading tiles of the output table that are the last hidden layer's activations themselves (0 or HT)
     int64_t sink;       // fast-I/O launches: device row of n_samples values that padded output rows are stored to
     int n_ktab;
     int n_otab;
@@ -177,7 +178,7 @@ __host__ __device__ constexpr int rho(int r) { return (r & 3) + 8 * (r >> 2); }
 // (32 features x 128 samples) are brought in by the whole workgroup with 16-byte loads, normalised
 // four at a time and parked in LDS; a k-pair slot then needs one ds_read for its B operand
 // instead of a table lookup, an address computation, a 4-byte load and the normalisation.
-template <int HT, bool SRC64, bool XBULK>
+template <int HT, bool SRC64, bool XBULK, bool HOUT>
 __global__ __launch_bounds__(kThreads, 1) void mlp_fused_kernel(const MlpLaunch p)
 {
     constexpr int HG = (HT + 3) / 4;          // float4 groups of hidden-feature tiles
@@ -681,6 +682,7 @@ __global__ __launch_bounds__(kThreads, 1) void mlp_fused_kernel(const MlpLaunch 
             typedef const d64x2 __attribute__((address_space(1))) *GCF64x2;
             const int64_t n0t = tile * kTileSamples + wave * 32;
             const int e_wrow = lane >> 3, e_wcol = (lane & 7) * 4;
+            constexpr int NHO = HOUT ? HT : 0;  // leading table tiles that are the hidden activations themselves
             // ---- fast-I/O epilogue pieces.  (n_samples is a multiple of 32: a wave's 32 samples are all
             // there or all beyond the end.)  An accumulator tile goes through the wave's 4 KB slice of
             // the xs half that is idle during the output layer, is read back row-wise and leaves as
@@ -881,7 +883,7 @@ __global__ __launch_bounds__(kThreads, 1) void mlp_fused_kernel(const MlpLaunch 
                     run_slot_out(y, s, [&](int s_) {
                         stage_step(s_, KC_O, gnext, par ^ 1);
                         if (EPI_SIDE) {
-                            if (decltype(has_prev_c)::value) epi_side(yo, t - 1, s_, plain_c);
+                            if (decltype(has_prev_c)::value) epi_side(yo, NHO + t - 1, s_, plain_c);
                             if (s_ == 12) load_bias(yo, t + 1);
                         }
                     });
@@ -892,6 +894,18 @@ __global__ __launch_bounds__(kThreads, 1) void mlp_fused_kernel(const MlpLaunch 
             };
             f32x16 yA, yB;
             const int NT = p.n_otiles;
+            // Hidden-output models (the cells of the RNN emulators): the first NHO tiles of the output table are
+            // the last hidden layer's activations themselves -- no weights, no MFMAs, the accumulators go
+            // through the same epilogue as an output tile (relu is already applied).
+            if constexpr (HOUT) {
+                const bool prefetch_next = !XBULK && NT == 0 && next_tile < p.n_tiles;
+                if (prefetch_next) issue_x(0, nn);
+#pragma unroll
+                for (int t = 0; t < HT; ++t) {
+                    if (XBULK) epi_fast_now(h[t], t); else epi_general(h[t], t);
+                }
+                if (prefetch_next) finish_x(0);
+            }
             auto tile_loop = [&](auto plain_c) __attribute__((always_inline)) {
                 if constexpr (EPI_SIDE) {
                     load_bias(yA, 0);
@@ -908,17 +922,19 @@ __global__ __launch_bounds__(kThreads, 1) void mlp_fused_kernel(const MlpLaunch 
                         // epilogue and finished after it)
                         const bool prefetch_next = (t + 1 == NT) && next_tile < p.n_tiles;
                         if (!XBULK && prefetch_next) issue_x(0, nn);
-                        if (XBULK) epi_fast_now(yA, t); else epi_general(yA, t);
+                        if (XBULK) epi_fast_now(yA, NHO + t); else epi_general(yA, NHO + t);
                         if (!XBULK && prefetch_next) finish_x(0);
                     }
                 }
             };
-            if (EPI_SIDE && !p.has_limits && !p.out64 && !p.n_residual && (tile + 1) * kTileSamples <= p.n_samples)
-                tile_loop(std::true_type{});
-            else tile_loop(std::false_type{});
+            if (!HOUT || NT > 0) {
+                if (EPI_SIDE && !p.has_limits && !p.out64 && !p.n_residual && (tile + 1) * kTileSamples <= p.n_samples)
+                    tile_loop(std::true_type{});
+                else tile_loop(std::false_type{});
+            }
             STAMP_END(2);
-            if (EPI_SIDE) {  // the last tile's epilogue (tile NT-1 sits in yA if NT is odd)
-                if (NT & 1) epi_fast_now(yA, NT - 1); else epi_fast_now(yB, NT - 1);
+            if (EPI_SIDE && (!HOUT || NT > 0)) {  // the last tile's epilogue (tile NT-1 sits in yA if NT is odd)
+                if (NT & 1) epi_fast_now(yA, NHO + NT - 1); else epi_fast_now(yB, NHO + NT - 1);
             }
             // the scratch half of xs is rewritten by the next tile's first layer-1 chunk
             if (XBULK) MLP_CHUNK_BARRIER();
@@ -946,7 +962,7 @@ struct fv3hip_mlp {
     int device = 0;
     int HT = 0;
     int n_sources = 0, n_inputs = 0, K = 0, width = 0, n_hidden = 0, n_outputs = 0, F = 0, n_residual = 0;
-    int n_chunks1 = 0, n_otiles = 0, n_ktab = 0, n_otab = 0, n_bias = 0;
+    int n_chunks1 = 0, n_otiles = 0, n_hout_tiles = 0, n_ktab = 0, n_otab = 0, n_bias = 0;
     int64_t flops = 0;
     int has_limits = 0;
     int n_log_chunks = 0, n_logfast_chunks = 0;
@@ -962,10 +978,10 @@ namespace {
 
 const int kHiddenTilings[] = {1, 2, 4, 8};  // compiled kernel variants: hidden width <= 32 * HT
 
-template <int HT, bool SRC64, bool XBULK>
+template <int HT, bool SRC64, bool XBULK, bool HOUT = false>
 int launch_one(const MlpLaunch &lp, int grid, size_t lds, hipStream_t st)
 {
-    auto kern = mlp_fused_kernel<HT, SRC64, XBULK>;
+    auto kern = mlp_fused_kernel<HT, SRC64, XBULK, HOUT>;
     FV3HIP_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(kern),
                                          hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
     hipLaunchKernelGGL(kern, dim3(grid), dim3(kThreads), lds, st, lp);
@@ -990,9 +1006,10 @@ extern "C" int fv3hip_mlp_create(const fv3hip_mlp_desc_t *d, fv3hip_mlp_t *out)
     *out = nullptr;
     FV3HIP_REQUIRE(d->n_sources >= 1 && d->n_sources <= kMaxSources, "n_sources must be in [1, %d], got %d", kMaxSources, d->n_sources);
     FV3HIP_REQUIRE(d->n_inputs >= 1, "n_inputs must be >= 1");
-    FV3HIP_REQUIRE(d->n_outputs >= 1, "n_outputs must be >= 1");
-    FV3HIP_REQUIRE(d->n_residual >= 0 && d->n_outputs + d->n_residual <= kMaxOutputs,
-                   "n_outputs + n_residual must be <= %d", kMaxOutputs);
+    const int hout = d->hidden_output ? 1 : 0;
+    FV3HIP_REQUIRE(d->n_outputs >= 1 || (d->n_outputs == 0 && hout), "n_outputs must be >= 1 (or 0 with hidden_output)");
+    FV3HIP_REQUIRE(d->n_residual >= 0 && d->n_outputs + d->n_residual + hout <= kMaxOutputs,
+                   "n_outputs + n_residual (+ the hidden output) must be <= %d", kMaxOutputs);
     FV3HIP_REQUIRE(d->width >= 1, "width must be >= 1");
     if (d->n_hidden < 1)
         return fail(FV3HIP_EUNSUPPORTED, "networks without a hidden layer (n_hidden=%d) are not implemented", d->n_hidden);
@@ -1044,7 +1061,8 @@ extern "C" int fv3hip_mlp_create(const fv3hip_mlp_desc_t *d, fv3hip_mlp_t *out)
     m->n_chunks1 = ((K + 1) / 2 + 15) / 16;
     m->n_otiles = nt_out;
     m->n_ktab = 2 * 16 * m->n_chunks1;
-    m->n_otab = 32 * nt_out;
+    m->n_hout_tiles = hout ? HT : 0;
+    m->n_otab = 32 * (m->n_hout_tiles + nt_out);
     m->n_bias = d->n_hidden * HT * 32 + nt_out * 32;
     m->flops = 2 * ((int64_t)K * width + (int64_t)(d->n_hidden - 1) * width * width + (int64_t)width * F);
 
@@ -1160,6 +1178,9 @@ extern "C" int fv3hip_mlp_create(const fv3hip_mlp_desc_t *d, fv3hip_mlp_t *out)
     // ---- output table ----
     std::vector<OEntry> otab(m->n_otab);
     for (auto &e : otab) e = OEntry{1.f, 0.f, -INFINITY, INFINITY, 1.f, -1, -1, 0};
+    // (hidden-output models: the table starts with the last hidden layer's features, stored to the output slot
+    // after the outputs and the residual outputs)
+    for (int q = 0; q < (hout ? width : 0); ++q) otab[q].out_feat = ((d->n_outputs + d->n_residual) << 20) | q;
     {
         int f = 0;
         for (int j = 0; j < d->n_outputs; ++j) {
@@ -1167,7 +1188,7 @@ extern "C" int fv3hip_mlp_create(const fv3hip_mlp_desc_t *d, fv3hip_mlp_t *out)
             for (int r = 0; r < d->n_residual; ++r)
                 if (d->res_output[r] == j) res = ((d->n_outputs + r) << 8) | d->res_source[r];
             for (int q = 0; q < d->out_nfeat[j]; ++q, ++f) {
-                OEntry &e = otab[f];
+                OEntry &e = otab[32 * m->n_hout_tiles + f];
                 e.scale = d->out_scale ? d->out_scale[f] : 1.f;
                 e.center = d->out_center ? d->out_center[f] : 0.f;
                 e.lo = d->out_min ? d->out_min[f] : -INFINITY;
@@ -1265,7 +1286,8 @@ extern "C" int fv3hip_mlp_predict(fv3hip_mlp_t m, const void *const *sources, co
         lp.src_ss[i] = src_sample_stride[i];
     }
     for (int i = m->n_sources; i < kMaxSources; ++i) lp.src[i] = sources[0];
-    for (int j = 0; j < m->n_outputs + m->n_residual; ++j) {
+    const int n_slots = m->n_outputs + m->n_residual + (m->n_hout_tiles ? 1 : 0);
+    for (int j = 0; j < n_slots; ++j) {
         FV3HIP_REQUIRE(outputs[j], "output %d is null", j);
         FV3HIP_REQUIRE(out_sample_stride[j] >= 0 && out_sample_stride[j] * (out_dtype == FV3HIP_F64 ? 8 : 4) < ((int64_t)1 << 32),
                        "sample stride of output %d must be in [0, 4 GiB)", j);
@@ -1281,6 +1303,7 @@ extern "C" int fv3hip_mlp_predict(fv3hip_mlp_t m, const void *const *sources, co
     lp.n_chunks1 = m->n_chunks1;
     lp.n_hidden = m->n_hidden;
     lp.n_otiles = m->n_otiles;
+    lp.n_hout_tiles = m->n_hout_tiles;
     lp.n_ktab = m->n_ktab;
     lp.n_otab = m->n_otab;
     lp.n_bias = m->n_bias;
@@ -1289,7 +1312,7 @@ extern "C" int fv3hip_mlp_predict(fv3hip_mlp_t m, const void *const *sources, co
     {
         const int oal = (out_dtype == FV3HIP_F64) ? 2 : 4, sal = src64 ? 2 : 4;  // elements per 16 bytes
         bool fast = (n_samples % 32 == 0);
-        for (int j = 0; j < m->n_outputs + m->n_residual && fast; ++j)
+        for (int j = 0; j < n_slots && fast; ++j)
             fast = out_sample_stride[j] == 1 && (reinterpret_cast<uintptr_t>(outputs[j]) % 16 == 0) &&
                    (out_feat_stride[j] % oal == 0);
         for (int i = 0; i < m->n_sources && fast; ++i)
@@ -1326,7 +1349,13 @@ extern "C" int fv3hip_mlp_predict(fv3hip_mlp_t m, const void *const *sources, co
         }
         lp.sink = reinterpret_cast<int64_t>(m->d_sink);
     }
+    // hidden-output models (recurrent cells) have their own instantiations, so that the plain ones keep their
+    // register allocation and schedule; they take float32 sources only (packed inputs and states)
+    if (m->n_hout_tiles && src64)
+        return fail(FV3HIP_EUNSUPPORTED, "hidden-output models take float32 sources only");
 #define VARIANT_(H)                                                                                \
+    if (m->HT == H && m->n_hout_tiles)                                                             \
+        return xbulk ? launch_one<H, false, true, true>(lp, grid, lds, st) : launch_one<H, false, false, true>(lp, grid, lds, st); \
     if (m->HT == H) {                                                                              \
         if (xbulk) return src64 ? launch_one<H, true, true>(lp, grid, lds, st) : launch_one<H, false, true>(lp, grid, lds, st); \
         return src64 ? launch_one<H, true, false>(lp, grid, lds, st) : launch_one<H, false, false>(lp, grid, lds, st);          \

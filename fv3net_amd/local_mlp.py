@@ -390,9 +390,9 @@ class LocalMlpModel(_PointModel):
 class RnnModel(_PointModel):
     """Device handle of an RNN emulator.  Every SimpleRNN step of every layer is one launch of the fused MLP
     kernel over all columns: hidden layer = the cell, ``relu([x_t, h_{t-1}] @ [kernel; recurrent_kernel] + bias)``,
-    output layer = the identity (the new state) -- for the last layer stacked with the output convolutions,
-    whose rows go straight into the level's slice of the output array.  79 levels x depth launches per call,
-    each with ``ncol`` samples; the states ping-pong between two buffers per layer."""
+    returned as the launch's hidden output (the new state); the last layer's launch also applies the output
+    convolutions, whose rows go straight into the level's slice of the output array.  79 levels x depth launches
+    per call, each with ``ncol`` samples; the states ping-pong between two buffers per layer."""
 
     def __init__(self, spec: RnnSpec, device="cuda"):
         super().__init__(spec, device)
@@ -401,14 +401,12 @@ class RnnModel(_PointModel):
         for n, layer in enumerate(spec.layers):
             fan, ch = int(layer.kernel.shape[0]), int(layer.kernel.shape[1])
             last = n == len(spec.layers) - 1
-            eye = np.eye(ch, dtype=np.float32)
-            outputs = [OutputSpec("h", ch)] + ([OutputSpec("y", c)] if last else [])
-            out_kernel = np.concatenate([eye, np.asarray(spec.out_kernel, np.float32)], axis=1) if last else eye
-            out_bias = np.concatenate([np.zeros(ch, np.float32), np.asarray(spec.out_bias, np.float32)]) if last else np.zeros(ch, np.float32)
             self._cells.append(MlpModel(MlpSpec(
                 inputs=[InputSpec("in", fan), InputSpec("rec", ch)],
                 hidden_kernels=[np.concatenate([layer.kernel, layer.recurrent_kernel], axis=0).astype(np.float32)],
-                hidden_biases=[np.asarray(layer.bias, np.float32)], outputs=outputs, out_kernel=out_kernel, out_bias=out_bias),
+                hidden_biases=[np.asarray(layer.bias, np.float32)], outputs=[OutputSpec("y", c)] if last else [],
+                out_kernel=np.asarray(spec.out_kernel, np.float32) if last else np.zeros((ch, 0), np.float32),
+                out_bias=np.asarray(spec.out_bias, np.float32) if last else np.zeros(0, np.float32), hidden_output="h"),
                 device=self.device))
         self.flops_per_point = sum(m.flops_per_sample for m in self._cells)
 

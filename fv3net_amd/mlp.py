@@ -62,6 +62,9 @@ class MlpSpec:
     out_bias: np.ndarray
     residuals: List[ResidualSpec] = dataclasses.field(default_factory=list)
     activation: str = "relu"
+    # name under which the last hidden layer's activations ([width] features) are returned as an output of
+    # their own (``outputs`` may then be empty): the cell of a recurrent layer is such a model
+    hidden_output: Optional[str] = None
 
     @property
     def sources(self) -> List[str]:
@@ -85,7 +88,7 @@ class MlpSpec:
 
     @property
     def output_names(self) -> List[str]:
-        return [o.name for o in self.outputs] + [r.name for r in self.residuals]
+        return [o.name for o in self.outputs] + [r.name for r in self.residuals] + ([self.hidden_output] if self.hidden_output else [])
 
     def source_nfeat(self) -> Dict[str, int]:
         """Minimum number of features each source array must have."""
@@ -130,6 +133,7 @@ class MlpSpec:
             ],
             "residuals": [dataclasses.asdict(r) for r in self.residuals],
             "n_hidden": len(self.hidden_kernels),
+            "hidden_output": self.hidden_output,
         }
         arrays: Dict[str, np.ndarray] = {}
         for n, i in enumerate(self.inputs):
@@ -177,6 +181,7 @@ class MlpSpec:
             out_bias=np.asarray(arrays["out_bias"]),
             residuals=[ResidualSpec(**r) for r in meta.get("residuals", [])],
             activation=meta.get("activation", "relu"),
+            hidden_output=meta.get("hidden_output"),
         )
 
 
@@ -242,7 +247,7 @@ class MlpModel:
                     np.full(o.nfeat, default, np.float32) if v is None
                     else np.broadcast_to(_f32(v), (o.nfeat,))
                 )
-            return np.concatenate(parts)
+            return np.concatenate(parts) if parts else np.zeros(0, np.float32)
 
         any_min = any(o.min is not None for o in spec.outputs)
         any_max = any(o.max is not None for o in spec.outputs)
@@ -283,6 +288,7 @@ class MlpModel:
                 [np.full(o.nfeat, np.inf if o.max is None else o.max, np.float32) for o in spec.outputs])))
         if any_mask:
             desc.out_mask = _fptr(arr_f(per_feature("mask", 1.0)))
+        desc.hidden_output = 1 if spec.hidden_output else 0
         desc.n_residual = len(spec.residuals)
         if spec.residuals:
             desc.res_source = _iptr(arr_i([sources.index(r.source) for r in spec.residuals]))
@@ -340,6 +346,8 @@ class MlpModel:
         nfeat = {o.name: o.nfeat for o in spec.outputs}
         for r in spec.residuals:
             nfeat[r.name] = nfeat[r.output]
+        if spec.hidden_output:
+            nfeat[spec.hidden_output] = spec.width
         out_list = []
         for name in spec.output_names:
             shape = (nfeat[name], n_samples) if layout == "feature_sample" else (n_samples, nfeat[name])

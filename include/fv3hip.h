@@ -292,6 +292,11 @@ typedef struct {
     int n_residual;
     const int *res_source;   /* [n_residual] */
     const int *res_output;   /* [n_residual] */
+    /* 1: the activations of the last hidden layer ([width] features) are an output of their own, stored
+     * to the array passed after the outputs and the residual outputs (n_outputs may then be 0).  The
+     * cell of a recurrent layer -- tf.keras.layers.SimpleRNN, relu([x_t, h_{t-1}] [W; U] + b)
+     * (external/fv3fit/fv3fit/emulation/layers/architecture.py:186-191) -- is such a model. */
+    int hidden_output;
 } fv3hip_mlp_desc_t;
 
 typedef struct fv3hip_mlp *fv3hip_mlp_t;
