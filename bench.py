@@ -516,8 +516,8 @@ def main():
                 "peak": PEAK_FP32_MFMA_TFLOPS,
                 "unit": "TFLOP/s",
                 "frac": achieved / PEAK_FP32_MFMA_TFLOPS,
-                "traffic": pmc_traffic("mlp_fused_kernel<8,false,true>"),
-                "kernel": "mlp_fused_kernel<8,false,true>",
+                "traffic": pmc_traffic("mlp_fused_kernel<8,false,true,false>"),
+                "kernel": "mlp_fused_kernel<8,false,true,false>",
                 "kernel_ms": kernel_ms,
             },
         }
