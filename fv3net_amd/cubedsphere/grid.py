@@ -60,12 +60,19 @@ def interp_tiles_to_edges(field: torch.Tensor, axis: str) -> torch.Tensor:
 
 
 def _validate_tile_coord(da: DataArray):
+    """All six tiles -- or, with ``torch.distributed`` initialised, exactly the tiles this rank owns
+    (``parallel.tiles_of_rank``): the cube is then sharded by tile and the halo rows are exchanged."""
+    from ..parallel import tiles_of_rank, world
+
     if "tile" not in da.dims:
         raise ValueError("The input Dataset must have a `tile` coordinate.")
-    if "tile" in da.coords and set(np.asarray(da.coords["tile"]).tolist()) != {0, 1, 2, 3, 4, 5}:
-        raise ValueError("`tile` coordinate must contain each of [0, 1, 2, 3, 4, 5]")
-    if da.sizes["tile"] != 6:
-        raise ValueError("`tile` coordinate must contain each of [0, 1, 2, 3, 4, 5]")
+    rank, size = world()
+    mine = list(range(6)) if size == 1 else tiles_of_rank(size, rank)
+    if "tile" in da.coords and sorted(np.asarray(da.coords["tile"]).tolist()) != mine:
+        raise ValueError(f"`tile` coordinate must contain each of {mine}")
+    if da.sizes["tile"] != len(mine):
+        raise ValueError(f"`tile` coordinate must contain each of {mine}")
+    return mine
 
 
 def interp_center_to_outer(da, axis: str, x_center: Hashable = COORD_X_CENTER, x_outer: Hashable = COORD_X_OUTER,
@@ -75,7 +82,7 @@ def interp_center_to_outer(da, axis: str, x_center: Hashable = COORD_X_CENTER, x
     if axis not in ("x", "y"):
         raise ValueError(f"axis must be 'x' or 'y', got {axis!r}")
     d = to_compat(da)
-    _validate_tile_coord(d)
+    mine = _validate_tile_coord(d)
     for dim in (x_center, y_center):
         if dim not in d.dims:
             raise ValueError(f"{dim!r} is not a dimension of the array")
@@ -84,14 +91,19 @@ def interp_center_to_outer(da, axis: str, x_center: Hashable = COORD_X_CENTER, x
     t = on_device(d.transpose(*order).data)
     if "tile" in d.coords:  # tiles in coordinate order
         perm = np.argsort(np.asarray(d.coords["tile"]))
-        if not np.array_equal(perm, np.arange(6)):
+        if not np.array_equal(perm, np.arange(len(mine))):
             t = t[torch.as_tensor(perm, device=t.device)]
-    res = interp_tiles_to_edges(t, axis)
+    if len(mine) == 6:
+        res = interp_tiles_to_edges(t, axis)
+    else:  # tile-sharded cube: the one exchange step of the path (parallel.exchange_edge_rows)
+        from ..parallel import interp_tiles_to_edges_sharded
+
+        res = interp_tiles_to_edges_sharded(t, axis)
     new_dim = x_outer if axis == "x" else y_outer
     old_dim = x_center if axis == "x" else y_center
     dims = tuple(new_dim if dim == old_dim else dim for dim in order)
     coords = {k: v for k, v in d.coords.items() if k != old_dim and k != "tile"}
-    coords["tile"] = np.arange(6)
+    coords["tile"] = np.asarray(mine)
     coords[new_dim] = np.arange(res.shape[-1 if axis == "x" else -2])
     out = DataArray(like_input(res, d.data), dims=dims, coords=coords, name=d.name, attrs=d.attrs)
     out = out.transpose(*[new_dim if dim == old_dim else dim for dim in d.dims])

@@ -108,8 +108,14 @@ def exchange_edge_rows(local_rows: torch.Tensor, n_tiles: int = 6) -> torch.Tens
         raise ValueError(f"rank {rank} owns {counts[rank]} tiles, got rows for {local_rows.shape[0]}")
     padded = torch.zeros((width,) + tuple(local_rows.shape[1:]), dtype=local_rows.dtype, device=local_rows.device)
     padded[: counts[rank]] = local_rows
-    bufs = [torch.empty_like(padded) for _ in range(size)]
-    dist.all_gather(bufs, padded.contiguous())
+    if padded.is_cuda and dist.get_backend() == "gloo":  # (CPU-backend rehearsals with device data: stage through the host)
+        host = padded.cpu()
+        bufs = [torch.empty_like(host) for _ in range(size)]
+        dist.all_gather(bufs, host)
+        bufs = [b.to(padded.device) for b in bufs]
+    else:
+        bufs = [torch.empty_like(padded) for _ in range(size)]
+        dist.all_gather(bufs, padded.contiguous())
     return torch.cat([b[:c] for b, c in zip(bufs, counts)], dim=0)
 
 

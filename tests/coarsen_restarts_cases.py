@@ -53,3 +53,24 @@ def plan(tag):
                 "pressure_edge_x": {"fv_core.res": ["u"]}, "pressure_edge_y": {"fv_core.res": ["v"]},
                 "extrapolate": "extrapolate" in tag}
     raise KeyError(tag)
+
+
+def medium_inputs(meta, n, nz, seed):
+    """The fixture schema's variables, dims and value ranges on C{n} tiles with ``nz`` levels (float64 restarts):
+    category -> variable -> (dims, array)."""
+    rng = np.random.default_rng(seed)
+    inp = {}
+    for category, variables in meta["inputs"].items():
+        inp[category] = {}
+        for name, info in variables.items():
+            lo, hi = meta["ranges"].get(name, meta["default_range"])
+            shape = []
+            for d, s0 in zip(info["dims"], info["shape"]):
+                if d in ("tile", "Time"):
+                    shape.append(s0)
+                elif d.startswith("zaxis"):
+                    shape.append(nz if category in ("fv_core.res", "fv_tracer.res") else s0)
+                else:  # horizontal: staggered dims are one longer than the centred ones in the fixture
+                    shape.append(n + (s0 - 4))
+            inp[category][name] = (info["dims"], rng.uniform(lo, hi, shape).astype(info["dtype"]))
+    return inp

@@ -355,22 +355,7 @@ def test_coarsen_restarts_pipelines_medium_size_against_oracle(method):
 
     meta, _ = cases.load()
     n, nz, f, toa = 24, 12, 4, 300.0
-    rng = np.random.default_rng({"sigma": 1, "pressure": 2, "blended": 3}[method])
-    sizes = {"xaxis_1": n, "yaxis_2": n, "zaxis_1": nz}
-    inp = {}
-    for category, variables in meta["inputs"].items():
-        inp[category] = {}
-        for name, info in variables.items():
-            lo, hi = meta["ranges"].get(name, meta["default_range"])
-            shape = []
-            for d, s0 in zip(info["dims"], info["shape"]):
-                if d in ("tile", "Time"):
-                    shape.append(s0)
-                elif d.startswith("zaxis"):
-                    shape.append(nz if category in ("fv_core.res", "fv_tracer.res") else s0)
-                else:  # horizontal: staggered dims are one longer than the centred ones in the fixture
-                    shape.append(n + (s0 - 4))
-            inp[category][name] = (info["dims"], rng.uniform(lo, hi, shape).astype(info["dtype"]))
+    inp = cases.medium_inputs(meta, n, nz, seed={"sigma": 1, "pressure": 2, "blended": 3}[method])
 
     def dataset(category):
         return Dataset({v: DataArray(a, dims=d, name=v) for v, (d, a) in inp[category].items()})
