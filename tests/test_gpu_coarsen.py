@@ -249,6 +249,44 @@ def test_full_size_c384_properties(device):
     assert torch.allclose(lhs, rhs, rtol=1e-5, atol=1.0)
 
 
+def test_full_size_c3072_properties(device):
+    """BASELINE configs[4] at full size: one [6, 79, 3072, 3072] float32 field (4.47 G elements, 17.9 GB -- element
+    offsets beyond 2^32) coarsened by 8 with 2-D area weights.  Size-independent properties: a constant field
+    averages to itself; sum(w * mean) over the coarse grid equals sum(w * field) over the fine grid, per tile;
+    and blocks sampled from all over the array -- the very last one included -- equal the float64 block
+    average of the same values to float32 rounding."""
+    from fv3net_amd import ops
+
+    if torch.cuda.get_device_properties(device).total_memory < 64e9:
+        pytest.skip("needs 64 GB of device memory")
+    g = torch.Generator(device=device).manual_seed(1)
+    n, nz, f = 3072, 79, 8
+    area = torch.rand((6, n, n), device=device, generator=g) * 0.5 + 0.5
+    obj = torch.empty((6, nz, n, n), device=device, dtype=torch.float32)
+    for t in range(6):  # (filled per tile: the generator's temporaries stay small)
+        obj[t] = torch.rand((nz, n, n), device=device, generator=g) * 2000 - 1000
+    out = ops.weighted_block_average(obj, area, f)
+    assert out.shape == (6, nz, n // f, n // f) and out.dtype == torch.float32
+    wsum = ops.block_reduce(area, (f, f), op="sum")
+    for t in range(6):
+        lhs = (out[t].double() * wsum[t].double()).sum()
+        rhs = sum((obj[t, k0:k0 + 8].double() * area[t].double()).sum() for k0 in range(0, nz, 8))
+        assert abs(float(lhs - rhs)) <= 1e-6 * float((obj[t].abs().double().sum() * 0.75)), t
+    rng = np.random.default_rng(2)
+    samples = [(5, nz - 1, n // f - 1, n // f - 1), (0, 0, 0, 0)] + [
+        (int(rng.integers(6)), int(rng.integers(nz)), int(rng.integers(n // f)), int(rng.integers(n // f))) for _ in range(200)]
+    for t, k, Y, X in samples:
+        blk = obj[t, k, Y * f:(Y + 1) * f, X * f:(X + 1) * f].double().cpu().numpy()
+        w = area[t, Y * f:(Y + 1) * f, X * f:(X + 1) * f].double().cpu().numpy()
+        want = (blk * w).sum() / w.sum()
+        assert abs(float(out[t, k, Y, X]) - want) <= 1e-5 * np.abs(blk).max(), (t, k, Y, X)
+    del obj
+    torch.cuda.empty_cache()
+    const = torch.full((6, nz, n, n), 3.25, device=device, dtype=torch.float32)
+    res = ops.weighted_block_average(const, area, f)
+    assert torch.allclose(res, torch.full_like(res, 3.25), rtol=1e-6, atol=0)
+
+
 @pytest.mark.parametrize("axis", ["x", "y"])
 @pytest.mark.parametrize("dt", [np.float32, np.float64])
 def test_cube_interp_center_to_outer_matches_oracle(device, axis, dt):
