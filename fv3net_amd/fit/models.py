@@ -2,7 +2,7 @@
 442-520; configs _shared/config.py:11-24, 116-142), registered under the reference's names so that
 model directories written for them load here.  Their array work -- vertical tapering, ensemble
 mean / median, output squashing -- runs on the device on the base models' predictions.
-``DerivedModel`` (models.py:110-220) is not included: it is a front end to ``vcm.DerivedMapping``."""
+``DerivedModel`` (models.py:110-220) lives in ``derived.py`` with the part of ``vcm.DerivedMapping`` it needs."""
 import dataclasses
 import os
 from typing import Hashable, Iterable, Mapping, Sequence, Set

@@ -151,6 +151,8 @@ int fv3hip_block_upsample(const void *in, int elem_size, int64_t n_outer, int ny
 #define FV3HIP_EW_BLEND 11     /* coarsen_restarts.blend: a * b + (1 - a) * c         */
 #define FV3HIP_EW_MUL_S 12     /* scalar * a                                          */
 #define FV3HIP_EW_WHERE_S 13   /* a.where(mask b, other=scalar)                       */
+#define FV3HIP_EW_ADD 14       /* a + b                                               */
+#define FV3HIP_EW_ADD_S 15     /* a + scalar                                          */
 int fv3hip_ew(int op, const void *a, const void *b, const void *c, double scalar, int dtype,
               int64_t n, int64_t inner, int64_t b_rep, int64_t c_rep, void *out, void *stream);
 
