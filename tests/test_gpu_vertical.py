@@ -301,6 +301,37 @@ def test_mappm_multi_level_col_layout_f64_and_errors(device):
         ops.mappm_multi(_dev(pe1, device), [_dev(qs[0], device), _dev(qs[1], device)], _dev(pe2, device), kord=9)
 
 
+@pytest.mark.parametrize("layout", ["col_level", "level_col"])
+def test_mappm_more_columns_than_one_launch_chunk(device, layout):
+    """The launcher cuts the columns into chunks of 2^20 (the work list and the fallback workspace are per
+    chunk): 1.3 M columns -- ill-formed ones on both sides of the cut -- single-field and multi-field, against
+    the oracle on the columns around the cut and a tiled copy property elsewhere."""
+    from fv3net_amd import ops
+
+    rng = np.random.default_rng(31)
+    base, km, kn = 4096, 12, 10
+    reps = 320                                # 1 310 720 columns
+    pe1, q, pe2 = _columns(rng, base, km, kn)
+    pe1[7, 3], pe1[7, 4] = pe1[7, 4], pe1[7, 3]   # an ill-formed column in every copy of the base block
+    pe2[100, 5] = np.nan
+    q2 = rng.uniform(-5, 5, (base, km)).astype(np.float32)
+    ref, ref2 = mappm_c.mappm(pe1, q, pe2), mappm_c.mappm(pe1, q2, pe2)
+
+    def tiled(a):
+        t = _dev(np.tile(a, (reps, 1)), device)
+        return t.t().contiguous() if layout == "level_col" else t   # [level, column]: z_axis 0
+
+    z_axis = 0 if layout == "level_col" else -1
+    P1, Q1, Q2, P2 = tiled(pe1), tiled(q), tiled(q2), tiled(pe2)
+    single = ops.mappm(P1, Q1, P2, z_axis=z_axis)
+    multi = ops.mappm_multi(P1, [Q1, Q2], P2, z_axis=z_axis)
+    for got, want in ((single, ref), (multi[0], ref), (multi[1], ref2)):
+        g = ops.as_numpy(got.t().contiguous() if layout == "level_col" else got).reshape(reps, base, kn)
+        for r in (0, 255, 256, reps - 1):      # 256 * 4096 = 2^20: the copies on either side of the chunk cut, and the ends
+            assert _bits_equal(g[r], want), r
+        assert _bits_equal(g, np.broadcast_to(want, g.shape).copy())
+
+
 @pytest.mark.parametrize("dt_np", [np.float32, np.float64])
 def test_humidity_limiters(device, dt_np):
     """vcm.non_negative_sphum(_mse_conserving) on the device (non_negative_sphum.py:6-45) against the
