@@ -155,7 +155,7 @@ def cpu_baseline(spec, budget_s=15.0):
     while True:
         mlp_np.forward(spec, src)
         reps += 1
-        if time.perf_counter() - t0 > budget_s or reps >= 50:
+        if time.perf_counter() - t0 > budget_s or reps >= 100:
             break
     dt = time.perf_counter() - t0
     return {
