@@ -212,3 +212,61 @@ def test_rnn_emulator_matches_oracle(nz, ncol, dtype, channels, tmp_path):
     out = loaded({k: v.T for k, v in st.items()})
     for name in spec.output_names:
         np.testing.assert_array_equal(out[name].T, got[name].cpu().numpy())
+
+
+def test_production_style_fv3config_both_hooks(tmp_path):
+    """projects/microphysics/configs/gscond-and-precpd.yaml:268-287 in miniature, through ``get_hooks``: the gscond
+    hook (dense-local regressor + classifier, conservation fixes, classifier masks, level masks filled from the
+    inputs) and then the microphysics hook (RNN precpd model) update the same Fortran state in place."""
+    from fv3net_amd.emulation.config import get_hooks
+    from fv3net_amd.emulation.models import HipLocalEmulator
+
+    rng = np.random.default_rng(13)
+    nz, ncol = 20, 256
+    st = cases.state(rng, nz, ncol)
+    reg_spec = cases.regressor(rng, st, nz, make=cases.product_makers())
+    reg_spec.outputs[0].after, reg_spec.outputs[1].after = E.QV_G, E.T_G
+    cls_spec = cases.classifier(rng, st, nz, make=cases.product_makers())
+    raw = mlp_np.forward_local(cls_spec, {k: v.T for k, v in st.items()}, dtype=np.float64)["gscond_classes"]
+    cls_spec.out_bias = (cls_spec.out_bias - raw.mean(axis=(0, 1))).astype(np.float32)
+    rnn_spec = cases.precpd_rnn(rng, st, nz, channels=32, make=cases.product_makers())
+    for name, spec in (("gscond", reg_spec), ("classifier", cls_spec), ("precpd", rnn_spec)):
+        HipLocalEmulator(spec).dump(str(tmp_path / name))
+    start = nz - 5
+    config = {"zhao_carr_emulation": {
+        "gscond": {"path": str(tmp_path / "gscond"), "classifier_path": str(tmp_path / "classifier"),
+                   "enforce_conservative": True, "gscond_cloud_conservative": True,
+                   "mask_gscond_zero_cloud_classifier": True, "mask_gscond_no_tend_classifier": True,
+                   "mask_emulator_levels": {
+                       E.CLOUD_G: {"start": start, "fill_value": cases.CLOUD_IN},
+                       E.QV_G: {"start": start, "fill_value": cases.QV_IN},
+                       E.T_G: {"start": start, "fill_value": cases.T_IN}}},
+        "model": {"path": str(tmp_path / "precpd")}}}
+    (tmp_path / "fv3config.yml").write_text(yaml.safe_dump(config))
+    gscond, microphysics, store = get_hooks(str(tmp_path / "fv3config.yml"))
+
+    state = {k: v.copy() for k, v in st.items()}
+    state[E.CLOUD_G] = st[cases.CLOUD_IN] * 1.1
+    state["model_time"], state["rank"] = [2016, 8, 1, 0, 0, 0], 0
+    assert gscond(state) is None
+    # masked levels hold the inputs exactly (masks.py:46-76), the rest went through the conservation fix
+    for out_name, in_name in ((E.CLOUD_G, cases.CLOUD_IN), (E.QV_G, cases.QV_IN), (E.T_G, cases.T_IN)):
+        assert state[out_name].shape == (nz, ncol)
+        np.testing.assert_array_equal(state[out_name][start:], st[in_name][start:])
+        assert not np.array_equal(state[out_name][:start], st[in_name][:start])
+    # water is conserved where the fix applied: cloud + vapour unchanged
+    total_before = st[cases.CLOUD_IN] + st[cases.QV_IN]
+    np.testing.assert_allclose(state[E.CLOUD_G] + state[E.QV_G], total_before, rtol=1e-12, atol=1e-18)
+    assert (state[E.CLOUD_G] >= 0).all() and (state[E.QV_G] >= 0).all()
+    assert state["gscond_classes"].shape == (4, nz, ncol)
+
+    after_gscond = {k: (v.copy() if isinstance(v, np.ndarray) else v) for k, v in state.items()}
+    assert microphysics(state) is None
+    truth = mlp_np.forward_rnn(rnn_spec, {k: v.T for k, v in st.items()}, dtype=np.float64)
+    for name in rnn_spec.output_names:
+        _check(state[name], truth[name].T, name, tol=2e-5)
+    assert state["total_precipitation"].shape == (1, ncol)
+    for k, v in after_gscond.items():  # the second hook adds its outputs and leaves the rest alone
+        if isinstance(v, np.ndarray):
+            np.testing.assert_array_equal(state[k], v)
+    assert store(state) is None
