@@ -410,3 +410,37 @@ def test_interpolate_1d_reference_known_answer(device):
     res = mappm.interpolate_2d(np.arange(12).reshape(1, 12), xs, xs ** 2, fill_value=np.nan)  # test_interpolate.py:120-133
     np.testing.assert_array_equal(res[:, :10], xs ** 2)
     assert np.isnan(res[:, -2:]).all() and res.dtype == np.float64
+
+
+def test_interpolate_1d_constant_levels_and_pressure_levels_known_answers(device):
+    """The 1-D-levels branch (metpy in the reference): external/vcm/tests/test_interpolate.py:60-96 and :135-147."""
+    from fv3net_amd.interpolate import PRESSURE_GRID, interpolate_1d, interpolate_to_pressure_levels
+    from fv3net_amd.xr_compat import DataArray, Dataset
+
+    var = DataArray(np.array([[1.0, 2.0, 3.0], [-1.0, -2.0, -3.0]]), dims=["x", "pfull"])
+    pressure = DataArray(np.array([[0.0, 1, 2], [0, 2, 4]]), dims=["x", "pfull"])
+    out_p = DataArray(np.array([0.5, 2]), dims=["pressure_uniform"])
+    got = interpolate_1d(out_p, pressure, var, "pfull")
+    assert got.dims == ("x", "pressure_uniform")
+    np.testing.assert_allclose(got.values, [[1.5, 3.0], [-1.25, -2.0]])
+    np.testing.assert_array_equal(got.coords["pressure_uniform"], [0.5, 2])
+    ds = interpolate_1d(out_p, pressure, Dataset({"interp_var": var, "pressure": pressure}), dim="pfull")
+    np.testing.assert_allclose(ds["interp_var"].values, got.values)
+    with pytest.raises(ValueError, match="dim argument"):
+        interpolate_1d(out_p, pressure, var)
+    # model top at 300 Pa, two 100 Pa layers: 350 Pa lies between the two midpoints -> no NaN
+    out = interpolate_to_pressure_levels(DataArray(np.array([2.0, 1.0]), dims=["z"]), DataArray(np.array([100.0, 100.0]), dims=["z"]),
+                                         levels=DataArray(np.array([350.0]), dims=["pressure"]), dim="z")
+    assert out.dims == ("pressure",) and not np.isnan(out.values).any() and 1.0 < float(out.values[0]) < 2.0
+    # the default grid on a [z, y, x] field: level axis in place, NaN below the surface and above the top layer's midpoint
+    rng = np.random.default_rng(0)
+    delp = DataArray(rng.uniform(800, 1400, (79, 6, 5)), dims=["pfull", "y", "x"])
+    t = DataArray(rng.uniform(200, 300, (79, 6, 5)), dims=["pfull", "y", "x"])
+    out = interpolate_to_pressure_levels(t, delp)
+    assert out.dims == ("pressure", "y", "x") and out.shape == (35, 6, 5)
+    mid = onp.pressure_at_midpoint_log(delp.values, 300.0, 0)
+    want = np.full((35, 6, 5), np.nan)
+    for j in range(6):
+        for i in range(5):
+            want[:, j, i] = np.interp(PRESSURE_GRID.values, mid[:, j, i], t.values[:, j, i], left=np.nan, right=np.nan)
+    np.testing.assert_allclose(out.values, want, rtol=1e-12, equal_nan=True)
