@@ -287,6 +287,47 @@ def test_full_size_c3072_properties(device):
     assert torch.allclose(res, torch.full_like(res, 3.25), rtol=1e-6, atol=0)
 
 
+def test_full_size_c3072_column_and_upsample_kernels(device):
+    """The other kernels of the pressure-level path on a 4.47 G-element field (offsets beyond 2^32): interface
+    pressures (cumulative sums down 79 levels), their consistency with the column-sum kernel, the coarse-to-fine
+    upsample and the weight mask, each checked on columns sampled from all over the array, the last one included."""
+    from fv3net_amd import ops
+
+    if torch.cuda.get_device_properties(device).total_memory < 128e9:
+        pytest.skip("needs 128 GB of device memory")
+    g = torch.Generator(device=device).manual_seed(3)
+    n, nz, f = 3072, 79, 8
+    delp = torch.empty((6, nz, n, n), device=device, dtype=torch.float32)
+    for t in range(6):
+        delp[t] = torch.rand((nz, n, n), device=device, generator=g) * 1200 + 300
+    phalf = ops.pressure_at_interface(delp, 300.0, 1)
+    assert phalf.shape == (6, nz + 1, n, n)
+    ps = ops.column_sum(delp, 1, addend=300.0)
+    rng = np.random.default_rng(4)
+    cols = [(5, n - 1, n - 1), (0, 0, 0)] + [(int(rng.integers(6)), int(rng.integers(n)), int(rng.integers(n))) for _ in range(100)]
+    for t, y, x in cols:
+        d = delp[t, :, y, x].cpu().numpy()
+        want = np.cumsum(np.concatenate([[np.float32(300.0)], d]), dtype=np.float32)  # p[0] = toa; p[k+1] = p[k] + delp[k]
+        np.testing.assert_array_equal(phalf[t, :, y, x].cpu().numpy(), want)           # the same additions in the same order
+        np.testing.assert_allclose(float(ps[t, y, x]), float(want[-1]), rtol=1e-6)     # (sum first, then + toa)
+    # weight mask against the interface pressures of a second, coarser-looking grid
+    area = torch.rand((6, n, n), device=device, generator=g) * 0.5 + 0.5
+    coarse = ops.block_upsample(ops.weighted_block_average(delp, area, f), f)
+    assert coarse.shape == delp.shape
+    for t, y, x in cols[:20]:
+        blk = coarse[t, :, (y // f) * f:(y // f + 1) * f, (x // f) * f:(x // f + 1) * f]
+        assert bool((blk == blk[:, :1, :1]).all())  # every fine cell of a block holds the block's value
+    del delp
+    torch.cuda.empty_cache()
+    phalf_c = ops.pressure_at_interface(coarse, 300.0, 1)
+    del coarse
+    masked = ops.mask_weights(area, phalf_c, phalf, z_axis=1)
+    assert masked.shape == (6, nz, n, n)
+    for t, y, x in cols:
+        pc, pf, a = phalf_c[t, :, y, x].cpu().numpy(), phalf[t, :, y, x].cpu().numpy(), float(area[t, y, x])
+        np.testing.assert_array_equal(masked[t, :, y, x].cpu().numpy(), np.where(pc[1:] < pf[-1], np.float32(a), np.float32(0)))
+
+
 @pytest.mark.parametrize("axis", ["x", "y"])
 @pytest.mark.parametrize("dt", [np.float32, np.float64])
 def test_cube_interp_center_to_outer_matches_oracle(device, axis, dt):
