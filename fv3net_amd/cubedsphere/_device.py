@@ -1,5 +1,5 @@
 """Host <-> device plumbing for the labelled-array entry points (torch is memory only)."""
-from typing import Hashable, List, Sequence
+from typing import Hashable, List
 
 import numpy as np
 import torch

@@ -4,7 +4,7 @@
 Same function names, argument meaning and error behaviour as the reference; objects are
 ``fv3net_amd.xr_compat`` DataArrays / Datasets, or real xarray objects when xarray is installed.
 """
-from typing import Any, Callable, Dict, Hashable, List, Mapping, Optional, Union
+from typing import Callable, Dict, Hashable, List, Mapping, Optional, Union
 
 import numpy as np
 

@@ -11,7 +11,6 @@ these functions (tests/test_gpu_api.py).
 from typing import Hashable, Mapping
 
 from .. import ops
-from ..thermo import pressure_at_midpoint_log
 from ..xr_compat import DataArray, Dataset, from_compat, merge, to_compat
 from ._device import like_input, on_device
 from .coarsen import block_coarsen, block_edge_coarsen, edge_weighted_block_average, weighted_block_average
@@ -32,7 +31,8 @@ from .constants import (
     SFC_DATA_X_CENTER,
     SFC_DATA_Y_CENTER,
 )
-from .regridz import compute_edge_delp, regrid_to_area_weighted_pressure, regrid_to_edge_weighted_pressure
+from .regridz import (compute_edge_delp, pressure_at_midpoint_log, regrid_to_area_weighted_pressure,
+                      regrid_to_edge_weighted_pressure)  # (pressure_at_midpoint_log: thermo imports this package's device helpers)
 from .sfc_data import _coarse_grain_sfc_data_complex
 
 CATEGORY_LIST = ["fv_core.res", "fv_srf_wnd.res", "fv_tracer.res", "sfc_data"]

@@ -5,8 +5,6 @@ The reference moves the vertical dim last, flattens to [column, level], lets f2p
 Fortran order and calls ``mappm`` per chunk.  Here the arrays stay in whatever layout they have
 (the native [tile, z, y, x] included) and the remap kernel walks the level axis in place.
 """
-from typing import Hashable, Union
-
 import numpy as np
 
 from .. import ops
@@ -101,8 +99,6 @@ def _mask_weights(weights, pfull_coarse_on_fine, phalf_coarse_on_fine, phalf_fin
     w_order = [d for d in order if d != dim_outer]
     if set(w.dims) != set(w_order):
         # broadcast the weights over the missing non-vertical dims (e.g. area [tile, y, x] vs time)
-        import numpy as np  # noqa: F401  (host-side metadata only)
-
         missing = [d for d in w_order if d not in w.dims]
         data = on_device(w.data)
         for _ in missing:

@@ -10,9 +10,8 @@ mean restricted to the cells of the dominant surface / vegetation / soil type, w
 block upsample, NaN-skipping weighted block average / block sum, and the elementwise mask vocabulary
 ``fv3hip_ew``; fields of a call stay on the device until the end.
 """
-from typing import Dict, Hashable, Mapping
+from typing import Dict, Mapping
 
-import numpy as np
 import torch
 
 from .. import ops

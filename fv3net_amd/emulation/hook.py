@@ -1,7 +1,7 @@
 """``MicrophysicsHook``: applies the emulator to the Fortran state in place
 (external/emulation/emulation/_emulate/microphysics.py:19-100)."""
 import gc
-from typing import Callable, Mapping, MutableMapping
+from typing import Callable, MutableMapping
 
 import numpy as np
 

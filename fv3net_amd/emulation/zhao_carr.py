@@ -5,7 +5,6 @@ dictionaries of [feature(z), sample] arrays).  Each function is one HIP launch
 tensors stay on the device.  Arithmetic follows numpy's promotion: float64 as soon as one operand
 (the Fortran state) is float64.
 """
-from typing import Mapping
 
 import numpy as np
 import torch

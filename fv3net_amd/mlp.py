@@ -7,13 +7,13 @@ once (``fv3hip_mlp_create``) and runs ``fv3hip_mlp_predict`` on device arrays.
 """
 import ctypes
 import dataclasses
-from typing import Dict, List, Mapping, Optional, Sequence, Tuple
+from typing import Dict, List, Mapping, Optional, Tuple
 
 import numpy as np
 import torch
 
 from . import _lib
-from .ops import _ptr, _require_device, _stream
+from .ops import _require_device, _stream
 
 
 @dataclasses.dataclass

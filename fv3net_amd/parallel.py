@@ -11,7 +11,7 @@ Besides that this module provides the partition (cube tiles / row bands / column
 ranks) and the optional gather of results to one consumer, on ``torch.distributed`` (backend
 ``nccl`` = RCCL over xGMI on the GPU box, ``gloo`` in CPU tests).
 """
-from typing import Dict, List, Sequence, Tuple
+from typing import Dict, List, Tuple
 
 import torch
 import torch.distributed as dist

@@ -4,7 +4,6 @@ and the humidity limiters applied to the ML tendencies every timestep
 (external/vcm/vcm/calc/thermo/non_negative_sphum.py:6-45)."""
 from typing import Hashable, Optional, Tuple
 
-import numpy as np
 import torch
 
 from . import _lib, ops

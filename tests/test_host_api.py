@@ -195,3 +195,16 @@ def test_partitioning():
     assert sum(hi - lo for _, lo, hi in flat) == 6 * 3072
     assert [len(u) for u in parallel.tile_bands(6, 384, 8, 6)] == [1] * 6
     assert parallel.world() == (0, 1)
+
+
+def test_every_module_imports_on_its_own():
+    """No import-order dependence between the subpackages (thermo <-> cubedsphere share device helpers)."""
+    import subprocess
+    import sys
+
+    mods = ["fv3net_amd.thermo", "fv3net_amd.cubedsphere", "fv3net_amd.cubedsphere.coarsen_restarts", "fv3net_amd.emulation",
+            "fv3net_amd.fit", "fv3net_amd.fit.streaming", "fv3net_amd.fit.derived", "fv3net_amd.parallel", "fv3net_amd.interpolate",
+            "fv3net_amd.mappm", "fv3net_amd.local_mlp", "fv3net_amd.mlp", "fv3net_amd.ops"]
+    code = "import importlib, sys\nfor m in sys.argv[1:]:\n    for k in [k for k in sys.modules if k.startswith('fv3net_amd')]:\n        del sys.modules[k]\n    importlib.import_module(m)\n"
+    res = subprocess.run([sys.executable, "-c", code, *mods], capture_output=True, text=True, cwd=os.path.dirname(os.path.dirname(__file__)))
+    assert res.returncode == 0, res.stderr[-2000:]
