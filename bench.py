@@ -441,9 +441,17 @@ def main():
     rank = int(os.environ.get("RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    # Rehearsal on a one-GPU box: FV3_BENCH_REHEARSAL=1 puts every rank on cuda:0 and rendezvouses over gloo
+    # (two ranks cannot share a device under RCCL).  Real runs: one rank per GPU, backend nccl = RCCL over xGMI.
+    rehearsal = os.environ.get("FV3_BENCH_REHEARSAL") == "1"
+    if rehearsal:
+        local_rank = 0
     if world > 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device(f"cuda:{local_rank}"))
+        if rehearsal:
+            dist.init_process_group("gloo", rank=rank, world_size=world)
+        else:
+            dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device(f"cuda:{local_rank}"))
     assert world == max(args.gpus, 1) or world == 1, f"--gpus {args.gpus} but WORLD_SIZE={world}"
     dev = torch.device(f"cuda:{local_rank}")
     torch.cuda.set_device(dev)
