@@ -98,18 +98,42 @@ def _coarse_grain_fv_srf_wnd(ds, area, coarsening_factor):
 # ------------------------------------------------------------------------------------------------
 # pressure-level coarse-graining
 # ------------------------------------------------------------------------------------------------
-def _coarse_grain_fv_core_on_pressure(ds, delp, area, dx, dy, toa_pressure, coarsening_factor, coarsen_agrid_winds=False,
-                                      extrapolate=False):
-    """coarsen_restarts.py:430-556: delp, DZ, phis on model surfaces, the rest on surfaces of constant pressure."""
-    area_weighted_vars = ["phis", "delp", "DZ"]
+def _masked_core_vars(ds, coarsen_agrid_winds):
     masked_area_weighted_vars = ["W", "T"]
     if coarsen_agrid_winds:
         if not ("ua" in ds and "va" in ds):
             raise ValueError("If 'coarsen_agrid_winds' is active, 'ua' and 'va' must be present in the 'fv_core.res' restart files.")
         masked_area_weighted_vars.extend(["ua", "va"])
-    area_regridded, masked_area = regrid_to_area_weighted_pressure(
-        ds[masked_area_weighted_vars], delp, area, toa_pressure, coarsening_factor, x_dim=FV_CORE_X_CENTER,
-        y_dim=FV_CORE_Y_CENTER, extrapolate=extrapolate)
+    return masked_area_weighted_vars
+
+
+def _area_weighted_pressure_means(core, tracer, delp, area, toa_pressure, coarsening_factor, coarsen_agrid_winds, extrapolate):
+    """The cell-centred fields of fv_core (W, T, ua, va) and all tracers are remapped between the same two pressure
+    grids with the same masked area weights (coarsen_restarts.py:483-495 and :940-961 compute them twice): here
+    once -- one pressure context and one multi-field remap for the 11-13 fields -- with identical results per field.
+    Returns (coarse fv_core fields, coarse tracers)."""
+    names_core = _masked_core_vars(core, coarsen_agrid_winds)
+    names_tracer = FRACTION_TRACERS + NON_FRACTION_TRACERS
+    t = to_compat(tracer)[names_tracer].rename({FV_TRACER_Y_CENTER: FV_CORE_Y_CENTER})
+    both = merge([to_compat(core)[names_core], t])
+    regridded, masked_area = regrid_to_area_weighted_pressure(
+        both, delp, area, toa_pressure, coarsening_factor, x_dim=FV_CORE_X_CENTER, y_dim=FV_CORE_Y_CENTER, extrapolate=extrapolate)
+    means = to_compat(weighted_block_average(regridded, masked_area, coarsening_factor, x_dim=FV_CORE_X_CENTER, y_dim=FV_CORE_Y_CENTER))
+    return means[names_core], means[names_tracer].rename({FV_CORE_Y_CENTER: FV_TRACER_Y_CENTER})
+
+
+def _coarse_grain_fv_core_on_pressure(ds, delp, area, dx, dy, toa_pressure, coarsening_factor, coarsen_agrid_winds=False,
+                                      extrapolate=False, area_means=None):
+    """coarsen_restarts.py:430-556: delp, DZ, phis on model surfaces, the rest on surfaces of constant pressure.
+    ``area_means``: the coarse W, T, (ua, va) when the caller has them already (``_area_weighted_pressure_means``)."""
+    area_weighted_vars = ["phis", "delp", "DZ"]
+    masked_area_weighted_vars = _masked_core_vars(ds, coarsen_agrid_winds)
+    if area_means is None:
+        area_regridded, masked_area = regrid_to_area_weighted_pressure(
+            ds[masked_area_weighted_vars], delp, area, toa_pressure, coarsening_factor, x_dim=FV_CORE_X_CENTER,
+            y_dim=FV_CORE_Y_CENTER, extrapolate=extrapolate)
+        area_means = weighted_block_average(area_regridded, masked_area, coarsening_factor, x_dim=FV_CORE_X_CENTER,
+                                            y_dim=FV_CORE_Y_CENTER)
     dx_regridded, masked_dx = regrid_to_edge_weighted_pressure(
         ds[["u"]], delp, dx, toa_pressure, coarsening_factor, x_dim=FV_CORE_X_CENTER, y_dim=FV_CORE_Y_OUTER, edge="x",
         extrapolate=extrapolate)
@@ -118,7 +142,7 @@ def _coarse_grain_fv_core_on_pressure(ds, delp, area, dx, dy, toa_pressure, coar
         extrapolate=extrapolate)
     return merge([
         weighted_block_average(ds[area_weighted_vars], area, coarsening_factor, x_dim=FV_CORE_X_CENTER, y_dim=FV_CORE_Y_CENTER),
-        weighted_block_average(area_regridded, masked_area, coarsening_factor, x_dim=FV_CORE_X_CENTER, y_dim=FV_CORE_Y_CENTER),
+        area_means,
         edge_weighted_block_average(dx_regridded, masked_dx, coarsening_factor, x_dim=FV_CORE_X_CENTER, y_dim=FV_CORE_Y_OUTER, edge="x"),
         edge_weighted_block_average(dy_regridded, masked_dy, coarsening_factor, x_dim=FV_CORE_X_OUTER, y_dim=FV_CORE_Y_CENTER, edge="y"),
     ])
@@ -230,10 +254,10 @@ def _names(ds, with_z: bool):
 
 
 def _coarse_grain_fv_core_via_blended_method(ds, delp, area, dx, dy, toa_pressure, coarsening_factor, coarsen_agrid_winds=False,
-                                             mass_weighted=True):
+                                             mass_weighted=True, area_means=None):
     """coarsen_restarts.py:679-778."""
     pressure_level = to_compat(_coarse_grain_fv_core_on_pressure(ds, delp, area, dx, dy, toa_pressure, coarsening_factor,
-                                                                  coarsen_agrid_winds))
+                                                                  coarsen_agrid_winds, area_means=area_means))
     model_level = to_compat(_coarse_grain_fv_core(ds, delp, area, dx, dy, coarsening_factor, coarsen_agrid_winds, mass_weighted))
     weights_agrid = _compute_blending_weights_agrid(delp, area, toa_pressure, coarsening_factor, x_dim=FV_CORE_X_CENTER,
                                                     y_dim=FV_CORE_Y_CENTER)
@@ -253,9 +277,11 @@ def _coarse_grain_fv_core_via_blended_method(ds, delp, area, dx, dy, toa_pressur
     ])
 
 
-def _coarse_grain_fv_tracer_via_blended_method(ds, delp, area, toa_pressure, coarsening_factor, mass_weighted=True):
-    """coarsen_restarts.py:781-822."""
-    pressure_level = _coarse_grain_fv_tracer_on_pressure(ds, delp, area, toa_pressure, coarsening_factor)
+def _coarse_grain_fv_tracer_via_blended_method(ds, delp, area, toa_pressure, coarsening_factor, mass_weighted=True,
+                                               pressure_level=None):
+    """coarsen_restarts.py:781-822.  ``pressure_level``: the pressure-level result when the caller has it already."""
+    if pressure_level is None:
+        pressure_level = _coarse_grain_fv_tracer_on_pressure(ds, delp, area, toa_pressure, coarsening_factor)
     model_level = _coarse_grain_fv_tracer(ds, delp, area, coarsening_factor, mass_weighted)
     weights = _compute_blending_weights_agrid(delp, area, toa_pressure, coarsening_factor, x_dim=FV_TRACER_X_CENTER,
                                               y_dim=FV_TRACER_Y_CENTER)
@@ -314,13 +340,13 @@ def coarsen_restarts_on_pressure(coarsening_factor: int, grid_spec, toa_pressure
     balance (coarsen_restarts.py:98-237)."""
     core = to_compat(restarts["fv_core.res"])
     coarsened = _common(coarsening_factor, grid_spec, restarts)
+    area = _grid(grid_spec, "area", FV_CORE_X_CENTER, FV_CORE_Y_CENTER)
+    core_means, coarsened["fv_tracer.res"] = _area_weighted_pressure_means(
+        core, restarts["fv_tracer.res"], core["delp"], area, toa_pressure, coarsening_factor, coarsen_agrid_winds, extrapolate)
     coarsened["fv_core.res"] = _coarse_grain_fv_core_on_pressure(
-        core, core["delp"], _grid(grid_spec, "area", FV_CORE_X_CENTER, FV_CORE_Y_CENTER),
-        _grid(grid_spec, "dx", FV_CORE_X_CENTER, FV_CORE_Y_OUTER), _grid(grid_spec, "dy", FV_CORE_X_OUTER, FV_CORE_Y_CENTER),
-        toa_pressure, coarsening_factor, coarsen_agrid_winds, extrapolate=extrapolate)
-    coarsened["fv_tracer.res"] = _coarse_grain_fv_tracer_on_pressure(
-        restarts["fv_tracer.res"], core["delp"].rename({FV_CORE_Y_CENTER: FV_TRACER_Y_CENTER}),
-        _grid(grid_spec, "area", FV_TRACER_X_CENTER, FV_TRACER_Y_CENTER), toa_pressure, coarsening_factor, extrapolate=extrapolate)
+        core, core["delp"], area, _grid(grid_spec, "dx", FV_CORE_X_CENTER, FV_CORE_Y_OUTER),
+        _grid(grid_spec, "dy", FV_CORE_X_OUTER, FV_CORE_Y_CENTER), toa_pressure, coarsening_factor, coarsen_agrid_winds,
+        extrapolate=extrapolate, area_means=core_means)
     coarsened["fv_core.res"] = _impose_hydrostatic_balance(coarsened["fv_core.res"], coarsened["fv_tracer.res"], toa_pressure)
     return _finish(coarsened, restarts)
 
@@ -330,12 +356,16 @@ def coarsen_restarts_via_blended_method(coarsening_factor: int, grid_spec, toa_p
     """Blended pressure-level / model-level coarse-graining of the 3-D fields (coarsen_restarts.py:240-332)."""
     core = to_compat(restarts["fv_core.res"])
     coarsened = _common(coarsening_factor, grid_spec, restarts)
+    area = _grid(grid_spec, "area", FV_CORE_X_CENTER, FV_CORE_Y_CENTER)
+    core_means, tracer_means = _area_weighted_pressure_means(
+        core, restarts["fv_tracer.res"], core["delp"], area, toa_pressure, coarsening_factor, coarsen_agrid_winds, False)
     coarsened["fv_core.res"] = _coarse_grain_fv_core_via_blended_method(
-        core, core["delp"], _grid(grid_spec, "area", FV_CORE_X_CENTER, FV_CORE_Y_CENTER),
-        _grid(grid_spec, "dx", FV_CORE_X_CENTER, FV_CORE_Y_OUTER), _grid(grid_spec, "dy", FV_CORE_X_OUTER, FV_CORE_Y_CENTER),
-        toa_pressure, coarsening_factor, coarsen_agrid_winds, mass_weighted)
+        core, core["delp"], area, _grid(grid_spec, "dx", FV_CORE_X_CENTER, FV_CORE_Y_OUTER),
+        _grid(grid_spec, "dy", FV_CORE_X_OUTER, FV_CORE_Y_CENTER), toa_pressure, coarsening_factor, coarsen_agrid_winds,
+        mass_weighted, area_means=core_means)
     coarsened["fv_tracer.res"] = _coarse_grain_fv_tracer_via_blended_method(
         restarts["fv_tracer.res"], core["delp"].rename({FV_CORE_Y_CENTER: FV_TRACER_Y_CENTER}),
-        _grid(grid_spec, "area", FV_TRACER_X_CENTER, FV_TRACER_Y_CENTER), toa_pressure, coarsening_factor, mass_weighted)
+        _grid(grid_spec, "area", FV_TRACER_X_CENTER, FV_TRACER_Y_CENTER), toa_pressure, coarsening_factor, mass_weighted,
+        pressure_level=tracer_means)
     coarsened["fv_core.res"] = _impose_hydrostatic_balance(coarsened["fv_core.res"], coarsened["fv_tracer.res"], toa_pressure)
     return _finish(coarsened, restarts)
