@@ -319,13 +319,16 @@ class _PointModel:
 
     def _pack(self, arrs, nz: int, ncol: int, dev) -> torch.Tensor:
         x = torch.empty((len(self.spec.inputs), nz * ncol), dtype=torch.float32, device=dev)
+        self._pack_into(arrs, nz, ncol, dev, x)
+        return x
+
+    def _pack_into(self, arrs, nz: int, ncol: int, dev, x: torch.Tensor) -> None:
         for n, i in enumerate(self.spec.inputs):
             t = arrs[i.source]
             _lib.call("fv3hip_local_pack", _ptr(t), _dt(t), int(t.shape[0] != 1),
                       _lib.TRANSFORM_LOG if i.transform == "log" else _lib.TRANSFORM_NONE, float(i.eps),
                       _ptr(self._table(f"in{n}_center", i.center, nz, 0.0)), _ptr(self._table(f"in{n}_scale", i.scale, nz, 1.0)),
                       nz, ncol, _ptr(x[n]), _stream(dev))
-        return x
 
     def _unpack_one(self, n: int, o: LocalOutput, rows: torch.Tensor, level_stride: int, arrs, nz: int, ncol: int, dev,
                     out: Dict[str, torch.Tensor]) -> None:
@@ -394,8 +397,14 @@ class RnnModel(_PointModel):
     convolutions, whose rows go straight into the level's slice of the output array.  79 levels x depth launches
     per call, each with ``ncol`` samples; the states ping-pong between two buffers per layer."""
 
-    def __init__(self, spec: RnnSpec, device="cuda"):
+    def __init__(self, spec: RnnSpec, device="cuda", use_graph: bool = False):
         super().__init__(spec, device)
+        # ``use_graph``: capture the level sweep (nz x depth launches) once per (nz, ncol) into a HIP graph on static
+        # buffers and replay it.  Bit-identical, but measured to gain nothing (9.90 vs 9.93 ms at the 2 304 columns of a
+        # C48 rank): a step there is bound by the ~60 us one 128-sample tile needs on each of the 18 CUs it occupies,
+        # not by launch overhead -- hence off by default.
+        self._use_graph = use_graph
+        self._graphs: Dict[Tuple[int, int], tuple] = {}
         self._cells: List[MlpModel] = []
         c = spec.n_channels
         for n, layer in enumerate(spec.layers):
@@ -414,13 +423,27 @@ class RnnModel(_PointModel):
         """As ``LocalMlpModel.predict``; single-level outputs come back as ``[1, ncol]``."""
         spec = self.spec
         arrs, nz, ncol, dev = self._gather(sources)
-        x = self._pack(arrs, nz, ncol, dev).view(len(spec.inputs), nz, ncol)
         c = spec.n_channels
-        y = torch.empty((c, nz, ncol), dtype=torch.float32, device=dev)
-        states = []
-        for m in self._cells:
-            ch = m.spec.width
-            states.append([torch.zeros((ch, ncol), dtype=torch.float32, device=dev), torch.empty((ch, ncol), dtype=torch.float32, device=dev)])
+        if self._use_graph:
+            x, y = self._sweep_graphed(arrs, nz, ncol, dev)
+        else:
+            x = self._pack(arrs, nz, ncol, dev).view(len(spec.inputs), nz, ncol)
+            y = torch.empty((c, nz, ncol), dtype=torch.float32, device=dev)
+            self._sweep(x, y, self._new_states(ncol, dev), nz)
+        del x
+        out: Dict[str, torch.Tensor] = {}
+        for n, o in enumerate(spec.outputs):
+            if o.single_level:  # the surface step holds the whole column's information (architecture.py:403-407)
+                self._unpack_one(n, o, y[n, 0], ncol, arrs, 1, ncol, dev, out)
+            else:
+                self._unpack_one(n, o, y[n], ncol, arrs, nz, ncol, dev, out)
+        return out
+
+    def _new_states(self, ncol: int, dev):
+        return [[torch.zeros((m.spec.width, ncol), dtype=torch.float32, device=dev),
+                 torch.empty((m.spec.width, ncol), dtype=torch.float32, device=dev)] for m in self._cells]
+
+    def _sweep(self, x: torch.Tensor, y: torch.Tensor, states, nz: int) -> None:
         for step, z in enumerate(range(nz - 1, -1, -1)):  # from the model top (last index) to the surface
             cur, nxt = step & 1, (step & 1) ^ 1
             below = x[:, z]
@@ -430,11 +453,27 @@ class RnnModel(_PointModel):
                     outs["y"] = y[:, z]
                 m.predict({"in": below, "rec": states[n][cur]}, out=outs)
                 below = states[n][nxt]
-        del x, states
-        out: Dict[str, torch.Tensor] = {}
-        for n, o in enumerate(spec.outputs):
-            if o.single_level:  # the surface step holds the whole column's information (architecture.py:403-407)
-                self._unpack_one(n, o, y[n, 0], ncol, arrs, 1, ncol, dev, out)
-            else:
-                self._unpack_one(n, o, y[n], ncol, arrs, nz, ncol, dev, out)
-        return out
+
+    def _sweep_graphed(self, arrs, nz: int, ncol: int, dev):
+        """Pack into the graph's static input buffer, replay the captured sweep, hand back its static output buffer
+        (valid until the next call with the same shape; ``predict`` consumes it before returning)."""
+        key = (nz, ncol)
+        entry = self._graphs.get(key)
+        if entry is None:
+            self._graphs.clear()  # one shape at a time: the static buffers of another shape are released
+            x = torch.empty((len(self.spec.inputs), nz, ncol), dtype=torch.float32, device=dev)
+            y = torch.empty((self.spec.n_channels, nz, ncol), dtype=torch.float32, device=dev)
+            states = self._new_states(ncol, dev)
+            self._pack_into(arrs, nz, ncol, dev, x)
+            self._sweep(x, y, states, nz)  # eager warm-up: the kernels' one-time allocations happen here
+            torch.cuda.synchronize(dev)
+            graph = torch.cuda.CUDAGraph()
+            with torch.cuda.graph(graph):
+                for st in states:
+                    st[0].zero_()
+                self._sweep(x, y, states, nz)
+            entry = self._graphs[key] = (graph, x, y, states)
+        graph, x, y, _ = entry
+        self._pack_into(arrs, nz, ncol, dev, x)
+        graph.replay()
+        return x, y
