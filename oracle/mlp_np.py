@@ -87,6 +87,8 @@ def forward(spec, sources, dtype=np.float32):
         h = np.maximum(h, 0)
     yhat = h @ np.asarray(spec.out_kernel, np.float32).astype(dtype) + np.asarray(spec.out_bias, np.float32).astype(dtype)
     out = {}
+    if getattr(spec, "hidden_output", None):  # the last hidden layer's activations as an output of their own
+        out[spec.hidden_output] = h
     f0 = 0
     for o in spec.outputs:
         y = yhat[:, f0:f0 + o.nfeat]

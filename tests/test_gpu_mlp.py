@@ -246,3 +246,33 @@ def test_snapshot_stream_matches_direct_predict(device, in_dtype, n_buffers):
     assert seen == list(range(n_snap))
     stream.run(3, fill, consume)  # reusable
     assert seen[-3:] == [0, 1, 2]
+
+
+@pytest.mark.parametrize("width", [16, 64, 100, 128, 256])
+@pytest.mark.parametrize("n_samples,with_outputs", [(4096, True), (1000, True), (4096, False), (77, False)])
+def test_hidden_output_models(device, width, n_samples, with_outputs):
+    """Models whose last hidden layer is an output of its own (the cells of the RNN emulators): every hidden
+    tiling (width 16 ... 256), the fast-I/O and the general kernels (sample counts that are / are not multiples of
+    32), with and without ordinary outputs, against the float64 oracle."""
+    from fv3net_amd.mlp import MlpModel
+
+    rng = np.random.default_rng(width + n_samples)
+    spec = _random_spec(rng, {"a": ("a", 21, 0), "b": ("b", 40, 0)}, width, 2, {"y": 7, "z": 33} if with_outputs else {})
+    spec.hidden_output = "h"
+    src = {"a": rng.normal(0, 1, (n_samples, 21)).astype(np.float32), "b": rng.normal(0, 1, (n_samples, 40)).astype(np.float32)}
+    model = MlpModel(spec, device=device)
+    got = model.predict({k: torch.from_numpy(np.ascontiguousarray(v.T)).to(device) for k, v in src.items()})
+    truth = mlp_np.forward(spec, src, dtype=np.float64)
+    assert list(got) == (["y", "z"] if with_outputs else []) + ["h"]
+    assert got["h"].shape == (width, n_samples)
+    assert (got["h"] >= 0).all()
+    for name in got:
+        t = truth[name].T
+        assert np.max(np.abs(got[name].cpu().numpy() - t)) <= 1e-5 * np.max(np.abs(t)), name
+    # strided outputs (a level's slice of a larger array, as the RNN sweep passes them) and reuse of the handle
+    big = torch.zeros((width, 3, n_samples), device=device)
+    outs = {"h": big[:, 1]}
+    if with_outputs:
+        outs.update({"y": torch.empty((7, n_samples), device=device), "z": torch.empty((33, n_samples), device=device)})
+    model.predict({k: torch.from_numpy(np.ascontiguousarray(v.T)).to(device) for k, v in src.items()}, out=outs)
+    assert torch.equal(big[:, 1], got["h"]) and not big[:, 0].any() and not big[:, 2].any()
