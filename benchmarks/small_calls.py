@@ -6,7 +6,7 @@ from fv3net_amd.local_mlp import LocalMlpModel, RnnModel
 dev = torch.device('cuda:0')
 rng = np.random.default_rng(0)
 nz = 79
-for ncol in (2304, 36864):
+for ncol in (2304, 36864, 147456):
     st = cases.state(rng, nz, ncol, np.float64)
     d = {k: torch.from_numpy(v).to(dev) for k, v in st.items()}
     for label, model in (("dense-local", LocalMlpModel(cases.regressor(rng, st, nz, width=256, make=cases.product_makers()), device=dev)),

@@ -429,7 +429,8 @@ class RnnModel(_PointModel):
         else:
             x = self._pack(arrs, nz, ncol, dev).view(len(spec.inputs), nz, ncol)
             y = torch.empty((c, nz, ncol), dtype=torch.float32, device=dev)
-            self._sweep(x, y, self._new_states(ncol, dev), nz)
+            # (below ~128 columns per CU the launches of one layer leave most of the chip idle)
+            self._sweep(x, y, self._new_states(ncol, dev), nz, pipelined=ncol < 128 * self._inner_cus())
         del x
         out: Dict[str, torch.Tensor] = {}
         for n, o in enumerate(spec.outputs):
@@ -439,20 +440,53 @@ class RnnModel(_PointModel):
                 self._unpack_one(n, o, y[n], ncol, arrs, nz, ncol, dev, out)
         return out
 
+    def _inner_cus(self) -> int:
+        from .ops import device_info
+
+        if not hasattr(self, "_n_cu"):
+            self._n_cu = int(device_info()["compute_units"])
+        return self._n_cu
+
     def _new_states(self, ncol: int, dev):
         return [[torch.zeros((m.spec.width, ncol), dtype=torch.float32, device=dev),
                  torch.empty((m.spec.width, ncol), dtype=torch.float32, device=dev)] for m in self._cells]
 
-    def _sweep(self, x: torch.Tensor, y: torch.Tensor, states, nz: int) -> None:
-        for step, z in enumerate(range(nz - 1, -1, -1)):  # from the model top (last index) to the surface
+    def _sweep(self, x: torch.Tensor, y: torch.Tensor, states, nz: int, pipelined: bool = False) -> None:
+        """The recurrence, from the model top (last index) to the surface.  ``pipelined``: one HIP stream per layer, so
+        that layer n+1 of level z runs beside layer n of level z-1 (for column counts that leave most CUs idle).  The
+        hazards are the state ping-pong buffers: layer n+1 reads at step t what layer n wrote at step t, and layer n
+        overwrites at step t+1 the buffer layer n+1 read at step t-1."""
+        depth = len(self._cells)
+        if pipelined and depth > 1:
+            dev = x.device
+            main = torch.cuda.current_stream(dev)
+            if not hasattr(self, "_streams"):
+                self._streams = [torch.cuda.Stream(dev) for _ in range(depth)]
+            done = [[torch.cuda.Event() for _ in range(nz)] for _ in range(depth)]
+            for s in self._streams:
+                s.wait_stream(main)
+        for step, z in enumerate(range(nz - 1, -1, -1)):
             cur, nxt = step & 1, (step & 1) ^ 1
             below = x[:, z]
             for n, m in enumerate(self._cells):
                 outs = {"h": states[n][nxt]}
-                if n == len(self._cells) - 1:
+                if n == depth - 1:
                     outs["y"] = y[:, z]
-                m.predict({"in": below, "rec": states[n][cur]}, out=outs)
+                if pipelined and depth > 1:
+                    st = self._streams[n]
+                    with torch.cuda.stream(st):
+                        if n > 0:
+                            st.wait_event(done[n - 1][step])
+                        if n + 1 < depth and step >= 2:
+                            st.wait_event(done[n + 1][step - 2])
+                        m.predict({"in": below, "rec": states[n][cur]}, out=outs)
+                        done[n][step].record(st)
+                else:
+                    m.predict({"in": below, "rec": states[n][cur]}, out=outs)
                 below = states[n][nxt]
+        if pipelined and depth > 1:
+            for s in self._streams:
+                main.wait_stream(s)
 
     def _sweep_graphed(self, arrs, nz: int, ncol: int, dev):
         """Pack into the graph's static input buffer, replay the captured sweep, hand back its static output buffer
