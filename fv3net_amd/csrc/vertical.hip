@@ -587,26 +587,24 @@ __global__ __launch_bounds__(256) void mappm_merge_kernel(
         // Per layer a lane goes through zero or more emitting events (the bottom part of an
         // accumulating target; targets lying entirely inside the layer) and then exactly one
         // non-emitting one (start a target that leaves the layer / add the whole layer / nothing).
-        for (;;) {
-            const bool part = live && accum && !(p2k1 > pL1);
-            const bool inside = live && !accum && (p2k >= pL && p2k <= pL1) && (p2k1 <= pL1);
-            if (!(part || inside)) break;
-            float val;
-            // (p2k1 - pL) / d0 is `esl` of the accumulating branch and `PR` of the inside branch: the
-            // same operations on the same operands, so one division serves whichever branch a lane takes
+        // an accumulating target can end in this layer only once, before any target that lies inside it:
+        // that step is taken out of the loop, so that lanes closing a target and lanes emitting inside
+        // ones do not serialise each other's branch
+        if (live && accum && !(p2k1 > pL1)) {
             const float delp = p2k1 - pL;
             const float PR = delp / d0;
-            if (part) {
-                qsum = qsum + delp * (al + 0.5f * PR * (ar - al + a6 * (1.f - r23 * PR)));
-                dpsum = dpsum + delp;
-                val = qsum / dpsum;
-                accum = false;
-            } else {
-                const float PL = (p2k - pL) / d0;
-                const float TT = r3 * (PR * (PR + PL) + PL * PL);
-                val = al + 0.5f * (a6 + ar - al) * (PR + PL) - a6 * TT;
-            }
-            OUT(k, val);
+            qsum = qsum + delp * (al + 0.5f * PR * (ar - al + a6 * (1.f - r23 * PR)));
+            dpsum = dpsum + delp;
+            OUT(k, qsum / dpsum);
+            accum = false;
+            advance();
+            live = (k <= kn) && !bad && !(p2k >= pe1_bot);
+        }
+        while (live && !accum && (p2k >= pL && p2k <= pL1) && (p2k1 <= pL1)) {
+            const float PR = (p2k1 - pL) / d0;
+            const float PL = (p2k - pL) / d0;
+            const float TT = r3 * (PR * (PR + PL) + PL * PL);
+            OUT(k, al + 0.5f * (a6 + ar - al) * (PR + PL) - a6 * TT);
             advance();
             live = (k <= kn) && !bad && !(p2k >= pe1_bot);
         }
@@ -874,26 +872,25 @@ __global__ __launch_bounds__(256) void mappm_merge_multi_kernel(
         }
         const float pL = pe_a, pL1 = pe_b;
 
-        for (;;) {
-            const bool part = live && accum && !(p2k1 > pL1);
-            const bool inside = live && !accum && (p2k >= pL && p2k <= pL1) && (p2k1 <= pL1);
-            if (!(part || inside)) break;
+        if (live && accum && !(p2k1 > pL1)) {  // (see mappm_merge_kernel)
             const float delp = p2k1 - pL;
             const float PR = delp / d0;
-            if (part) {
-                dpsum = dpsum + delp;
+            dpsum = dpsum + delp;
 #pragma unroll
-                for (int f = 0; f < NF; ++f) {
-                    qsum[f] = qsum[f] + delp * (al[f] + 0.5f * PR * (ar[f] - al[f] + a6[f] * (1.f - r23 * PR)));
-                    OUT(f, k, qsum[f] / dpsum);
-                }
-                accum = false;
-            } else {
-                const float PL = (p2k - pL) / d0;
-                const float TT = r3 * (PR * (PR + PL) + PL * PL);
-#pragma unroll
-                for (int f = 0; f < NF; ++f) OUT(f, k, al[f] + 0.5f * (a6[f] + ar[f] - al[f]) * (PR + PL) - a6[f] * TT);
+            for (int f = 0; f < NF; ++f) {
+                qsum[f] = qsum[f] + delp * (al[f] + 0.5f * PR * (ar[f] - al[f] + a6[f] * (1.f - r23 * PR)));
+                OUT(f, k, qsum[f] / dpsum);
             }
+            accum = false;
+            advance();
+            live = (k <= kn) && !bad && !(p2k >= pe1_bot);
+        }
+        while (live && !accum && (p2k >= pL && p2k <= pL1) && (p2k1 <= pL1)) {
+            const float PR = (p2k1 - pL) / d0;
+            const float PL = (p2k - pL) / d0;
+            const float TT = r3 * (PR * (PR + PL) + PL * PL);
+#pragma unroll
+            for (int f = 0; f < NF; ++f) OUT(f, k, al[f] + 0.5f * (a6[f] + ar[f] - al[f]) * (PR + PL) - a6[f] * TT);
             advance();
             live = (k <= kn) && !bad && !(p2k >= pe1_bot);
         }
