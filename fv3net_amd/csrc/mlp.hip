@@ -128,6 +128,8 @@ struct MlpLaunch {
     int n_hidden;
     int n_otiles;       // 32-feature output tiles (= output-type chunks per sample tile)
     int n_hout_tiles;   // leading tiles of the output table that are the last hidden layer's activations themselves (0 or HT)
+    int smallf_off;     // small-output launches: offset (floats) in the bias block of the [HT*32][4] output weights
+    int smallf_n;       // small-output launches: number of network outputs (1..4)
     int64_t sink;       // fast-I/O launches: device row of n_samples values that padded output rows are stored to
     int n_ktab;
     int n_otab;
@@ -178,7 +180,7 @@ __host__ __device__ constexpr int rho(int r) { return (r & 3) + 8 * (r >> 2); }
 // (32 features x 128 samples) are brought in by the whole workgroup with 16-byte loads, normalised
 // four at a time and parked in LDS; a k-pair slot then needs one ds_read for its B operand
 // instead of a table lookup, an address computation, a 4-byte load and the normalisation.
-template <int HT, bool SRC64, bool XBULK, bool HOUT>
+template <int HT, bool SRC64, bool XBULK, bool HOUT, bool SMALLF>
 __global__ __launch_bounds__(kThreads, 1) void mlp_fused_kernel(const MlpLaunch p)
 {
     constexpr int HG = (HT + 3) / 4;          // float4 groups of hidden-feature tiles
@@ -906,6 +908,47 @@ __global__ __launch_bounds__(kThreads, 1) void mlp_fused_kernel(const MlpLaunch 
                 }
                 if (prefetch_next) finish_x(0);
             }
+            // Small-output models (at most 4 network outputs: the "dense-local" regressors and classifier, the RNN
+            // emulators' output convolutions): a 32-row output tile would spend 128 fp32 32x32x2 MFMAs (8 192 cycles) on
+            // 2-4 useful rows.  Instead the contraction runs on v_mfma_f32_4x4x1 (16 blocks of 4 outputs x 4 samples, 8
+            // cycles): a lane's B operand is its own hidden activation h[t][r] (feature 32t + rho(r) + 4*half of its
+            // sample), its A operand the weight of output (lane & 3) for that feature, and D[v] accumulates output v of
+            // the lane's sample over the lane's half of the features; the two halves are added with one cross-lane move.
+            // The launch carries no output chunk in its weight stream (NT = 0); float32 outputs without limits only.
+            if constexpr (SMALLF) {
+                // the lane's 16 weights of a hidden tile are contiguous ([half][output][tile][reg], packed by the host): four
+                // 16-byte LDS reads per tile, those of tile t+1 in flight under the 16 MFMAs of tile t
+                typedef const f32x4 __attribute__((address_space(3))) *LW4;
+                LW4 wl = (LW4)(biasl + p.smallf_off + (half * 4 + (lane & 3)) * HT * 16);
+                asm volatile("" : "+v"(wl));  // (opaque base: the reads use immediate offsets)
+                const f32x4 *wq = (const f32x4 *)wl;
+                f32x4 acc4[4], wcur[4], wnxt[4];
+#pragma unroll
+                for (int i = 0; i < 4; ++i) {
+                    acc4[i] = f32x4{0.f, 0.f, 0.f, 0.f};
+                    wcur[i] = wq[i];
+                }
+#pragma unroll
+                for (int t = 0; t < HT; ++t) {
+#pragma unroll
+                    for (int i = 0; i < 4; ++i) wnxt[i] = wq[((t + 1 < HT) ? t + 1 : t) * 4 + i];
+#pragma unroll
+                    for (int r = 0; r < 16; ++r)
+                        acc4[r & 3] = __builtin_amdgcn_mfma_f32_4x4x1f32(wcur[r >> 2][r & 3], h[t][r], acc4[r & 3], 0, 0, 0);
+#pragma unroll
+                    for (int i = 0; i < 4; ++i) wcur[i] = wnxt[i];
+                }
+                f32x4 y4 = (acc4[0] + acc4[1]) + (acc4[2] + acc4[3]);
+#pragma unroll
+                for (int v = 0; v < 4; ++v) y4[v] += __shfl_xor(y4[v], 32, 64);
+                if (half == 0 && n0t < p.n_samples) {
+                    typedef float __attribute__((address_space(1))) *GF32;
+                    const float *bo = biasl + p.n_hidden * HT * 32;  // [reg][half] of output tile 0: output f sits at 2 f
+#pragma unroll
+                    for (int v = 0; v < 4; ++v)
+                        if (v < p.smallf_n) *(GF32)(ofast[NHO * 32 + v].row + (n0t + lane) * 4) = y4[v] + bo[2 * v];
+                }
+            }
             auto tile_loop = [&](auto plain_c) __attribute__((always_inline)) {
                 if constexpr (EPI_SIDE) {
                     load_bias(yA, 0);
@@ -927,6 +970,7 @@ __global__ __launch_bounds__(kThreads, 1) void mlp_fused_kernel(const MlpLaunch 
                     }
                 }
             };
+            if constexpr (!SMALLF) {  // (small-output launches carry no output chunk: NT = 0)
             if (!HOUT || NT > 0) {
                 if (EPI_SIDE && !p.has_limits && !p.out64 && !p.n_residual && (tile + 1) * kTileSamples <= p.n_samples)
                     tile_loop(std::true_type{});
@@ -935,6 +979,7 @@ __global__ __launch_bounds__(kThreads, 1) void mlp_fused_kernel(const MlpLaunch 
             STAMP_END(2);
             if (EPI_SIDE && (!HOUT || NT > 0)) {  // the last tile's epilogue (tile NT-1 sits in yA if NT is odd)
                 if (NT & 1) epi_fast_now(yA, NHO + NT - 1); else epi_fast_now(yB, NHO + NT - 1);
+            }
             }
             // the scratch half of xs is rewritten by the next tile's first layer-1 chunk
             if (XBULK) MLP_CHUNK_BARRIER();
@@ -963,6 +1008,7 @@ struct fv3hip_mlp {
     int HT = 0;
     int n_sources = 0, n_inputs = 0, K = 0, width = 0, n_hidden = 0, n_outputs = 0, F = 0, n_residual = 0;
     int n_chunks1 = 0, n_otiles = 0, n_hout_tiles = 0, n_ktab = 0, n_otab = 0, n_bias = 0;
+    int smallf_off = 0, smallf_n = 0;  // small-output path: where its [HT*32][4] weights sit in the bias block; 0 = not eligible
     int64_t flops = 0;
     int has_limits = 0;
     int n_log_chunks = 0, n_logfast_chunks = 0;
@@ -978,10 +1024,10 @@ namespace {
 
 const int kHiddenTilings[] = {1, 2, 4, 8};  // compiled kernel variants: hidden width <= 32 * HT
 
-template <int HT, bool SRC64, bool XBULK, bool HOUT = false>
+template <int HT, bool SRC64, bool XBULK, bool HOUT = false, bool SMALLF = false>
 int launch_one(const MlpLaunch &lp, int grid, size_t lds, hipStream_t st)
 {
-    auto kern = mlp_fused_kernel<HT, SRC64, XBULK, HOUT>;
+    auto kern = mlp_fused_kernel<HT, SRC64, XBULK, HOUT, SMALLF>;
     FV3HIP_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(kern),
                                          hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
     hipLaunchKernelGGL(kern, dim3(grid), dim3(kThreads), lds, st, lp);
@@ -1064,6 +1110,11 @@ extern "C" int fv3hip_mlp_create(const fv3hip_mlp_desc_t *d, fv3hip_mlp_t *out)
     m->n_hout_tiles = hout ? HT : 0;
     m->n_otab = 32 * (m->n_hout_tiles + nt_out);
     m->n_bias = d->n_hidden * HT * 32 + nt_out * 32;
+    if (F >= 1 && F <= 4 && !m->has_limits && d->n_residual == 0) {  // eligible for the small-output path (see the kernel)
+        m->smallf_n = F;
+        m->smallf_off = m->n_bias;
+        m->n_bias += HT * 32 * 4;
+    }
     m->flops = 2 * ((int64_t)K * width + (int64_t)(d->n_hidden - 1) * width * width + (int64_t)width * F);
 
     const int HG = (HT + 3) / 4;
@@ -1217,6 +1268,17 @@ extern "C" int fv3hip_mlp_create(const fv3hip_mlp_desc_t *d, fv3hip_mlp_t *out)
                         (float)((double)d->out_bias[f] * (d->out_scale ? d->out_scale[f] : 1.f) + (d->out_center ? d->out_center[f] : 0.f));
             }
 
+    if (m->smallf_n)  // [half][output f][hidden tile t][accumulator register r] -> feature k = 32 t + rho(r) + 4 half; scale folded in
+        for (int hf = 0; hf < 2; ++hf)
+            for (int f = 0; f < F; ++f)
+                for (int t = 0; t < HT; ++t)
+                    for (int r = 0; r < 16; ++r) {
+                        const int k = 32 * t + rho(r) + 4 * hf;
+                        if (k < width)
+                            bias[(size_t)m->smallf_off + (size_t)(((hf * 4 + f) * HT + t) * 16 + r)] =
+                                d->out_kernel[(size_t)k * F + f] * (d->out_scale ? d->out_scale[f] : 1.f);
+                    }
+
     int rc;
     FV3HIP_REQUIRE(w.size() * sizeof(float) < (1ull << 31), "model too large: the packed weight stream exceeds 2 GiB");
     m->w_bytes = (unsigned int)(w.size() * sizeof(float));
@@ -1353,7 +1415,17 @@ extern "C" int fv3hip_mlp_predict(fv3hip_mlp_t m, const void *const *sources, co
     // register allocation and schedule; they take float32 sources only (packed inputs and states)
     if (m->n_hout_tiles && src64)
         return fail(FV3HIP_EUNSUPPORTED, "hidden-output models take float32 sources only");
+    // small-output launches (<= 4 outputs, fast I/O, float32 in and out): no output chunk in the stream
+    const bool smallf = m->smallf_n && xbulk && !src64 && out_dtype == FV3HIP_F32;
+    if (smallf) {
+        lp.n_otiles = 0;
+        lp.smallf_off = m->smallf_off;
+        lp.smallf_n = m->smallf_n;
+    }
 #define VARIANT_(H)                                                                                \
+    if (m->HT == H && smallf)                                                                      \
+        return m->n_hout_tiles ? launch_one<H, false, true, true, true>(lp, grid, lds, st)         \
+                               : launch_one<H, false, true, false, true>(lp, grid, lds, st);       \
     if (m->HT == H && m->n_hout_tiles)                                                             \
         return xbulk ? launch_one<H, false, true, true>(lp, grid, lds, st) : launch_one<H, false, false, true>(lp, grid, lds, st); \
     if (m->HT == H) {                                                                              \
