@@ -180,7 +180,7 @@ __host__ __device__ constexpr int rho(int r) { return (r & 3) + 8 * (r >> 2); }
 // (32 features x 128 samples) are brought in by the whole workgroup with 16-byte loads, normalised
 // four at a time and parked in LDS; a k-pair slot then needs one ds_read for its B operand
 // instead of a table lookup, an address computation, a 4-byte load and the normalisation.
-template <int HT, bool SRC64, bool XBULK, bool HOUT, bool SMALLF>
+template <int HT, bool SRC64, bool XBULK, bool HOUT, bool SMALLF, bool L1SHORT>
 __global__ __launch_bounds__(kThreads, 1) void mlp_fused_kernel(const MlpLaunch p)
 {
     constexpr int HG = (HT + 3) / 4;          // float4 groups of hidden-feature tiles
@@ -576,7 +576,10 @@ __global__ __launch_bounds__(kThreads, 1) void mlp_fused_kernel(const MlpLaunch 
             // XBULK path: the B operand comes from the LDS input tile xs[xb]; the tile of chunk cn of
             // the workgroup tile starting at sample n0 is requested in slot 1 (4 x 16-byte loads per
             // thread) and normalised and written to xs[xb ^ 1] in slots 9..12.
-            auto l1_chunk_bulk = [&](int cn, int64_t n0, auto with_log) __attribute__((always_inline)) {
+            // (kc1_c: slots of the chunk -- 16, or 8 in the L1SHORT kernels, whose single layer-1 chunk holds at most 16
+            // inputs: the k-pairs beyond them would multiply zeros; the input tile is then finished in slots 4..7)
+            auto l1_chunk_bulk = [&](int cn, int64_t n0, auto with_log, auto kc1_c) __attribute__((always_inline)) {
+                constexpr int KC1 = decltype(kc1_c)::value, FIN0 = (KC1 == 16) ? 8 : 3;
                 const int gnext = (g + 1 < G) ? g + 1 : 0;
                 const float *xsb = xs + xb * 32 * kTileSamples + half * kTileSamples + wave * 32 + (lane & 31);
                 const float *xsn = xs + (xb ^ 1) * 32 * kTileSamples + half * kTileSamples + wave * 32 + (lane & 31);
@@ -592,11 +595,11 @@ __global__ __launch_bounds__(kThreads, 1) void mlp_fused_kernel(const MlpLaunch 
                 const XAddr *xa_g = (const XAddr *)xa_c;
                 const XNorm *xn_g = (const XNorm *)xn_c;
 #pragma unroll
-                for (int s = 0; s < KC_H; ++s) {
+                for (int s = 0; s < KC1; ++s) {
                     SLOT_STAMP((int)decltype(with_log)::value, s);
-                    run_slot(h, HT_c{}, HG_c{}, Q5_c{}, s, KC_H, b_cur, [&](int s_) {
+                    run_slot(h, HT_c{}, HG_c{}, Q5_c{}, s, KC1, b_cur, [&](int s_) {
                         // (the last slot runs this after the chunk barrier: xs[xb ^ 1] is complete)
-                        b_cur = (s_ + 1 < KC_H) ? xsb[2 * (s_ + 1) * kTileSamples] : xsn[0];
+                        b_cur = (s_ + 1 < KC1) ? xsb[2 * (s_ + 1) * kTileSamples] : xsn[0];
                         // table entries are read a slot before they are used
                         if (s_ == 0) {
 #pragma unroll
@@ -606,15 +609,15 @@ __global__ __launch_bounds__(kThreads, 1) void mlp_fused_kernel(const MlpLaunch 
 #pragma unroll
                             for (int i = 0; i < 4; ++i) bulk_issue1(xa4[i], i, nb);
                         }
-                        if (s_ == KC_H / 2) {
+                        if (s_ == FIN0) {
 #pragma unroll
                             for (int i = 0; i < 4; ++i) xn4[i] = xn_g[8 * i];
                         }
-                        if (s_ > KC_H / 2 && s_ <= KC_H / 2 + 4) bulk_finish_e(xn4[s_ - KC_H / 2 - 1], s_ - KC_H / 2 - 1, xb ^ 1, with_log);
-                        stage_step(s_, KC_H, gnext, par ^ 1);
+                        if (s_ > FIN0 && s_ <= FIN0 + 4) bulk_finish_e(xn4[s_ - FIN0 - 1], s_ - FIN0 - 1, xb ^ 1, with_log);
+                        stage_step(s_, KC1, gnext, par ^ 1);
                     });
                 }
-                CHUNK_STAMP_END((int)decltype(with_log)::value, KC_H);
+                CHUNK_STAMP_END((int)decltype(with_log)::value, KC1);
                 par ^= 1;
                 xb ^= 1;
                 ++g;
@@ -625,15 +628,20 @@ __global__ __launch_bounds__(kThreads, 1) void mlp_fused_kernel(const MlpLaunch 
                 using M1_ = std::integral_constant<int, 1>;
                 using M2_ = std::integral_constant<int, 2>;
                 const int NF = p.n_logfast_chunks;  // chunks [0, NF) take the fast log (NF <= L)
-                int c = 0;  // chunk c prepares the inputs of chunk c + 1
-                for (; c + 1 < NF; ++c) l1_chunk_bulk(c + 1, n0, M2_{});
-                for (; c + 1 < L; ++c) l1_chunk_bulk(c + 1, n0, M1_{});
-                for (; c < NC - 1; ++c) l1_chunk_bulk(c + 1, n0, M0_{});
+                using KC16_ = std::integral_constant<int, 16>;
                 // the last chunk brings in chunk 0 of the workgroup's next tile
                 const int64_t n1 = (next_tile < p.n_tiles ? next_tile : tile) * kTileSamples;
-                if (NF > 0) l1_chunk_bulk(0, n1, M2_{});
-                else if (L > 0) l1_chunk_bulk(0, n1, M1_{});
-                else l1_chunk_bulk(0, n1, M0_{});
+                if constexpr (L1SHORT) {  // one chunk of at most 16 plain inputs (the host checks)
+                    l1_chunk_bulk(0, n1, M0_{}, std::integral_constant<int, 8>{});
+                } else {
+                    int c = 0;  // chunk c prepares the inputs of chunk c + 1
+                    for (; c + 1 < NF; ++c) l1_chunk_bulk(c + 1, n0, M2_{}, KC16_{});
+                    for (; c + 1 < L; ++c) l1_chunk_bulk(c + 1, n0, M1_{}, KC16_{});
+                    for (; c < NC - 1; ++c) l1_chunk_bulk(c + 1, n0, M0_{}, KC16_{});
+                    if (NF > 0) l1_chunk_bulk(0, n1, M2_{}, KC16_{});
+                    else if (L > 0) l1_chunk_bulk(0, n1, M1_{}, KC16_{});
+                    else l1_chunk_bulk(0, n1, M0_{}, KC16_{});
+                }
             } else {
                 // a chunk that mixes both kinds (the boundary chunk, or the re-derivation on the last
                 // chunk) takes the with-log flavour, which selects per feature
@@ -1024,10 +1032,10 @@ namespace {
 
 const int kHiddenTilings[] = {1, 2, 4, 8};  // compiled kernel variants: hidden width <= 32 * HT
 
-template <int HT, bool SRC64, bool XBULK, bool HOUT = false, bool SMALLF = false>
+template <int HT, bool SRC64, bool XBULK, bool HOUT = false, bool SMALLF = false, bool L1SHORT = false>
 int launch_one(const MlpLaunch &lp, int grid, size_t lds, hipStream_t st)
 {
-    auto kern = mlp_fused_kernel<HT, SRC64, XBULK, HOUT, SMALLF>;
+    auto kern = mlp_fused_kernel<HT, SRC64, XBULK, HOUT, SMALLF, L1SHORT>;
     FV3HIP_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(kern),
                                          hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
     hipLaunchKernelGGL(kern, dim3(grid), dim3(kThreads), lds, st, lp);
@@ -1422,7 +1430,10 @@ extern "C" int fv3hip_mlp_predict(fv3hip_mlp_t m, const void *const *sources, co
         lp.smallf_off = m->smallf_off;
         lp.smallf_n = m->smallf_n;
     }
+    // ... and, with one layer-1 chunk of at most 16 untransformed inputs, an 8-slot first chunk (the dense-local models)
+    const bool l1short = smallf && !m->n_hout_tiles && m->K <= 16 && m->n_log_chunks == 0;
 #define VARIANT_(H)                                                                                \
+    if (m->HT == H && l1short) return launch_one<H, false, true, false, true, true>(lp, grid, lds, st); \
     if (m->HT == H && smallf)                                                                      \
         return m->n_hout_tiles ? launch_one<H, false, true, true, true>(lp, grid, lds, st)         \
                                : launch_one<H, false, true, false, true>(lp, grid, lds, st);       \
