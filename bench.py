@@ -524,8 +524,8 @@ def main():
                 "peak": PEAK_FP32_MFMA_TFLOPS,
                 "unit": "TFLOP/s",
                 "frac": achieved / PEAK_FP32_MFMA_TFLOPS,
-                "traffic": pmc_traffic("mlp_fused_kernel<8,false,true,false>"),
-                "kernel": "mlp_fused_kernel<8,false,true,false>",
+                "traffic": pmc_traffic("mlp_fused_kernel<8,false,true,false,false,false>"),
+                "kernel": "mlp_fused_kernel<8,false,true,false,false,false>",
                 "kernel_ms": kernel_ms,
             },
         }
