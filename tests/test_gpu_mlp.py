@@ -276,3 +276,27 @@ def test_hidden_output_models(device, width, n_samples, with_outputs):
         outs.update({"y": torch.empty((7, n_samples), device=device), "z": torch.empty((33, n_samples), device=device)})
     model.predict({k: torch.from_numpy(np.ascontiguousarray(v.T)).to(device) for k, v in src.items()}, out=outs)
     assert torch.equal(big[:, 1], got["h"]) and not big[:, 0].any() and not big[:, 2].any()
+
+
+@pytest.mark.parametrize("width", [16, 64, 100, 128, 256])
+@pytest.mark.parametrize("k_in,n_out,n_samples", [(12, 2, 4096), (16, 4, 2048), (40, 1, 4096), (12, 3, 1000), (300, 4, 4096)])
+def test_small_output_and_short_first_chunk_variants(device, width, k_in, n_out, n_samples):
+    """Models with at most 4 outputs take the v_mfma_f32_4x4x1 output path on fast-I/O launches (and, with at most 16
+    inputs, the 8-slot first chunk); ragged sample counts fall back to the ordinary kernels of the same handle.
+    Every hidden tiling, against the float64 oracle; with and without a hidden output."""
+    from fv3net_amd.mlp import MlpModel
+
+    rng = np.random.default_rng(width * 7 + k_in + n_out)
+    outs = {f"y{i}": 1 for i in range(n_out)}
+    src = {"a": rng.normal(0, 1, (n_samples, k_in)).astype(np.float32)}
+    dev_src = {"a": torch.from_numpy(np.ascontiguousarray(src["a"].T)).to(device)}
+    for hidden_output in (None, "h"):
+        spec = _random_spec(rng, {"a": ("a", k_in, 0)}, width, 2, outs)
+        spec.hidden_output = hidden_output
+        got = MlpModel(spec, device=device).predict(dev_src)
+        truth = mlp_np.forward(spec, src, dtype=np.float64)
+        assert list(got) == list(outs) + ([hidden_output] if hidden_output else [])
+        for name in got:
+            t = truth[name].T
+            assert got[name].shape == t.shape
+            assert np.max(np.abs(got[name].cpu().numpy() - t)) <= 1e-5 * max(np.max(np.abs(t)), 1e-30), (name, hidden_output)
