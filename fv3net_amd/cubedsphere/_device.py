@@ -46,3 +46,23 @@ def horizontal_last(da: DataArray, y_dim: Hashable, x_dim: Hashable):
 def float_tensor(t: torch.Tensor) -> torch.Tensor:
     """numpy promotion of `field * float weights`: integer fields become float64."""
     return t if t.dtype in (torch.float32, torch.float64) else t.to(torch.float64)
+
+
+def download_all(outputs):
+    """{name: device tensor or anything else} -> {name: numpy array or the value as it was}, with one device-to-host
+    copy (one synchronisation) per dtype instead of one per array: for small arrays the copies' fixed cost dominates."""
+    result = {name: t for name, t in outputs.items() if not (isinstance(t, torch.Tensor) and t.is_cuda)}
+    by_dtype = {}
+    for name, t in outputs.items():
+        if name not in result:
+            by_dtype.setdefault(t.dtype, []).append((name, t))
+    for items in by_dtype.values():
+        if len(items) == 1:
+            result[items[0][0]] = items[0][1].cpu().numpy()
+            continue
+        flat = torch.cat([t.reshape(-1) for _, t in items]).cpu().numpy()
+        pos = 0
+        for name, t in items:
+            result[name] = flat[pos:pos + t.numel()].reshape(tuple(t.shape))
+            pos += t.numel()
+    return {name: result[name] for name in outputs}

@@ -13,28 +13,6 @@ def always_emulator(state: FortranState, emulator: FortranState):
     return emulator
 
 
-def _download(outputs):
-    """Device outputs -> numpy, one device-to-host copy (one synchronisation) per dtype instead of one per array: at the
-    column counts of one rank the copies' fixed cost, not their size, is what a hook call spends its time on."""
-    import torch
-
-    result = {name: t for name, t in outputs.items() if not (hasattr(t, "is_cuda") and t.is_cuda)}
-    by_dtype = {}
-    for name, t in outputs.items():
-        if name not in result:
-            by_dtype.setdefault(t.dtype, []).append((name, t))
-    for dtype, items in by_dtype.items():
-        if len(items) == 1:
-            result[items[0][0]] = items[0][1].cpu().numpy()
-            continue
-        flat = torch.cat([t.reshape(-1) for _, t in items]).cpu().numpy()
-        pos = 0
-        for name, t in items:
-            result[name] = flat[pos:pos + t.numel()].reshape(tuple(t.shape))
-            pos += t.numel()
-    return {name: result[name] for name in outputs}
-
-
 class MicrophysicsHook:
     """Object that applies a ML model to the fortran state."""
 
@@ -65,7 +43,7 @@ class MicrophysicsHook:
         every mask run on the device, and only the final outputs come back: one PCIe round trip per
         call instead of one per mask."""
         if getattr(self.model, "device_resident", False):
-            from ..cubedsphere._device import on_device
+            from ..cubedsphere._device import download_all, on_device
 
             dev_state = {name: on_device(v) if isinstance(v, np.ndarray) else v for name, v in state.items()}
             inputs = {name: v.t() if v.dim() == 2 else v for name, v in dev_state.items() if hasattr(v, "dim")}
@@ -73,7 +51,7 @@ class MicrophysicsHook:
             # numpy's .T: reverse all axes ([sample, z, class] logits -> [class, z, sample])
             model_outputs = {name: t.permute(*reversed(range(t.dim()))) for name, t in predictions.items()}
             model_outputs.update(self.mask(dev_state, model_outputs))
-            state.update(_download(model_outputs))
+            state.update(download_all(model_outputs))
             self._maybe_garbage_collect()
             return
         inputs = {name: state[name].T for name in state if hasattr(state[name], "T")}

@@ -19,7 +19,7 @@ import numpy as np
 import torch
 import yaml
 
-from ..cubedsphere._device import compute_device, on_device
+from ..cubedsphere._device import compute_device, download_all, on_device
 from ..mlp import InputSpec, MlpModel, MlpSpec, OutputSpec
 from ..xr_compat import DataArray, Dataset, from_compat, to_compat
 from . import io
@@ -100,16 +100,18 @@ class HipDenseModel(Predictor):
         nfeat_out = {o.name: o.nfeat for o in self.spec.outputs}
         for r in self.spec.residuals:
             nfeat_out[r.name] = nfeat_out[r.output]
+        shaped, dims_of = {}, {}
         for name in self.output_variables:
             t = outs[name]
             if nfeat_out[name] == 1:
-                data, dims = t.reshape([sizes[d] for d in sample_dims]), tuple(sample_dims)
+                shaped[name], dims_of[name] = t.reshape([sizes[d] for d in sample_dims]), tuple(sample_dims)
             else:
-                data = t.reshape([nfeat_out[name]] + [sizes[d] for d in sample_dims])
-                dims = (zname,) + tuple(sample_dims)
-            if not (isinstance(host_input, torch.Tensor) and host_input.is_cuda):
-                data = data.cpu().numpy()
-            result[name] = DataArray(data, dims=dims)
+                shaped[name] = t.reshape([nfeat_out[name]] + [sizes[d] for d in sample_dims])
+                dims_of[name] = (zname,) + tuple(sample_dims)
+        if not (isinstance(host_input, torch.Tensor) and host_input.is_cuda):
+            shaped = download_all(shaped)  # host data in -> host data out, one copy for all outputs
+        for name in self.output_variables:
+            result[name] = DataArray(shaped[name], dims=dims_of[name])
         return from_compat(match_prediction_to_input_coords(x, result), X)
 
     # -- serialisation ----------------------------------------------------------------------
