@@ -78,7 +78,12 @@ def zc_spec(seed=0):
     """Random-init weights of the reference architecture; normalisation fitted on a sample the
     way MicrophysicsConfig does (center per feature, one std over all features)."""
     from fv3net_amd.mlp import InputSpec, MlpSpec, OutputSpec
-    from oracle import mlp_np
+
+    def fit_mean_per_feature(data):  # MeanMethod.per_feature (emulation/layers/normalization.py:117-128)
+        return data.mean(axis=0).astype(np.float32)
+
+    def fit_std_all(data):  # StdDevMethod.all: one standard deviation over all features, centred per feature
+        return np.sqrt(np.mean((data - data.mean(axis=0).astype(np.float32)) ** 2)).astype(np.float32)
 
     rng = np.random.default_rng(seed)
     sample = zc_inputs_numpy(rng, 4096)
@@ -89,11 +94,10 @@ def zc_spec(seed=0):
             source, eps = LOG_FIELDS[name]
             data = np.log(np.maximum(sample[source], np.float32(eps)))
             inputs.append(InputSpec(source, NZ, transform="log", eps=eps,
-                                    center=mlp_np.fit_mean_per_feature(data), scale=mlp_np.fit_std_all(data)))
+                                    center=fit_mean_per_feature(data), scale=fit_std_all(data)))
         else:
             data = sample[name]
-            inputs.append(InputSpec(name, NZ, center=mlp_np.fit_mean_per_feature(data),
-                                    scale=mlp_np.fit_std_all(data)))
+            inputs.append(InputSpec(name, NZ, center=fit_mean_per_feature(data), scale=fit_std_all(data)))
     k, w = NZ * len(inputs), 256
     f = sum(OUTPUTS.values())
     glorot = lambda a, b: rng.uniform(-1, 1, (a, b)).astype(np.float32) * np.float32(np.sqrt(6.0 / (a + b)))
