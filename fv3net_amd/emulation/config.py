@@ -3,9 +3,9 @@ at ``path`` in the ``HipEmulator`` format plus the reference's post-processing o
 level masks, cloud squashing and the Zhao-Carr conservation fixes -- composed in the reference's
 order (config.py:175-221) and run on the device.  ``path`` / ``classifier_path`` name saved "dense" or
 "dense-local" emulators (``models.load_emulator``); their tensor transforms are part of the saved
-model, as they are part of the reference's SavedModel graph.  Config-level tensor transforms, the
-online schedule and the zarr monitor are not part of this build and are rejected loudly rather than
-silently ignored."""
+model, as they are part of the reference's SavedModel graph.  Config-level tensor transforms and the
+online schedule are not part of this build and are rejected loudly rather than silently ignored; a ``storage``
+section (the zarr / netCDF monitor) is accepted with a warning and its hook does nothing."""
 import dataclasses
 import logging
 from typing import Dict, Iterable, Mapping, Optional
@@ -160,7 +160,12 @@ class EmulationConfig:
         if unknown:
             raise ValueError(f"unknown zhao_carr_emulation keys: {unknown}")
         if dict_.get("storage"):
-            raise NotImplementedError("the storage hook (zarr/netCDF monitor) is outside this build")
+            # the reference's production configs carry a `storage` section (projects/microphysics/configs/*.yaml); its
+            # zarr / netCDF monitor (emulation/_monitor) needs writers this build does not have.  Refusing the whole
+            # configuration would stop the model run over a diagnostic; the emulation hooks are built and the store hook
+            # does nothing -- loudly.
+            logger.warning("zhao_carr_emulation.storage is configured, but this build has no zarr / netCDF monitor: "
+                           "the `store` hook does nothing and the microphysics state is NOT saved.")
         return EmulationConfig(
             model=ModelConfig.from_dict(dict_["model"]) if dict_.get("model") else None,
             gscond=ModelConfig.from_dict(dict_["gscond"]) if dict_.get("gscond") else None,

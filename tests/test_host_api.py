@@ -173,6 +173,25 @@ def test_emulation_config(tmp_path):
                                                "mask_emulator_levels": {"air_temperature_after_precpd": {"start": 74}}}})
     # the reference's composition order (config.py:178-221): range, squash x2, conservation, level mask
     assert len(list(cfg.model._build_masks())) == 5
+    # the reference's production configs carry a storage section: accepted with a warning, its hook does nothing
+    import logging
+
+    class _Catch(logging.Handler):
+        def __init__(self):
+            super().__init__()
+            self.messages = []
+
+        def emit(self, record):
+            self.messages.append(record.getMessage())
+
+    catch = _Catch()
+    logging.getLogger("emulation").addHandler(catch)
+    try:
+        cfg2 = EmulationConfig.from_dict({"storage": {"output_freq_sec": 10800, "save_zarr": True}})
+    finally:
+        logging.getLogger("emulation").removeHandler(catch)
+    assert any("NOT saved" in m for m in catch.messages)
+    assert cfg2.build_storage_hook()({"a": np.zeros(3)}) is None
     with pytest.raises(ValueError, match="mutually exclusive"):
         EmulationConfig.from_dict({"model": {"enforce_conservative": True, "enforce_conservative_phase_dependent": True}})
     with pytest.raises(ValueError, match="unknown"):
