@@ -3,8 +3,7 @@ at ``path`` in the ``HipEmulator`` format plus the reference's post-processing o
 level masks, cloud squashing and the Zhao-Carr conservation fixes -- composed in the reference's
 order (config.py:175-221) and run on the device.  ``path`` / ``classifier_path`` name saved "dense" or
 "dense-local" emulators (``models.load_emulator``); their tensor transforms are part of the saved
-model, as they are part of the reference's SavedModel graph.  Config-level tensor transforms and the
-online schedule are not part of this build and are rejected loudly rather than silently ignored; a ``storage``
+model, as they are part of the reference's SavedModel graph.  Config-level tensor transforms are not part of this build and are rejected loudly rather than silently ignored; a ``storage``
 section (the zarr / netCDF monitor) is accepted with a warning and its hook does nothing."""
 import dataclasses
 import logging
@@ -16,10 +15,11 @@ from . import zhao_carr
 from .hook import MicrophysicsHook
 from .masks import LevelMask, Mask, RangeMask, compose_masks
 from .models import combine_classifier_and_regressor, load_emulator
+from .schedule import IntervalSchedule, TimeMask
 
 logger = logging.getLogger("emulation")
 
-_UNIMPLEMENTED = ("tensor_transform", "online_schedule")
+_UNIMPLEMENTED = ("tensor_transform",)
 _FLAGS = (
     "gscond_cloud_conservative", "mask_gscond_identical_cloud", "mask_gscond_zero_cloud", "enforce_conservative",
     "enforce_conservative_phase_dependent", "mask_gscond_zero_cloud_classifier", "mask_gscond_no_tend_classifier",
@@ -52,6 +52,7 @@ class ModelConfig:
 
     path: Optional[str] = None
     classifier_path: Optional[str] = None
+    online_schedule: Optional[object] = None  # IntervalSchedule, or any callable time -> weight of the Fortran physics
     ranges: Mapping[str, Range] = dataclasses.field(default_factory=dict)
     mask_emulator_levels: Mapping[str, LevelSlice] = dataclasses.field(default_factory=dict)
     cloud_squash: Optional[float] = None
@@ -87,6 +88,8 @@ class ModelConfig:
             kwargs["cloud_squash"] = float(d["cloud_squash"])
         kwargs["ranges"] = {k: Range(**v) for k, v in (d.get("ranges") or {}).items()}
         kwargs["mask_emulator_levels"] = {k: LevelSlice(**v) for k, v in (d.get("mask_emulator_levels") or {}).items()}
+        if d.get("online_schedule"):
+            kwargs["online_schedule"] = IntervalSchedule.from_dict(d["online_schedule"])
         return ModelConfig(path=d.get("path"), classifier_path=d.get("classifier_path"), batch_size=int(d.get("batch_size", 512)), **kwargs)
 
     def build(self) -> MicrophysicsHook:
@@ -103,7 +106,9 @@ class ModelConfig:
         return compose_masks(self._build_masks())
 
     def _build_masks(self) -> Iterable[Mask]:
-        """The reference's order (config.py:178-221)."""
+        """The reference's order (config.py:175-221)."""
+        if self.online_schedule:
+            yield TimeMask(self.online_schedule)
         for key, rng in self.ranges.items():
             yield RangeMask(key, min=rng.min, max=rng.max)
         if self.gscond_cloud_conservative:

@@ -1,5 +1,5 @@
 """Generic masks applied to the emulator outputs (external/emulation/emulation/masks.py:1-76), on the
-device.  ``TimeMask`` (online schedule) is host logic and not part of this build."""
+device.  ``TimeMask`` (the online schedule) lives in ``schedule.py``."""
 from typing import Callable, Iterable, Optional, Union
 
 import torch

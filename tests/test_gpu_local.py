@@ -281,3 +281,34 @@ def test_production_style_fv3config_both_hooks(tmp_path):
         if isinstance(v, np.ndarray):
             np.testing.assert_array_equal(state[k], v)
     assert store(state) is None
+
+
+def test_online_schedule_switches_between_physics_and_emulator(tmp_path):
+    """ModelConfig.online_schedule (config.py:83-88, 176-177): in the first half of every period the Fortran physics'
+    own values are kept for the keys the emulator also produces, in the second half the emulator's."""
+    import datetime
+
+    from fv3net_amd.emulation.config import ModelConfig
+    from fv3net_amd.emulation.models import HipLocalEmulator
+
+    rng = np.random.default_rng(17)
+    nz, ncol = 11, 96
+    st = cases.state(rng, nz, ncol)
+    spec = cases.regressor(rng, st, nz, make=cases.product_makers())
+    spec.outputs[0].after, spec.outputs[1].after = E.QV_G, E.T_G
+    HipLocalEmulator(spec).dump(str(tmp_path / "reg"))
+    hook = ModelConfig.from_dict({"path": str(tmp_path / "reg"), "online_schedule": {
+        "period": 7200, "initial_time": datetime.datetime(2016, 8, 1)}}).build()
+    truth = mlp_np.forward_local(spec, {k: v.T for k, v in st.items()}, dtype=np.float64)
+    fortran = {E.QV_G: st[cases.QV_IN] * 0.99, E.T_G: st[cases.T_IN] + 0.25}
+    for minute, emulated in ((30, False), (90, True)):
+        state = {**{k: v.copy() for k, v in st.items()}, **{k: v.copy() for k, v in fortran.items()}}
+        state["model_time"] = [2016, 8, 1, 0, minute // 60, minute % 60]
+        hook.microphysics(state)
+        for name in (E.QV_G, E.T_G):
+            if emulated:
+                _check(state[name], truth[name].T, name)
+            else:
+                np.testing.assert_array_equal(state[name], fortran[name])
+        # outputs the Fortran state does not hold come from the emulator either way
+        _check(state["humidity_gscond_difference"], truth["humidity_gscond_difference"].T, "humidity_gscond_difference")

@@ -165,8 +165,8 @@ def test_emulation_config(tmp_path):
     gscond, micro, store = get_hooks(str(tmp_path / "missing.yml"))
     state = {"a": np.zeros(3)}
     assert micro(state) is None and gscond(state) is None and store(state) is None and list(state) == ["a"]
-    with pytest.raises(NotImplementedError, match="online_schedule"):
-        EmulationConfig.from_dict({"model": {"path": "x", "online_schedule": {"period": 3600}}})
+    with pytest.raises(NotImplementedError, match="tensor_transform"):
+        EmulationConfig.from_dict({"model": {"path": "x", "tensor_transform": [{"to": "a", "source": "b"}]}})
     assert EmulationConfig.from_dict({"model": {"path": "x", "classifier_path": "y"}}).model.classifier_path == "y"
     cfg = EmulationConfig.from_dict({"model": {"path": "x", "cloud_squash": 1e-6, "enforce_conservative": True,
                                                "ranges": {"total_precipitation": {"min": 0}},
@@ -227,3 +227,41 @@ def test_every_module_imports_on_its_own():
     code = "import importlib, sys\nfor m in sys.argv[1:]:\n    for k in [k for k in sys.modules if k.startswith('fv3net_amd')]:\n        del sys.modules[k]\n    importlib.import_module(m)\n"
     res = subprocess.run([sys.executable, "-c", code, *mods], capture_output=True, text=True, cwd=os.path.dirname(os.path.dirname(__file__)))
     assert res.returncode == 0, res.stderr[-2000:]
+
+
+def test_interval_schedule_and_time_mask_known_answers():
+    """external/emulation/tests/test_microphysics.py:47-66 and test_config.py:16-55 (cftime.DatetimeJulian there:
+    plain (year, month, day, hour, minute, second) tuples or datetimes here)."""
+    import datetime
+
+    from fv3net_amd.emulation.config import EmulationConfig, ModelConfig
+    from fv3net_amd.emulation.schedule import IntervalSchedule, TimeMask, julian_seconds
+
+    scheduler = IntervalSchedule(datetime.timedelta(hours=3), (2000, 1, 1))
+    assert scheduler((2000, 1, 1)) == 1
+    assert scheduler((2000, 1, 1, 1)) == 1
+    assert scheduler((2000, 1, 1, 1, 30)) == 0
+    assert scheduler((2000, 1, 1, 2)) == 0
+    assert scheduler((2000, 1, 20)) == 1
+    assert scheduler(datetime.datetime(2000, 1, 1, 1, 30)) == 0
+    # Julian calendar: 1900 is a leap year there (not in the Gregorian one); day numbers are consecutive
+    assert julian_seconds((1900, 3, 1)) - julian_seconds((1900, 2, 28)) == 2 * 86400
+    assert julian_seconds((2001, 1, 1)) - julian_seconds((2000, 1, 1)) == 366 * 86400
+    for weight in (0.0, 0.5, 1.0):
+        mask = TimeMask(schedule=lambda time: weight)
+        assert mask({"a": 0.0, "model_time": [2021, 1, 1, 0, 0, 0]}, {"a": 1.0}) == {"a": 1 - weight}
+    config = EmulationConfig.from_dict({"model": {"path": "some-path", "online_schedule": {
+        "period": 60, "initial_time": datetime.datetime(2000, 2, 1)}}})
+    assert config.model.online_schedule.period == datetime.timedelta(seconds=60)
+    assert config.model.online_schedule.initial_time.month == 2
+    assert len(list(ModelConfig(path="")._build_masks())) == 0
+
+    def schedule(time):
+        return 1.0
+
+    time_masks = [m for m in ModelConfig(path="", online_schedule=schedule)._build_masks() if isinstance(m, TimeMask)]
+    assert time_masks[0].schedule == schedule
+    # the model's time tuple: fields 0, 1, 2, 4, 5 (_time.py:6-12)
+    mask = TimeMask(IntervalSchedule(datetime.timedelta(hours=2), (2016, 8, 1)))
+    assert mask({"a": 5.0, "model_time": [2016, 8, 1, 0, 0, 30]}, {"a": 1.0}) == {"a": 5.0}   # 00:30 -> first half: physics
+    assert mask({"a": 5.0, "model_time": [2016, 8, 1, 0, 1, 30]}, {"a": 1.0}) == {"a": 1.0}   # 01:30 -> second half: emulator
