@@ -538,7 +538,11 @@ def main():
             },
         }
         if world == 1 and not args.no_cpu:
-            line["cpu_baseline"] = cpu_baseline(spec)
+            try:
+                line["cpu_baseline"] = cpu_baseline(spec)
+            except Exception as err:  # noqa: BLE001
+                line["cpu_baseline"] = {"value": None, "unit": "columns/s", "cores": os.cpu_count(), "kind": "port",
+                                        "sample": f"failed: {type(err).__name__}: {err}"}
         if world == 1 and not args.no_secondary:
             del src
             torch.cuda.empty_cache()
