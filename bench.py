@@ -142,6 +142,17 @@ def pmc_traffic(kernel_key):
         return None
 
 
+def pmc_valu(kernel_key):
+    """VALU issue-bound fraction of a remap kernel from the committed PMC passes (profiles/r01_pmc_mappm_valu.json), a
+    recorded measurement like ``pmc_traffic``; None if absent."""
+    path = os.path.join(os.path.dirname(os.path.abspath(__file__)), "profiles", "r01_pmc_mappm_valu.json")
+    try:
+        with open(path) as f:
+            return json.load(f)["kernels"][kernel_key]["valu_issue_bound_fraction"]
+    except (OSError, KeyError, ValueError):
+        return None
+
+
 def cpu_baseline(spec, budget_s=15.0):
     """The oracle (numpy float32, [sample, feature]) on a bounded sample of the same workload."""
     from oracle import mlp_np
@@ -235,7 +246,9 @@ def secondary_benchmarks(dev, steps):
             "kernel": "mappm", "workload": f"C384 884736 columns, km=kn=79, iv=1 kord=1, [tile,z,y,x] f32, {label}",
             "ms": ms, "columns_per_s": ncol / ms * 1e3,
             "roofline": {"bound": "hbm", "achieved": alg_bytes / ms / 1e6, "peak": PEAK_HBM_GBPS, "unit": "GB/s",
-                         "frac": alg_bytes / ms / 1e6 / PEAK_HBM_GBPS, "traffic": None},
+                         "frac": alg_bytes / ms / 1e6 / PEAK_HBM_GBPS, "traffic": None,
+                         "note": "VALU-issue-bound (bit-exact IEEE divisions): see valu_issue_bound_frac",
+                         "valu_issue_bound_frac": pmc_valu("mappm_merge_kernel<float>")},
         })
     # the same remap for 4 fields that share their pressures (one fv_core / tracer group of the pipeline)
     qs = [q] + [torch.rand((6, NZ, n, n), device=dev, generator=g) * 2000 - 1000 for _ in range(3)]
@@ -249,7 +262,8 @@ def secondary_benchmarks(dev, steps):
         "kernel": "mappm_multi (4 fields per sweep)", "workload": "C384 884736 columns x 4 fields sharing pe1/pe2, km=kn=79, "
         "iv=1 kord=1, coarse-pressure target (config 3)", "ms": ms, "columns_per_s": 4 * ncol / ms * 1e3,
         "roofline": {"bound": "hbm", "achieved": alg_bytes / ms / 1e6, "peak": PEAK_HBM_GBPS, "unit": "GB/s",
-                     "frac": alg_bytes / ms / 1e6 / PEAK_HBM_GBPS, "traffic": None},
+                     "frac": alg_bytes / ms / 1e6 / PEAK_HBM_GBPS, "traffic": None,
+                     "valu_issue_bound_frac": pmc_valu("mappm_merge_multi_kernel<float,4>")},
     })
     del qs
     # (the secondary workloads never cost the headline line: a failure is recorded in place of the numbers)
