@@ -54,6 +54,15 @@ OUTPUTS = {
     "temperature_gscond_difference": 79,
     "humidity_gscond_difference": 79,
 }
+# Difference.backward (fv3fit/emulation/transforms/transforms.py:54-58; projects/microphysics/train/dense.yaml:22-36):
+# after = before + difference -- the five fields the Fortran model reads back from the hook
+RESIDUALS = {
+    "air_temperature_after_gscond": ("air_temperature_input", "temperature_gscond_difference"),
+    "specific_humidity_after_gscond": ("specific_humidity_input", "humidity_gscond_difference"),
+    "cloud_water_mixing_ratio_after_precpd": ("cloud_water_mixing_ratio_input", "cloud_precpd_difference"),
+    "air_temperature_after_precpd": ("air_temperature_input", "temperature_precpd_difference"),
+    "specific_humidity_after_precpd": ("specific_humidity_input", "humidity_precpd_difference"),
+}
 NZ = 79
 
 
@@ -74,10 +83,12 @@ def zc_inputs_numpy(rng, n):
     return {k: v.astype(np.float32) for k, v in src.items()}
 
 
-def zc_spec(seed=0):
+def zc_spec(seed=0, residuals=True):
     """Random-init weights of the reference architecture; normalisation fitted on a sample the
-    way MicrophysicsConfig does (center per feature, one std over all features)."""
-    from fv3net_amd.mlp import InputSpec, MlpSpec, OutputSpec
+    way MicrophysicsConfig does (center per feature, one std over all features).  ``residuals``: the
+    production graph of dense.yaml, whose five difference outputs also leave as ``after = before +
+    difference`` (396 + 395 output rows); False: the 396 direct outputs only."""
+    from fv3net_amd.mlp import InputSpec, MlpSpec, OutputSpec, ResidualSpec
 
     def fit_mean_per_feature(data):  # MeanMethod.per_feature (emulation/layers/normalization.py:117-128)
         return data.mean(axis=0).astype(np.float32)
@@ -109,7 +120,26 @@ def zc_spec(seed=0):
                  for n_, nf in OUTPUTS.items()],
         out_kernel=glorot(w, f),
         out_bias=rng.normal(0, 0.01, f).astype(np.float32),
+        residuals=[ResidualSpec(name, before, diff) for name, (before, diff) in RESIDUALS.items()] if residuals else [],
     )
+
+
+def parity_max_rel(model, spec, src, n=4096):
+    """max over the output variables of max|gpu - truth| / max|truth| on the first ``n`` columns of the timed
+    inputs: the timed model object (same kernel instantiation: the slice keeps unit sample stride and 16-byte
+    alignment) against the float64 oracle.  Returns (value, variant the slice launched)."""
+    from oracle import mlp_np
+
+    part = {k: v[:, :n] for k, v in src.items()}
+    got = model.predict(part)
+    variant = model.last_variant
+    host = {k: v.T.contiguous().cpu().numpy() for k, v in part.items()}
+    truth = mlp_np.forward(spec, host, dtype=np.float64)
+    worst = 0.0
+    for name, t in truth.items():
+        g = got[name].cpu().numpy().T
+        worst = max(worst, float(np.max(np.abs(g - t)) / np.max(np.abs(t))))
+    return worst, variant
 
 
 def zc_inputs_device(dev, n, seed):
@@ -129,17 +159,24 @@ def zc_inputs_device(dev, n, seed):
     }
 
 
+PMC_TRAFFIC_FILES = ("r02_pmc_traffic.json", "r01_pmc_traffic.json")
+
+
 def pmc_traffic(kernel_key):
-    """HBM bytes per launch from the committed PMC passes (profiles/r01_pmc_traffic.json: rocprofv3
-    --pmc FETCH_SIZE / WRITE_SIZE in separate runs of this script, FETCH_SIZE corrected as
-    MI355X_MICROARCH.md prescribes for gfx950) -- a recorded measurement of the same launch, not
-    collected live; None where the counters are uncalibrated or the file is absent."""
-    path = os.path.join(os.path.dirname(os.path.abspath(__file__)), "profiles", "r01_pmc_traffic.json")
-    try:
-        with open(path) as f:
-            return json.load(f)["kernels"][kernel_key]["traffic_bytes_per_launch"]
-    except (OSError, KeyError, ValueError):
-        return None
+    """(HBM bytes per launch, where the figure comes from) for the kernel named ``kernel_key`` -- the name the
+    library reports for the launch it made (``fv3hip_mlp_last_variant``), so a changed dispatch finds no entry.  The
+    figure is a RECORDED measurement of the same launch (profiles/r0N_pmc_traffic.json: rocprofv3 --pmc FETCH_SIZE /
+    WRITE_SIZE in separate runs of this script, FETCH_SIZE corrected as MI355X_MICROARCH.md prescribes for gfx950),
+    not collected in this run; (None, reason) where absent or uncalibrated."""
+    for name in PMC_TRAFFIC_FILES:
+        path = os.path.join(ROOT, "profiles", name)
+        try:
+            with open(path) as f:
+                value = json.load(f)["kernels"][kernel_key]["traffic_bytes_per_launch"]
+        except (OSError, KeyError, ValueError):
+            continue
+        return value, f"recorded: profiles/{name} (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of this script), not measured in this run"
+    return None, f"no recorded PMC pass for {kernel_key!r}"
 
 
 def pmc_valu(kernel_key):
@@ -153,33 +190,102 @@ def pmc_valu(kernel_key):
         return None
 
 
-def cpu_baseline(spec, budget_s=15.0):
-    """The oracle (numpy float32, [sample, feature]) on a bounded sample of the same workload."""
-    from oracle import mlp_np
-
-    try:
-        from threadpoolctl import threadpool_info
-
-        threads = max([p.get("num_threads", 1) for p in threadpool_info()] or [1])
-    except Exception:
-        threads = os.cpu_count() or 1
-    n = 16384
-    src = zc_inputs_numpy(np.random.default_rng(1), n)
-    mlp_np.forward(spec, src)  # warm
+def _timed_reps(fn, budget_s, max_reps=100):
+    fn()  # warm
     t0, reps = time.perf_counter(), 0
     while True:
-        mlp_np.forward(spec, src)
+        fn()
         reps += 1
-        if time.perf_counter() - t0 > budget_s or reps >= 100:
+        if time.perf_counter() - t0 > budget_s or reps >= max_reps:
             break
-    dt = time.perf_counter() - t0
-    return {
+    return reps, time.perf_counter() - t0
+
+
+def cpu_baseline(spec, budget_s=6.0):
+    """The oracle on bounded samples of the same workloads, on this box's host cores (rank 0, N = 1 only; a reported
+    baseline, not a target).  Headline entry: the numpy float32 restatement of the network with all BLAS threads;
+    ``others``: the same single-threaded, and the two coarse-graining kernels: numpy
+    ``weighted_block_average`` on one C384 field and the C port of ``mappm`` (and, when the compiled reference Fortran
+    travelled with the repo, that too) on a column sample, single-threaded and over a thread pool."""
+    from concurrent.futures import ThreadPoolExecutor
+
+    from oracle import coarsen_np, mappm_c, mlp_np
+
+    cores = os.cpu_count() or 1
+    try:
+        from threadpoolctl import threadpool_info, threadpool_limits
+
+        blas_threads = max([p.get("num_threads", 1) for p in threadpool_info()] or [1])
+    except Exception:
+        threadpool_limits, blas_threads = None, cores
+    n = 16384
+    src = zc_inputs_numpy(np.random.default_rng(1), n)
+    reps, dt = _timed_reps(lambda: mlp_np.forward(spec, src), budget_s)
+    out = {
         "value": n * reps / dt,
         "unit": "columns/s",
-        "cores": int(threads),
+        "cores": int(cores),
+        "threads": int(blas_threads),
         "kind": "port",
-        "sample": f"{reps} passes over {n} of the 884736 C384 columns, numpy float32 oracle (BLAS threads = {threads})",
+        "sample": f"{reps} passes over {n} of the 884736 C384 columns, numpy float32 oracle of the same network "
+                  f"(BLAS threads = {blas_threads} on {cores} host cores)",
+        "others": [],
     }
+    others = out["others"]
+    try:
+        if threadpool_limits is not None:
+            n1 = 4096
+            src1 = {k: v[:n1] for k, v in src.items()}
+            with threadpool_limits(limits=1):
+                reps, dt = _timed_reps(lambda: mlp_np.forward(spec, src1), budget_s / 2)
+            others.append({"workload": "MLP, single thread", "value": n1 * reps / dt, "unit": "columns/s", "threads": 1,
+                           "kind": "port", "sample": f"{reps} passes over {n1} columns, numpy float32, BLAS limited to 1 thread"})
+    except Exception as err:  # noqa: BLE001
+        others.append({"workload": "MLP, single thread", "error": f"{type(err).__name__}: {err}"})
+    pool_threads = min(cores, 32)
+    try:  # weighted_block_average, one C384 -> C48 field (config 3), float32, 2-D area weights
+        rng = np.random.default_rng(2)
+        obj = rng.uniform(-1000, 1000, (6, NZ, 384, 384)).astype(np.float32)
+        area = rng.uniform(0.5, 1, (6, 1, 384, 384)).astype(np.float32)
+        alg = 4 * obj.size * (1 + 1 / 64) + 4 * obj.size / NZ
+        reps, dt = _timed_reps(lambda: coarsen_np.weighted_block_average(obj, area, 8), budget_s / 2, 20)
+        others.append({"workload": "weighted_block_average C384->C48, one [6,79,384,384] f32 field, single thread",
+                       "value": alg * reps / dt / 1e9, "unit": "GB/s (algorithmic)", "threads": 1, "kind": "port",
+                       "ms": dt / reps * 1e3, "sample": f"{reps} passes, numpy reshape-sum oracle"})
+        parts = [(t, z0) for t in range(6) for z0 in range(0, NZ, 10)]
+        with ThreadPoolExecutor(pool_threads) as ex:
+            run = lambda: list(ex.map(lambda tz: coarsen_np.weighted_block_average(
+                obj[tz[0], tz[1]:tz[1] + 10], area[tz[0]], 8), parts))
+            reps, dt = _timed_reps(run, budget_s / 2, 50)
+        others.append({"workload": f"weighted_block_average C384->C48, the same field over a pool of {pool_threads} threads",
+                       "value": alg * reps / dt / 1e9, "unit": "GB/s (algorithmic)", "threads": pool_threads, "kind": "port",
+                       "ms": dt / reps * 1e3, "sample": f"{reps} passes, {len(parts)} (tile, 10-level) pieces"})
+        del obj, area
+    except Exception as err:  # noqa: BLE001
+        others.append({"workload": "weighted_block_average", "error": f"{type(err).__name__}: {err}"})
+    try:  # mappm, km = kn = 79, [column, level] as the f2py module takes them
+        rng = np.random.default_rng(3)
+        ncol = 65536
+        pe1 = np.concatenate([np.full((ncol, 1), 300.0), 300 + np.cumsum(rng.uniform(300, 1500, (ncol, NZ)), 1)], 1).astype(np.float32)
+        pe2 = np.concatenate([np.full((ncol, 1), 300.0), 300 + np.cumsum(rng.uniform(300, 1500, (ncol, NZ)), 1)], 1).astype(np.float32)
+        q = rng.uniform(-1000, 1000, (ncol, NZ)).astype(np.float32)
+        impls = [("port", "C restatement of mappm.f90 (-O2)", mappm_c.mappm)]
+        if mappm_c.have_reference():
+            impls.append(("reference", "the reference's own mappm.f90 compiled with amdflang -O2 (oracle/_ref)", mappm_c.reference_mappm))
+        for kind, what, fn in impls:
+            reps, dt = _timed_reps(lambda: fn(pe1, q, pe2), budget_s / 4, 20)
+            others.append({"workload": f"mappm iv=1 kord=1 km=kn=79, single thread: {what}", "value": ncol * reps / dt,
+                           "unit": "columns/s", "threads": 1, "kind": kind, "sample": f"{reps} passes over {ncol} of the 884736 C384 columns"})
+            pieces = [slice(i, i + 2048) for i in range(0, ncol, 2048)]
+            with ThreadPoolExecutor(pool_threads) as ex:
+                run = lambda: list(ex.map(lambda sl: fn(pe1[sl], q[sl], pe2[sl]), pieces))
+                reps, dt = _timed_reps(run, budget_s / 4, 50)
+            others.append({"workload": f"mappm, pool of {pool_threads} threads: {what}", "value": ncol * reps / dt,
+                           "unit": "columns/s", "threads": pool_threads, "kind": kind,
+                           "sample": f"{reps} passes over {ncol} columns in pieces of 2048"})
+    except Exception as err:  # noqa: BLE001
+        others.append({"workload": "mappm", "error": f"{type(err).__name__}: {err}"})
+    return out
 
 
 def time_kernel(fn, steps, dev):
@@ -198,6 +304,26 @@ def secondary_benchmarks(dev, steps):
     from fv3net_amd import ops
 
     out = []
+    try:  # the headline network without its residual outputs (the round-1 headline): 396 output rows, "plain" epilogue
+        from fv3net_amd.mlp import MlpModel
+
+        ncol = 6 * 384 * 384
+        model = MlpModel(zc_spec(0, residuals=False), device=dev)
+        src = zc_inputs_device(dev, ncol, seed=1000)
+        fn = lambda: model.predict(src)
+        fn()
+        torch.cuda.synchronize(dev)
+        ms = time_kernel(fn, max(3, min(steps, 20)), dev)
+        achieved = model.flops_per_sample * ncol / (ms * 1e-3) / 1e12
+        out.append({"kernel": model.last_variant, "workload": "the headline network with its 396 direct outputs only (no Difference residuals)",
+                    "ms": ms, "columns_per_s": ncol / ms * 1e3,
+                    "roofline": {"bound": "mfma", "achieved": achieved, "peak": PEAK_FP32_MFMA_TFLOPS, "unit": "TFLOP/s",
+                                 "frac": achieved / PEAK_FP32_MFMA_TFLOPS, "traffic": pmc_traffic("mlp_fused_kernel<8,false,true,false,false,false>")[0],
+                                 "traffic_source": pmc_traffic("mlp_fused_kernel<8,false,true,false,false,false>")[1]}})
+        del model, src
+    except Exception as err:  # noqa: BLE001
+        out.append({"kernel": "mlp_fused_kernel plain", "error": f"{type(err).__name__}: {err}"})
+    torch.cuda.empty_cache()
     g = torch.Generator(device=dev).manual_seed(0)
     # C3072 -> C384 (f = 8) weighted_block_average of one 3-D float32 field, 2-D area weights
     for label, n, tiles in (("C3072->C384", 3072, 6), ("C384->C48", 384, 6)):
@@ -214,7 +340,8 @@ def secondary_benchmarks(dev, steps):
                 "kernel": "weighted_block_average", "workload": f"{label} f=8, one [6,79,{n},{n}] f32 field, 2-D area weights",
                 "ms": ms, "roofline": {"bound": "hbm", "achieved": alg_bytes / ms / 1e6, "peak": PEAK_HBM_GBPS,
                                        "unit": "GB/s", "frac": alg_bytes / ms / 1e6 / PEAK_HBM_GBPS,
-                                       "traffic": pmc_traffic("wavg_block_kernel<float,float,8> C3072->C384") if n == 3072 else None},
+                                       "traffic": pmc_traffic("wavg_block_kernel<float,float,8> C3072->C384")[0] if n == 3072 else None,
+                                       "traffic_source": pmc_traffic("wavg_block_kernel<float,float,8> C3072->C384")[1] if n == 3072 else None},
             })
             del obj, area
         except torch.cuda.OutOfMemoryError:
@@ -276,27 +403,31 @@ def secondary_benchmarks(dev, steps):
     return out
 
 
-def restart_pipeline_benchmark(dev, n=384, f=8, reps=3):
+def restart_pipeline_benchmark(dev, n=384, f=8, reps=3, tiles=tuple(range(6)), which=("sigma", "pressure", "blended"), sync=None):
     """BASELINE configs[2] end to end: the three restart coarse-graining pipelines (vcm coarsen_restarts_on_sigma /
     _on_pressure / _via_blended_method, all four restart categories, 'complex' surface method) C384 -> C48 on float64
-    restarts resident in HBM, through the drop-in Python API.  Wall time of a whole pipeline call."""
+    restarts resident in HBM, through the drop-in Python API.  Wall time of a whole pipeline call.  ``tiles``: the cube
+    tiles this rank owns (tile-sharded runs: the halo rows of the D-grid winds' edge pressures then come from the
+    all-gather of parallel.exchange_edge_rows); ``sync``: fence to use instead of a device synchronise (a barrier)."""
     from fv3net_amd.cubedsphere import (coarsen_restarts_on_pressure, coarsen_restarts_on_sigma,
                                         coarsen_restarts_via_blended_method)
     from fv3net_amd.xr_compat import DataArray, Dataset
 
-    g = torch.Generator(device=dev).manual_seed(3)
+    nt = len(tiles)
+    sync = sync or (lambda: torch.cuda.synchronize(dev))
+    g = torch.Generator(device=dev).manual_seed(3 + 17 * int(tiles[0]))
     u = lambda lo, hi, *shape: torch.rand(shape, device=dev, generator=g, dtype=torch.float64) * (hi - lo) + lo
     zc = ["tile", "Time", "zaxis_1", "yaxis_2", "xaxis_1"]
     core = Dataset({
-        "u": DataArray(u(-30, 30, 6, 1, NZ, n + 1, n), dims=["tile", "Time", "zaxis_1", "yaxis_1", "xaxis_1"]),
-        "v": DataArray(u(-30, 30, 6, 1, NZ, n, n + 1), dims=["tile", "Time", "zaxis_1", "yaxis_2", "xaxis_2"]),
-        **{k: DataArray(u(lo, hi, 6, 1, NZ, n, n), dims=zc) for k, (lo, hi) in
+        "u": DataArray(u(-30, 30, nt, 1, NZ, n + 1, n), dims=["tile", "Time", "zaxis_1", "yaxis_1", "xaxis_1"]),
+        "v": DataArray(u(-30, 30, nt, 1, NZ, n, n + 1), dims=["tile", "Time", "zaxis_1", "yaxis_2", "xaxis_2"]),
+        **{k: DataArray(u(lo, hi, nt, 1, NZ, n, n), dims=zc) for k, (lo, hi) in
            {"W": (-1, 1), "T": (200, 300), "delp": (300, 1500), "DZ": (-500, -50), "ua": (-30, 30), "va": (-30, 30)}.items()},
-        "phis": DataArray(u(0, 1e4, 6, 1, n, n), dims=["tile", "Time", "yaxis_2", "xaxis_1"]),
+        "phis": DataArray(u(0, 1e4, nt, 1, n, n), dims=["tile", "Time", "yaxis_2", "xaxis_1"]),
     })
     tracers = ["sphum", "liq_wat", "rainwat", "ice_wat", "snowwat", "graupel", "o3mr", "sgs_tke", "cld_amt"]
-    tracer = Dataset({k: DataArray(u(0, 0.02, 6, 1, NZ, n, n), dims=["tile", "Time", "zaxis_1", "yaxis_1", "xaxis_1"]) for k in tracers})
-    srf = Dataset({k: DataArray(u(-10, 10, 6, 1, n, n), dims=["tile", "Time", "yaxis_1", "xaxis_1"]) for k in ("u_srf", "v_srf")})
+    tracer = Dataset({k: DataArray(u(0, 0.02, nt, 1, NZ, n, n), dims=["tile", "Time", "zaxis_1", "yaxis_1", "xaxis_1"]) for k in tracers})
+    srf = Dataset({k: DataArray(u(-10, 10, nt, 1, n, n), dims=["tile", "Time", "yaxis_1", "xaxis_1"]) for k in ("u_srf", "v_srf")})
     # surface data: the variables, dims and value ranges of the reference's regression schema (tests/golden metadata)
     with np.load(os.path.join(ROOT, "tests", "golden", "coarsen_restarts_reference.npz")) as z:
         meta = json.loads(bytes(z["meta_json"]).decode())
@@ -304,30 +435,33 @@ def restart_pipeline_benchmark(dev, n=384, f=8, reps=3):
     sfc = Dataset()
     for name, info in meta["inputs"]["sfc_data"].items():
         lo, hi = meta["ranges"].get(name, meta["default_range"])
-        shape = list(info["shape"][:-2]) + [n, n]
+        shape = [nt if d == "tile" else sz for d, sz in zip(info["dims"], info["shape"])][:-2] + [n, n]
         sfc[name] = DataArray(torch.from_numpy(rng.uniform(lo, hi, shape).astype(info["dtype"])).to(dev), dims=info["dims"])
-    grid = Dataset({"area": DataArray(u(0.5, 1, 6, n, n).float(), dims=["tile", "grid_yt", "grid_xt"]),
-                    "dx": DataArray(u(0.5, 1, 6, n + 1, n).float(), dims=["tile", "grid_y", "grid_xt"]),
-                    "dy": DataArray(u(0.5, 1, 6, n, n + 1).float(), dims=["tile", "grid_yt", "grid_x"])})
+    grid = Dataset({"area": DataArray(u(0.5, 1, nt, n, n).float(), dims=["tile", "grid_yt", "grid_xt"]),
+                    "dx": DataArray(u(0.5, 1, nt, n + 1, n).float(), dims=["tile", "grid_y", "grid_xt"]),
+                    "dy": DataArray(u(0.5, 1, nt, n, n + 1).float(), dims=["tile", "grid_yt", "grid_x"])})
     restarts = {"fv_core.res": core, "fv_tracer.res": tracer, "fv_srf_wnd.res": srf, "sfc_data": sfc}
     nbytes = sum(v.data.numel() * v.data.element_size() for ds in restarts.values() for v in ds.values())
     out = []
-    for label, fn in (("coarsen_restarts_on_sigma", lambda: coarsen_restarts_on_sigma(f, grid, restarts, coarsen_agrid_winds=True)),
-                      ("coarsen_restarts_on_pressure", lambda: coarsen_restarts_on_pressure(f, grid, 300.0, restarts, coarsen_agrid_winds=True)),
-                      ("coarsen_restarts_via_blended_method",
-                       lambda: coarsen_restarts_via_blended_method(f, grid, 300.0, restarts, coarsen_agrid_winds=True))):
+    fns = {"sigma": ("coarsen_restarts_on_sigma", lambda: coarsen_restarts_on_sigma(f, grid, restarts, coarsen_agrid_winds=True)),
+           "pressure": ("coarsen_restarts_on_pressure", lambda: coarsen_restarts_on_pressure(f, grid, 300.0, restarts, coarsen_agrid_winds=True)),
+           "blended": ("coarsen_restarts_via_blended_method",
+                       lambda: coarsen_restarts_via_blended_method(f, grid, 300.0, restarts, coarsen_agrid_winds=True))}
+    for key in which:
+        label, fn = fns[key]
         fn()
-        torch.cuda.synchronize(dev)
+        sync()
         t0 = time.perf_counter()
         for _ in range(reps):
             fn()
-        torch.cuda.synchronize(dev)
+        sync()
         ms = (time.perf_counter() - t0) / reps * 1e3
         out.append({"kernel": f"{label} (whole pipeline, Python API)",
-                    "workload": f"C{n}->C{n // f}, 4 restart categories, {nbytes / 1e9:.2f} GB of float64 restarts in HBM",
-                    "ms": ms, "roofline": {"bound": "hbm", "achieved": nbytes / ms / 1e6, "peak": PEAK_HBM_GBPS, "unit": "GB/s",
-                                           "frac": nbytes / ms / 1e6 / PEAK_HBM_GBPS, "traffic": None,
-                                           "note": "input bytes / wall time; the pressure-level pipelines are bound by the VALU-limited remap"}})
+                    "workload": f"C{n}->C{n // f}, 4 restart categories, {nt} tile(s), {nbytes / 1e9:.2f} GB of float64 restarts in HBM",
+                    "ms": ms, "bytes": nbytes,
+                    "roofline": {"bound": "hbm", "achieved": nbytes / ms / 1e6, "peak": PEAK_HBM_GBPS, "unit": "GB/s",
+                                 "frac": nbytes / ms / 1e6 / PEAK_HBM_GBPS, "traffic": None,
+                                 "note": "input bytes / wall time"}})
     return out
 
 
@@ -451,6 +585,121 @@ def dense_local_benchmark(dev, steps):
     return out
 
 
+def sharded_secondary_benchmarks(dev, steps, rank, world, rehearsal):
+    """N > 1: the second metric across the GPUs (BASELINE configs[4]).  Every rank takes part (collective).
+      * one C3072 -> C384 float32 field sharded by (tile, row band) over ALL ranks (parallel.tile_bands: 6 tiles x 4 bands on
+        8 GPUs), no data-path collective: per-rank and aggregate algorithmic GB/s against N x 8 TB/s;
+      * the pressure-level restart pipeline C384 -> C48 sharded by whole tiles over min(N, 6) ranks, the edge pressures of
+        the D-grid winds taking their halo rows from the all-gather of parallel.exchange_edge_rows (RCCL over xGMI)."""
+    from fv3net_amd import parallel
+
+    host = torch.device("cpu")
+
+    def reduce_max(x):
+        t = torch.tensor([x], dtype=torch.float64, device=host if rehearsal else dev)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        return float(t.item())
+
+    def fence():
+        torch.cuda.synchronize(dev)
+        dist.barrier()
+        torch.cuda.synchronize(dev)
+
+    out = []
+    try:
+        n = int(os.environ.get("FV3_BENCH_SHARDED_N", "3072"))
+        units = parallel.units_of_rank(6, n, 8, world, rank)
+        g = torch.Generator(device=dev).manual_seed(200 + rank)
+        objs = [torch.rand((NZ, r1 - r0, n), device=dev, generator=g) * 2000 - 1000 for (_, r0, r1) in units]
+        areas = [torch.rand((r1 - r0, n), device=dev, generator=g) * 0.5 + 0.5 for (_, r0, r1) in units]
+        fn = lambda: parallel.weighted_block_average_banded(objs, areas, 8)
+        fn()
+        fence()
+        reps = max(3, min(steps, 10))
+        t0 = time.perf_counter()
+        for _ in range(reps):
+            fn()
+        torch.cuda.synchronize(dev)
+        mine_ms = (time.perf_counter() - t0) / reps * 1e3
+        fence()
+        ms = reduce_max(mine_ms)
+        nel_rank = sum(o.numel() for o in objs)
+        nel = 6 * NZ * n * n
+        alg = lambda e: 4 * e * (1 + 1 / 64) + 4 * e / NZ
+        out.append({
+            "kernel": "weighted_block_average, (tile, row-band) sharded",
+            "workload": f"C{n}->C{n // 8} f=8, one [6,79,{n},{n}] f32 field over {world} ranks: {len(units)} band(s) of "
+                        f"{units[0][2] - units[0][1]} rows per rank, no collective",
+            "ms": ms, "rank0_ms": mine_ms, "rank0_GBps": alg(nel_rank) / mine_ms / 1e6,
+            "roofline": {"bound": "hbm", "achieved": alg(nel) / ms / 1e6, "peak": PEAK_HBM_GBPS * world, "unit": "GB/s",
+                         "frac": alg(nel) / ms / 1e6 / (PEAK_HBM_GBPS * world), "traffic": None,
+                         "note": "aggregate algorithmic bytes of the whole field / max-over-ranks time, against N x 8 TB/s"},
+        })
+        del objs, areas
+    except Exception as err:  # noqa: BLE001
+        out.append({"kernel": "weighted_block_average, (tile, row-band) sharded", "error": f"{type(err).__name__}: {err}"})
+    torch.cuda.empty_cache()
+    try:
+        owners = min(world, 6)
+        group = dist.new_group(list(range(owners))) if owners < world else None  # (every rank calls new_group)
+        res = None
+        if rank < owners:
+            parallel.use_group(group)
+            tiles = parallel.tiles_of_rank(owners, rank)
+            sync = (lambda: (torch.cuda.synchronize(dev), dist.barrier(group=group), torch.cuda.synchronize(dev)))
+            res = restart_pipeline_benchmark(dev, tiles=tuple(tiles), which=("pressure",), sync=sync)[0]
+            parallel.use_group(None)
+        fence()
+        ms = reduce_max(res["ms"] if res else 0.0)
+        if rank == 0:
+            total = res["bytes"] * 6 / len(parallel.tiles_of_rank(owners, 0))
+            res.update({"kernel": res["kernel"] + f", tile-sharded over {owners} of {world} ranks, halo rows by all_gather",
+                        "ms": ms, "roofline": {"bound": "hbm", "achieved": total / ms / 1e6, "peak": PEAK_HBM_GBPS * owners,
+                                               "unit": "GB/s", "frac": total / ms / 1e6 / (PEAK_HBM_GBPS * owners), "traffic": None,
+                                               "note": "input bytes of the whole cube / max-over-ranks wall time"}})
+            out.append(res)
+    except Exception as err:  # noqa: BLE001
+        out.append({"kernel": "coarsen_restarts_on_pressure, tile-sharded", "error": f"{type(err).__name__}: {err}"})
+    torch.cuda.empty_cache()
+    return out
+
+
+def spawn_ranks(n):
+    """``python bench.py --gpus N`` without a launcher (WORLD_SIZE unset): start the N ranks here, as fresh child
+    processes, BEFORE anything in this process touches the GPU, and leave with their worst exit code.  Rank 0's
+    stdout (the JSON line) passes through.  If any rank fails the others are stopped: never a silent 1-GPU line."""
+    import socket
+    import subprocess
+
+    rehearsal = os.environ.get("FV3_BENCH_REHEARSAL") == "1"
+    have = torch.cuda.device_count()  # (counts devices without initialising the GPU)
+    if not rehearsal and have < n:
+        print(f"bench.py: --gpus {n} but only {have} GPU(s) visible", file=sys.stderr)
+        sys.exit(2)
+    with socket.socket() as sock:
+        sock.bind(("127.0.0.1", 0))
+        port = sock.getsockname()[1]
+    procs = []
+    for r in range(n):
+        env = dict(os.environ, RANK=str(r), LOCAL_RANK=str(r), WORLD_SIZE=str(n), LOCAL_WORLD_SIZE=str(n),
+                   MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+        procs.append(subprocess.Popen([sys.executable, os.path.abspath(__file__)] + sys.argv[1:], env=env))
+    worst = 0
+    live = list(procs)
+    while live:
+        time.sleep(0.2)
+        for pr in list(live):
+            code = pr.poll()
+            if code is None:
+                continue
+            live.remove(pr)
+            if code != 0:
+                worst = worst or (code if code > 0 else 1)
+                for other in live:  # a rank died: the others would wait at the barrier forever
+                    other.terminate()
+    sys.exit(worst)
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -460,9 +709,14 @@ def main():
     ap.add_argument("--no-cpu", action="store_true")
     args = ap.parse_args()
 
+    if "WORLD_SIZE" not in os.environ and args.gpus > 1:
+        spawn_ranks(args.gpus)  # does not return
     rank = int(os.environ.get("RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if world != max(args.gpus, 1):
+        print(f"bench.py: --gpus {args.gpus} but WORLD_SIZE={world}", file=sys.stderr)
+        sys.exit(2)
     # Rehearsal on a one-GPU box: FV3_BENCH_REHEARSAL=1 puts every rank on cuda:0 and rendezvouses over gloo
     # (two ranks cannot share a device under RCCL).  Real runs: one rank per GPU, backend nccl = RCCL over xGMI.
     rehearsal = os.environ.get("FV3_BENCH_REHEARSAL") == "1"
@@ -474,7 +728,6 @@ def main():
             dist.init_process_group("gloo", rank=rank, world_size=world)
         else:
             dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device(f"cuda:{local_rank}"))
-    assert world == max(args.gpus, 1) or world == 1, f"--gpus {args.gpus} but WORLD_SIZE={world}"
     dev = torch.device(f"cuda:{local_rank}")
     torch.cuda.set_device(dev)
 
@@ -482,16 +735,25 @@ def main():
     from fv3net_amd.mlp import MlpModel
 
     _lib.load()
-    spec = zc_spec(0)
+    spec = zc_spec(0)  # the production graph: 396 direct + 395 residual output rows
     model = MlpModel(spec, device=dev)
     ncol = 6 * 384 * 384
     src = zc_inputs_device(dev, ncol, seed=1000 + rank)
+    n_out_rows = sum(OUTPUTS.values()) + NZ * len(RESIDUALS)
 
     def step():
         return model.predict(src)
 
     for _ in range(args.warmup):
         step()
+    variant = model.last_variant
+    # parity of the timed object on a slice of the timed inputs (rank 0; the oracle is the checker, never the thing timed)
+    parity, parity_variant = (None, None)
+    if rank == 0:
+        try:
+            parity, parity_variant = parity_max_rel(model, spec, src)
+        except Exception as err:  # noqa: BLE001
+            parity_variant = f"failed: {type(err).__name__}: {err}"
 
     def fence():
         torch.cuda.synchronize(dev)
@@ -512,14 +774,16 @@ def main():
     elapsed = time.perf_counter() - t0
     kernel_ms = timer.elapsed_ms() / args.steps
     if world > 1:
-        t = torch.tensor([elapsed], device=dev, dtype=torch.float64)
+        t = torch.tensor([elapsed], dtype=torch.float64, device="cpu" if rehearsal else dev)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t.item())
 
+    line = None
     if rank == 0:
         total_cols = ncol * world * args.steps
         flops = model.flops_per_sample
         achieved = flops * ncol / (kernel_ms * 1e-3) / 1e12
+        traffic, traffic_source = pmc_traffic(variant)
         line = {
             "metric": "columns/s ML-tendency inference at C384x79 (Zhao-Carr dense emulator)",
             "value": total_cols / elapsed,
@@ -535,19 +799,26 @@ def main():
             "data": "synthetic (SURVEY 8d config 2 distributions, random-init weights of the dense.yaml architecture)",
             "config": {
                 "workload": "C384 Zhao-Carr microphysics MLP emulator, one 6x384x384x79 snapshot per GPU "
-                            "(BASELINE configs[1]): K=711 -> 256 -> 256 -> 396, float32 [feature, sample] inputs in HBM",
+                            "(BASELINE configs[1]), the production graph of projects/microphysics/train/dense.yaml: "
+                            f"K=711 -> 256 -> 256 -> 396 direct outputs + the five Difference residuals after = before + "
+                            f"difference ({n_out_rows} output rows), float32 [feature, sample] inputs in HBM",
                 "columns_per_gpu": ncol,
                 "flops_per_column": flops,
+                "output_rows": n_out_rows,
                 "parallelism": f"snapshot/tile sharding over {world} GPU(s), no collective on the data path",
             },
+            "parity_max_rel": parity,
+            "parity_note": "max over the 11 outputs of max|gpu - f64 oracle| / max|oracle| on the first 4096 timed columns, "
+                           f"same model object and kernel ({parity_variant}); bar 1e-5",
             "roofline": {
                 "bound": "mfma",
                 "achieved": achieved,
                 "peak": PEAK_FP32_MFMA_TFLOPS,
                 "unit": "TFLOP/s",
                 "frac": achieved / PEAK_FP32_MFMA_TFLOPS,
-                "traffic": pmc_traffic("mlp_fused_kernel<8,false,true,false,false,false>"),
-                "kernel": "mlp_fused_kernel<8,false,true,false,false,false>",
+                "traffic": traffic,
+                "traffic_source": traffic_source,
+                "kernel": variant,
                 "kernel_ms": kernel_ms,
             },
         }
@@ -557,13 +828,20 @@ def main():
             except Exception as err:  # noqa: BLE001
                 line["cpu_baseline"] = {"value": None, "unit": "columns/s", "cores": os.cpu_count(), "kind": "port",
                                         "sample": f"failed: {type(err).__name__}: {err}"}
-        if world == 1 and not args.no_secondary:
-            del src
-            torch.cuda.empty_cache()
+    del src
+    torch.cuda.empty_cache()
+    if not args.no_secondary:
+        # (never lose the headline line to a secondary workload)
+        if world == 1:
             try:
-                line["secondary"] = secondary_benchmarks(dev, args.steps)
-            except Exception as err:  # noqa: BLE001  (never lose the headline line to a secondary workload)
-                line["secondary"] = [{"kernel": "secondary_benchmarks", "error": f"{type(err).__name__}: {err}"}]
+                sec = secondary_benchmarks(dev, args.steps)
+            except Exception as err:  # noqa: BLE001
+                sec = [{"kernel": "secondary_benchmarks", "error": f"{type(err).__name__}: {err}"}]
+        else:
+            sec = sharded_secondary_benchmarks(dev, args.steps, rank, world, rehearsal)  # collective: every rank takes part
+        if line is not None:
+            line["secondary"] = sec
+    if rank == 0:
         info = ops.device_info()
         line["device"] = {"name": info["name"], "arch": info["arch"], "compute_units": info["compute_units"]}
         print(json.dumps(line), flush=True)

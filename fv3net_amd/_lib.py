@@ -157,6 +157,7 @@ SIGNATURES = {
          POINTER(c_void_p), c_int, POINTER(c_int64), POINTER(c_int64), c_void_p],
     ),
     "fv3hip_mlp_flops_per_sample": (c_int64, [c_void_p]),
+    "fv3hip_mlp_last_variant": (c_char_p, [c_void_p]),
     "fv3hip_timer_create": (c_int, [POINTER(c_void_p)]),
     "fv3hip_timer_start": (c_int, [c_void_p, c_void_p]),
     "fv3hip_timer_stop": (c_int, [c_void_p, c_void_p]),

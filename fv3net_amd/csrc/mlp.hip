@@ -269,8 +269,10 @@ __global__ __launch_bounds__(kThreads, 1) void mlp_fused_kernel(const MlpLaunch 
             oslow[i] = sl;
             if (p.n_residual) {
                 ORes r;
-                r.src_row = 0;
-                r.out_row = 0;
+                // (fast-I/O launches: an output row without a residual reads and writes the scratch row, so that
+                // the branch-free epilogue treats every row alike; general launches: 0 = none)
+                r.src_row = p.sink;
+                r.out_row = p.sink;
                 r.src_ss = r.out_ss = r.pad0 = r.pad1 = 0;
                 if (e.out_feat >= 0 && e.res >= 0) {
                     const int rslot = e.res >> 8, rs = e.res & 0xFF;
@@ -496,8 +498,15 @@ __global__ __launch_bounds__(kThreads, 1) void mlp_fused_kernel(const MlpLaunch 
             for (int i = 0; i < NVH; ++i) commit_w1(0, part, i);
         }
         if (XBULK) {
+            // (the same flavour the steady state gives chunk 0 -- see the end of the layer-1 chunk loop -- so that a
+            // column's result does not depend on whether its tile is a workgroup's first)
+            if (p.n_logfast_chunks > 0) {
 #pragma unroll
-            for (int i = 0; i < 4; ++i) bulk_finish1(0, i, 0, std::integral_constant<int, 1>{});
+                for (int i = 0; i < 4; ++i) bulk_finish1(0, i, 0, std::integral_constant<int, 2>{});
+            } else {
+#pragma unroll
+                for (int i = 0; i < 4; ++i) bulk_finish1(0, i, 0, std::integral_constant<int, 1>{});
+            }
         } else {
             finish_x(0);
         }
@@ -711,12 +720,14 @@ __global__ __launch_bounds__(kThreads, 1) void mlp_fused_kernel(const MlpLaunch 
                     *(GF32x4)(row_addr + (n0t + e_wcol) * 4) = v;
                 }
             };
-            // (plain_c: float32 outputs, no limits / masks, no residual outputs -- decided once per
-            // tile loop, so that the side work inside the MFMA slots is branch-free: the MFMAs of a
-            // slot queue only one deep, every branch in its side work is matrix-pipe idle time)
-            auto epi_row = [&](const OFast of, f32x4 v, int idx, auto plain_c) {
+            // (mode_c: 1 = "plain": float32 outputs, no limits / masks, no residual outputs; 2 = plain with
+            // residual outputs (float32 sources; the residual rows are handled by epi_side); 0 = everything
+            // else -- decided once per tile loop, so that the side work inside the MFMA slots of modes 1 and 2
+            // is branch-free: the MFMAs of a slot queue only one deep, every branch in its side work is
+            // matrix-pipe idle time)
+            auto epi_row = [&](const OFast of, f32x4 v, int idx, auto mode_c) {
                 // (v is the physical value: scale and center live in the output weights and bias)
-                if (decltype(plain_c)::value) {
+                if (decltype(mode_c)::value != 0) {
                     *(GF32x4)(of.row + (n0t + e_wcol) * 4) = v;  // (padded rows point at the sink row)
                     return;
                 }
@@ -754,7 +765,7 @@ __global__ __launch_bounds__(kThreads, 1) void mlp_fused_kernel(const MlpLaunch 
 #pragma unroll
                 for (int j = 0; j < 4; ++j) {
                     const int row = e_wrow + 8 * j, idx = t * 32 + row;
-                    epi_row(ofast[idx], *reinterpret_cast<const f32x4 *>(scr + row * 32 + e_wcol), idx, std::false_type{});
+                    epi_row(ofast[idx], *reinterpret_cast<const f32x4 *>(scr + row * 32 + e_wcol), idx, std::integral_constant<int, 0>{});
                 }
             };
             // ... or spread over the slots of the next tile's chunk (EPI_SIDE, KC_O >= 12):
@@ -768,12 +779,39 @@ __global__ __launch_bounds__(kThreads, 1) void mlp_fused_kernel(const MlpLaunch 
             // scratch against whatever the other waves do next.
             OFast e_of[2];
             f32x4 e_v[2];
-            auto epi_side = [&](const f32x16 &y, int t, int s_, auto plain_c) __attribute__((always_inline)) {
-                if (!decltype(plain_c)::value && n0t >= p.n_samples) return;  // (plain: only for full tiles)
+            // mode 2 (the production Zhao-Carr graph: every difference output also leaves as after = before + difference,
+            // transforms.py:54-58): the four rows' {before row, after row} table entries are read in slot 0, the four
+            // 16-byte `before` loads issued in slot 1 -- older than the second staging request of slot KC/2 - 1, eight slots
+            // (~1.7 us: they come from HBM, like the layer-1 inputs) before their first use -- and the sum leaves with a
+            // second store next to the row's own in slots 9, 10.
+            // Rows without a residual (total_precipitation, padding) read and write the scratch row.
+            typedef long long i64x2 __attribute__((ext_vector_type(2)));
+            constexpr bool RES_SIDE = EPI_SIDE && !SRC64 && !HOUT && !SMALLF;
+            i64x2 e_res[RES_SIDE ? 4 : 1];
+            f32x4 e_before[RES_SIDE ? 4 : 1];
+            const int64_t e_loff = (n0t + e_wcol) * 4;
+            auto epi_side = [&](const f32x16 &y, int t, int s_, auto mode_c) __attribute__((always_inline)) {
+                constexpr int MODE = decltype(mode_c)::value;
+                if (MODE == 0 && n0t >= p.n_samples) return;  // (modes 1, 2: only for full tiles)
                 if (s_ == 1) epi_put_tile(y);
+                if constexpr (MODE == 2 && RES_SIDE) {
+                    if (s_ == 0) {
+#pragma unroll
+                        for (int j = 0; j < 4; ++j)
+                            e_res[j] = *reinterpret_cast<const i64x2 *>(&ores[t * 32 + e_wrow + 8 * j]);
+                    }
+                    if (s_ == 1) {
+#pragma unroll
+                        for (int j = 0; j < 4; ++j) e_before[j] = *(GCF32x4)(e_res[j][0] + e_loff);
+                    }
+                }
                 if (s_ == 9 || s_ == 10) {
 #pragma unroll
-                    for (int i = 0; i < 2; ++i) epi_row(e_of[i], e_v[i], t * 32 + e_wrow + 8 * (2 * (s_ - 9) + i), plain_c);
+                    for (int i = 0; i < 2; ++i) {
+                        epi_row(e_of[i], e_v[i], t * 32 + e_wrow + 8 * (2 * (s_ - 9) + i), mode_c);
+                        if constexpr (MODE == 2 && RES_SIDE)
+                            *(GF32x4)(e_res[2 * (s_ - 9) + i][1] + e_loff) = e_before[2 * (s_ - 9) + i] + e_v[i];
+                    }
                 }
                 if (s_ == 8 || s_ == 9) {
 #pragma unroll
@@ -885,7 +923,7 @@ __global__ __launch_bounds__(kThreads, 1) void mlp_fused_kernel(const MlpLaunch 
             // one output tile = one chunk.  EPI_SIDE: two accumulators used alternately -- while `y`
             // accumulates tile t, `yo` still holds tile t-1: its epilogue runs in slots 1..10, then
             // (slot 12) it is re-initialised with the bias of tile t+1.
-            auto out_chunk = [&](f32x16 &y, f32x16 &yo, int t, auto has_prev_c, auto plain_c) __attribute__((always_inline)) {
+            auto out_chunk = [&](f32x16 &y, f32x16 &yo, int t, auto has_prev_c, auto mode_c) __attribute__((always_inline)) {
                 const int gnext = (g + 1 == G) ? 0 : g + 1;
 #pragma unroll
                 for (int s = 0; s < KC_O; ++s) {
@@ -893,7 +931,7 @@ __global__ __launch_bounds__(kThreads, 1) void mlp_fused_kernel(const MlpLaunch 
                     run_slot_out(y, s, [&](int s_) {
                         stage_step(s_, KC_O, gnext, par ^ 1);
                         if (EPI_SIDE) {
-                            if (decltype(has_prev_c)::value) epi_side(yo, NHO + t - 1, s_, plain_c);
+                            if (decltype(has_prev_c)::value) epi_side(yo, NHO + t - 1, s_, mode_c);
                             if (s_ == 12) load_bias(yo, t + 1);
                         }
                     });
@@ -957,18 +995,18 @@ __global__ __launch_bounds__(kThreads, 1) void mlp_fused_kernel(const MlpLaunch 
                         if (v < p.smallf_n) *(GF32)(ofast[NHO * 32 + v].row + (n0t + lane) * 4) = y4[v] + bo[2 * v];
                 }
             }
-            auto tile_loop = [&](auto plain_c) __attribute__((always_inline)) {
+            auto tile_loop = [&](auto mode_c) __attribute__((always_inline)) {
                 if constexpr (EPI_SIDE) {
                     load_bias(yA, 0);
-                    out_chunk(yA, yB, 0, std::false_type{}, plain_c);
+                    out_chunk(yA, yB, 0, std::false_type{}, mode_c);
                     for (int t = 1; t < NT; t += 2) {
-                        out_chunk(yB, yA, t, std::true_type{}, plain_c);
-                        if (t + 1 < NT) out_chunk(yA, yB, t + 1, std::true_type{}, plain_c);
+                        out_chunk(yB, yA, t, std::true_type{}, mode_c);
+                        if (t + 1 < NT) out_chunk(yA, yB, t + 1, std::true_type{}, mode_c);
                     }
                 } else {
                     for (int t = 0; t < NT; ++t) {
                         load_bias(yA, t);
-                        out_chunk(yA, yB, t, std::false_type{}, plain_c);
+                        out_chunk(yA, yB, t, std::false_type{}, mode_c);
                         // (general kernels: the next tile's first inputs are requested before the last
                         // epilogue and finished after it)
                         const bool prefetch_next = (t + 1 == NT) && next_tile < p.n_tiles;
@@ -980,9 +1018,19 @@ __global__ __launch_bounds__(kThreads, 1) void mlp_fused_kernel(const MlpLaunch 
             };
             if constexpr (!SMALLF) {  // (small-output launches carry no output chunk: NT = 0)
             if (!HOUT || NT > 0) {
-                if (EPI_SIDE && !p.has_limits && !p.out64 && !p.n_residual && (tile + 1) * kTileSamples <= p.n_samples)
-                    tile_loop(std::true_type{});
-                else tile_loop(std::false_type{});
+                const bool side_plain = EPI_SIDE && !p.has_limits && !p.out64 && (tile + 1) * kTileSamples <= p.n_samples;
+                bool done = false;
+                if (side_plain && !p.n_residual) {
+                    tile_loop(std::integral_constant<int, 1>{});
+                    done = true;
+                }
+                if constexpr (RES_SIDE) {
+                    if (!done && side_plain) {
+                        tile_loop(std::integral_constant<int, 2>{});
+                        done = true;
+                    }
+                }
+                if (!done) tile_loop(std::integral_constant<int, 0>{});
             }
             STAMP_END(2);
             if (EPI_SIDE && (!HOUT || NT > 0)) {  // the last tile's epilogue (tile NT-1 sits in yA if NT is odd)
@@ -1026,6 +1074,7 @@ struct fv3hip_mlp {
     void *d_w = nullptr, *d_ktab = nullptr, *d_otab = nullptr, *d_bias = nullptr;
     int n_cu = 256;
     size_t lds_bytes = 0;
+    char last_variant[160] = {0};  // what the last fv3hip_mlp_predict launched (fv3hip_mlp_last_variant)
 };
 
 namespace {
@@ -1327,6 +1376,8 @@ extern "C" int fv3hip_mlp_destroy(fv3hip_mlp_t m)
 
 extern "C" int64_t fv3hip_mlp_flops_per_sample(fv3hip_mlp_t m) { return m ? m->flops : 0; }
 
+extern "C" const char *fv3hip_mlp_last_variant(fv3hip_mlp_t m) { return m ? m->last_variant : ""; }
+
 extern "C" int fv3hip_mlp_predict(fv3hip_mlp_t m, const void *const *sources, const int *src_dtype,
                                   const int64_t *src_feat_stride, const int64_t *src_sample_stride,
                                   int64_t n_samples, void *const *outputs, int out_dtype,
@@ -1432,6 +1483,19 @@ extern "C" int fv3hip_mlp_predict(fv3hip_mlp_t m, const void *const *sources, co
     }
     // ... and, with one layer-1 chunk of at most 16 untransformed inputs, an 8-slot first chunk (the dense-local models)
     const bool l1short = smallf && !m->n_hout_tiles && m->K <= 16 && m->n_log_chunks == 0;
+    // the instantiation and the epilogue flavour of this launch, for fv3hip_mlp_last_variant: full sample tiles of a
+    // fast-I/O float32 launch of the 8-tile kernel take the branch-free side epilogue ("plain", or "residual" when the
+    // model has residual outputs), everything else the general one
+    {
+        const bool hout_v = m->n_hout_tiles != 0;
+        const bool src64_v = src64 && !smallf && !hout_v;
+        const bool side = xbulk && !smallf && m->HT == 8 && !m->has_limits && out_dtype == FV3HIP_F32 && n_samples >= kTileSamples;
+        const char *epi = smallf ? "small-output" : (side && !m->n_residual) ? "plain"
+                          : (side && !src64_v && !hout_v) ? "residual" : "general";
+        snprintf(m->last_variant, sizeof(m->last_variant), "mlp_fused_kernel<%d,%s,%s,%s,%s,%s> epilogue=%s", m->HT,
+                 src64_v ? "true" : "false", xbulk ? "true" : "false", hout_v ? "true" : "false",
+                 smallf ? "true" : "false", l1short ? "true" : "false", epi);
+    }
 #define VARIANT_(H)                                                                                \
     if (m->HT == H && l1short) return launch_one<H, false, true, false, true, true>(lp, grid, lds, st); \
     if (m->HT == H && smallf)                                                                      \

@@ -377,6 +377,11 @@ class MlpModel:
         )
         return outs
 
+    @property
+    def last_variant(self) -> str:
+        """Kernel instantiation and epilogue flavour of the last ``predict`` (``fv3hip_mlp_last_variant``)."""
+        return _lib.load().fv3hip_mlp_last_variant(self._handle).decode()
+
     def __del__(self):
         h = getattr(self, "_handle", None)
         if h:

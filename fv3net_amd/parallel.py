@@ -17,11 +17,26 @@ import torch
 import torch.distributed as dist
 
 
+_GROUP = None  # process group the partition functions and the halo exchange run in (None = the default group)
+
+
+def use_group(group) -> None:
+    """Run the sharded entry points of this module inside ``group`` (a ``torch.distributed`` process group) instead of
+    the default one -- e.g. the six tile owners of an 8-rank job for the tile-sharded restart pipelines
+    (``dist.new_group(range(6))``; the other ranks do not call them).  ``None`` restores the default group."""
+    global _GROUP
+    _GROUP = group
+
+
 def world() -> Tuple[int, int]:
-    """(rank, world_size); (0, 1) when torch.distributed is not initialised."""
+    """(rank, world_size) in the active group; (0, 1) when torch.distributed is not initialised."""
     if dist.is_available() and dist.is_initialized():
-        return dist.get_rank(), dist.get_world_size()
+        return dist.get_rank(_GROUP), dist.get_world_size(_GROUP)
     return 0, 1
+
+
+def _global(group_rank: int) -> int:
+    return group_rank if _GROUP is None else dist.get_global_rank(_GROUP, group_rank)
 
 
 def column_range(n_columns: int, world_size: int, rank: int) -> Tuple[int, int]:
@@ -55,6 +70,55 @@ def tile_bands(n_tiles: int, ny: int, factor: int, world_size: int) -> List[List
     return out
 
 
+def units_of_rank(n_tiles: int, ny: int, factor: int, world_size: int, rank: int) -> List[Tuple[int, int, int]]:
+    """The (tile, row_start, row_stop) row bands ``rank`` owns (:func:`tile_bands`)."""
+    return tile_bands(n_tiles, ny, factor, world_size)[rank]
+
+
+def weighted_block_average_banded(obj_bands: List[torch.Tensor], weight_bands: List[torch.Tensor], factor: int,
+                                  n_tiles: int = 6, ny: int = None, gather: bool = False, dst: int = 0):
+    """``weighted_block_average`` of a cube sharded by row bands (BASELINE configs[4]: 6 tiles x row bands over 8 GPUs; the
+    reference's fine-resolution restarts arrive as such sub-tile files, external/vcm/vcm/cubedsphere/coarsen.py:27).
+    ``obj_bands[i]`` [..., rows, nx] and ``weight_bands[i]`` ([rows, nx] or the field's shape) are this rank's units in
+    the order of :func:`units_of_rank`; every f x f block lies inside one band, so there is no exchange step.  Returns the
+    coarse bands [..., rows / f, nx / f]; with ``gather`` rank ``dst`` gets the assembled coarse cube
+    [n_tiles, ..., ny / f, nx / f] (others None) -- the coarse field is 1 / f^2 of the data, one small collective."""
+    from . import ops
+
+    coarse = [ops.weighted_block_average(o, w, factor) for o, w in zip(obj_bands, weight_bands)]
+    if not gather:
+        return coarse
+    rank, size = world()
+    if ny is None:
+        raise ValueError("gather needs the tile's row count ny")
+    plan = tile_bands(n_tiles, ny, factor, size)
+    if len(coarse) != len(plan[rank]):
+        raise ValueError(f"rank {rank} owns {len(plan[rank])} bands, got {len(coarse)}")
+    if size == 1:
+        pieces = {0: coarse}
+    else:
+        # bands of one plan share their shape except when whole tiles were dealt unevenly: pad the count, not the shape
+        width = max(len(units) for units in plan)
+        ref = coarse[0] if coarse else None
+        if ref is None:
+            raise ValueError("a rank without bands cannot take part in the gather")
+        stacked = torch.zeros((width,) + tuple(ref.shape), dtype=ref.dtype, device=ref.device)
+        for i, c in enumerate(coarse):
+            stacked[i] = c
+        staged = stacked.cpu() if (stacked.is_cuda and dist.get_backend(_GROUP) == "gloo") else stacked
+        bufs = [torch.empty_like(staged) for _ in range(size)] if rank == dst else None
+        dist.gather(staged, bufs, dst=_global(dst), group=_GROUP)
+        if rank != dst:
+            return None
+        pieces = {r: [bufs[r][i].to(ref.device) for i in range(len(plan[r]))] for r in range(size)}
+    first = pieces[0][0]
+    out = torch.empty((n_tiles,) + tuple(first.shape[:-2]) + (ny // factor, first.shape[-1]), dtype=first.dtype, device=first.device)
+    for r, units in enumerate(plan):
+        for (t, r0, r1), c in zip(units, pieces[r]):
+            out[t, ..., r0 // factor:r1 // factor, :] = c
+    return out
+
+
 def gather_columns(local: torch.Tensor, n_columns: int, dst: int = 0):
     """Gather per-rank ``[features, n_local]`` blocks (split by :func:`column_range`) to rank
     ``dst`` as ``[features, n_columns]``; returns None on the other ranks.  The only collective
@@ -68,9 +132,9 @@ def gather_columns(local: torch.Tensor, n_columns: int, dst: int = 0):
     padded[:, : local.shape[1]] = local
     if rank == dst:
         bufs = [torch.empty_like(padded) for _ in range(size)]
-        dist.gather(padded, bufs, dst=dst)
+        dist.gather(padded, bufs, dst=_global(dst), group=_GROUP)
         return torch.cat([b[:, : (hi - lo)] for b, (lo, hi) in zip(bufs, counts)], dim=1)
-    dist.gather(padded, None, dst=dst)
+    dist.gather(padded, None, dst=_global(dst), group=_GROUP)
     return None
 
 
@@ -108,14 +172,14 @@ def exchange_edge_rows(local_rows: torch.Tensor, n_tiles: int = 6) -> torch.Tens
         raise ValueError(f"rank {rank} owns {counts[rank]} tiles, got rows for {local_rows.shape[0]}")
     padded = torch.zeros((width,) + tuple(local_rows.shape[1:]), dtype=local_rows.dtype, device=local_rows.device)
     padded[: counts[rank]] = local_rows
-    if padded.is_cuda and dist.get_backend() == "gloo":  # (CPU-backend rehearsals with device data: stage through the host)
+    if padded.is_cuda and dist.get_backend(_GROUP) == "gloo":  # (CPU-backend rehearsals with device data: stage through the host)
         host = padded.cpu()
         bufs = [torch.empty_like(host) for _ in range(size)]
-        dist.all_gather(bufs, host)
+        dist.all_gather(bufs, host, group=_GROUP)
         bufs = [b.to(padded.device) for b in bufs]
     else:
         bufs = [torch.empty_like(padded) for _ in range(size)]
-        dist.all_gather(bufs, padded.contiguous())
+        dist.all_gather(bufs, padded.contiguous(), group=_GROUP)
     return torch.cat([b[:c] for b, c in zip(bufs, counts)], dim=0)
 
 

@@ -326,6 +326,12 @@ int fv3hip_mlp_predict(fv3hip_mlp_t model, const void *const *sources, const int
 /* FLOPs of the dense contraction per sample (2 * sum(in * out)), for roofline accounting. */
 int64_t fv3hip_mlp_flops_per_sample(fv3hip_mlp_t model);
 
+/* Diagnostic: the kernel instantiation the model's last fv3hip_mlp_predict launched and the epilogue its full
+ * sample tiles took, e.g. "mlp_fused_kernel<8,false,true,false,false,false> epilogue=residual" (the name rocprofv3
+ * reports, so that tests and bench.py can tell which code path a result came from).  "" before the first call.
+ * The string lives in the model handle. */
+const char *fv3hip_mlp_last_variant(fv3hip_mlp_t model);
+
 /* ------------------------------------------------------------------------------------------
  * Timing helper: HIP events on the caller's stream (bench.py measures kernels with these
  * because torch.cuda.Event only sees torch's current stream).

@@ -210,6 +210,61 @@ def test_full_size_c384_properties(device):
     assert torch.equal(permuted["y"], full["y"][:, perm])
 
 
+@pytest.mark.parametrize("n", [4096, 147456])
+@pytest.mark.parametrize("residuals", [True, False])
+def test_timed_kernel_against_oracle(device, n, residuals):
+    """The instantiation bench.py times -- float32 [feature, sample] sources, fast I/O, K = 711 -> 256 -> 256 -> 396 with
+    the fast-log chunks, the tile-major output layer and the branch-free side epilogue ("plain"; "residual" with the
+    five ``after = before + difference`` outputs of dense.yaml:22-36) -- on bench.py's own model and input
+    distributions against the float64 oracle (microphysics.py:123-139).  The launch must really be that kernel."""
+    import bench
+    from fv3net_amd.mlp import MlpModel
+
+    spec = bench.zc_spec(0, residuals=residuals)
+    src = bench.zc_inputs_numpy(np.random.default_rng(11), n)
+    model = MlpModel(spec, device=device)
+    dev_src = {k: torch.from_numpy(np.ascontiguousarray(v.T)).to(device) for k, v in src.items()}
+    out = model.predict(dev_src)
+    assert model.last_variant == ("mlp_fused_kernel<8,false,true,false,false,false> epilogue="
+                                  + ("residual" if residuals else "plain")), model.last_variant
+    truth = mlp_np.forward(spec, src, dtype=np.float64)
+    cpu32 = mlp_np.forward(spec, src, dtype=np.float32)
+    assert set(out) == set(truth) and len(truth) == (11 if residuals else 6)
+    for name, t in truth.items():
+        got = out[name].cpu().numpy().T
+        assert got.shape == t.shape
+        scale = np.max(np.abs(t))
+        err = np.max(np.abs(got - t))
+        assert err <= 1e-5 * scale, (name, err, scale)
+        assert err <= 4 * np.max(np.abs(cpu32[name] - t)) + 1e-7 * scale, name
+    if residuals:  # the residual rows are exactly before + the difference row the kernel stored
+        for name, (before, diff) in bench.RESIDUALS.items():
+            assert torch.equal(out[name], dev_src[before] + out[diff]), name
+    # the same columns inside a full C384-sized call (other tile positions, the persistent loop wrapped around)
+    if n == 4096:
+        big = 6 * 384 * 384
+        reps = big // n
+        full = model.predict({k: v.repeat(1, reps) for k, v in dev_src.items()})
+        for name in truth:
+            assert torch.equal(full[name][:, -n:], out[name]), name
+
+
+def test_timed_kernel_float64_sources_take_general_epilogue(device):
+    """float64 sources (what call_py_fort hands the hook) with residual outputs: same results as float32 sources to
+    rounding of the inputs, through the f64 instantiation."""
+    import bench
+    from fv3net_amd.mlp import MlpModel
+
+    spec = bench.zc_spec(0)
+    src = bench.zc_inputs_numpy(np.random.default_rng(12), 4096)
+    model = MlpModel(spec, device=device)
+    out = model.predict({k: torch.from_numpy(np.ascontiguousarray(v.T.astype(np.float64))).to(device) for k, v in src.items()})
+    assert model.last_variant.startswith("mlp_fused_kernel<8,true,true,false,false,false>"), model.last_variant
+    truth = mlp_np.forward(spec, src, dtype=np.float64)
+    for name, t in truth.items():
+        assert np.max(np.abs(out[name].cpu().numpy().T - t)) <= 1e-5 * np.max(np.abs(t)), name
+
+
 @pytest.mark.parametrize("in_dtype,n_buffers", [(np.float32, 3), (np.float64, 2)])
 def test_snapshot_stream_matches_direct_predict(device, in_dtype, n_buffers):
     """Streaming snapshots through pinned host buffers on three HIP streams gives, for every snapshot and
