@@ -780,37 +780,39 @@ __global__ __launch_bounds__(kThreads, 1) void mlp_fused_kernel(const MlpLaunch 
             OFast e_of[2];
             f32x4 e_v[2];
             // mode 2 (the production Zhao-Carr graph: every difference output also leaves as after = before + difference,
-            // transforms.py:54-58): the four rows' {before row, after row} table entries are read in slot 0, the four
+            // transforms.py:54-58): the four rows' `before` row addresses are read from the table in slot 0, the four
             // 16-byte `before` loads issued in slot 1 -- older than the second staging request of slot KC/2 - 1, eight slots
             // (~1.7 us: they come from HBM, like the layer-1 inputs) before their first use -- and the sum leaves with a
-            // second store next to the row's own in slots 9, 10.
+            // second store next to the row's own in slots 9, 10.  (Tried and dropped: requesting the last tile's rows in
+            // slots 11, 12 of its own chunk -- branch-free, every other chunk reading an all-scratch table tile -- cost
+            // 900 cycles per chunk in slot 12.)
             // Rows without a residual (total_precipitation, padding) read and write the scratch row.
-            typedef long long i64x2 __attribute__((ext_vector_type(2)));
             constexpr bool RES_SIDE = EPI_SIDE && !SRC64 && !HOUT && !SMALLF;
-            i64x2 e_res[RES_SIDE ? 4 : 1];
+            int64_t e_src[RES_SIDE ? 4 : 1], e_out[2];
             f32x4 e_before[RES_SIDE ? 4 : 1];
             const int64_t e_loff = (n0t + e_wcol) * 4;
+            // (mode 2) `before` row addresses of tile t in slot s0, the four loads in slot s0 + 1
+            auto epi_res_fetch = [&](int t, int s_, int s0) __attribute__((always_inline)) {
+                if (s_ == s0) {
+#pragma unroll
+                    for (int j = 0; j < 4; ++j) e_src[RES_SIDE ? j : 0] = ores[t * 32 + e_wrow + 8 * j].src_row;
+                }
+                if (s_ == s0 + 1) {
+#pragma unroll
+                    for (int j = 0; j < 4; ++j) e_before[RES_SIDE ? j : 0] = *(GCF32x4)(e_src[RES_SIDE ? j : 0] + e_loff);
+                }
+            };
             auto epi_side = [&](const f32x16 &y, int t, int s_, auto mode_c) __attribute__((always_inline)) {
                 constexpr int MODE = decltype(mode_c)::value;
                 if (MODE == 0 && n0t >= p.n_samples) return;  // (modes 1, 2: only for full tiles)
                 if (s_ == 1) epi_put_tile(y);
-                if constexpr (MODE == 2 && RES_SIDE) {
-                    if (s_ == 0) {
-#pragma unroll
-                        for (int j = 0; j < 4; ++j)
-                            e_res[j] = *reinterpret_cast<const i64x2 *>(&ores[t * 32 + e_wrow + 8 * j]);
-                    }
-                    if (s_ == 1) {
-#pragma unroll
-                        for (int j = 0; j < 4; ++j) e_before[j] = *(GCF32x4)(e_res[j][0] + e_loff);
-                    }
-                }
+                if constexpr (MODE == 2 && RES_SIDE) epi_res_fetch(t, s_, 0);
                 if (s_ == 9 || s_ == 10) {
 #pragma unroll
                     for (int i = 0; i < 2; ++i) {
                         epi_row(e_of[i], e_v[i], t * 32 + e_wrow + 8 * (2 * (s_ - 9) + i), mode_c);
                         if constexpr (MODE == 2 && RES_SIDE)
-                            *(GF32x4)(e_res[2 * (s_ - 9) + i][1] + e_loff) = e_before[2 * (s_ - 9) + i] + e_v[i];
+                            *(GF32x4)(e_out[i] + e_loff) = e_before[2 * (s_ - 9) + i] + e_v[i];
                     }
                 }
                 if (s_ == 8 || s_ == 9) {
@@ -819,7 +821,33 @@ __global__ __launch_bounds__(kThreads, 1) void mlp_fused_kernel(const MlpLaunch 
                         const int row = e_wrow + 8 * (2 * (s_ - 8) + i);
                         e_of[i] = ofast[t * 32 + row];
                         e_v[i] = *reinterpret_cast<const f32x4 *>(scr + row * 32 + e_wcol);
+                        if constexpr (MODE == 2 && RES_SIDE) e_out[i] = ores[t * 32 + row].out_row;
                     }
+                }
+            };
+            // (mode 2) the last tile's epilogue, matrix pipe idle: the `before` loads first, the rows' own stores while they fly
+            auto epi_res_last = [&](const f32x16 &y, int t) {
+                epi_res_fetch(t, 0, 0);
+                epi_res_fetch(t, 1, 0);
+                epi_put_tile(y);
+                f32x4 v[4];
+#pragma unroll
+                for (int j = 0; j < 4; ++j) {
+                    const int row = e_wrow + 8 * j;
+                    v[j] = *reinterpret_cast<const f32x4 *>(scr + row * 32 + e_wcol);
+                    *(GF32x4)(ofast[t * 32 + row].row + e_loff) = v[j];
+                }
+#pragma unroll
+                for (int j = 0; j < 4; ++j)
+                    *(GF32x4)(ores[t * 32 + e_wrow + 8 * j].out_row + e_loff) = e_before[RES_SIDE ? j : 0] + v[j];
+            };
+            // (mode 1) the last tile's epilogue without a branch
+            auto epi_plain_last = [&](const f32x16 &y, int t) {
+                epi_put_tile(y);
+#pragma unroll
+                for (int j = 0; j < 4; ++j) {
+                    const int row = e_wrow + 8 * j;
+                    *(GF32x4)(ofast[t * 32 + row].row + e_loff) = *reinterpret_cast<const f32x4 *>(scr + row * 32 + e_wcol);
                 }
             };
             // ---- general epilogue (any strides / dtypes): per-value stores straight from the accumulator
@@ -1016,25 +1044,31 @@ __global__ __launch_bounds__(kThreads, 1) void mlp_fused_kernel(const MlpLaunch 
                     }
                 }
             };
+            bool done = false, res_last = false, plain_last = false;
             if constexpr (!SMALLF) {  // (small-output launches carry no output chunk: NT = 0)
             if (!HOUT || NT > 0) {
                 const bool side_plain = EPI_SIDE && !p.has_limits && !p.out64 && (tile + 1) * kTileSamples <= p.n_samples;
-                bool done = false;
                 if (side_plain && !p.n_residual) {
                     tile_loop(std::integral_constant<int, 1>{});
-                    done = true;
+                    done = plain_last = true;
                 }
                 if constexpr (RES_SIDE) {
                     if (!done && side_plain) {
                         tile_loop(std::integral_constant<int, 2>{});
-                        done = true;
+                        done = res_last = true;
                     }
                 }
                 if (!done) tile_loop(std::integral_constant<int, 0>{});
             }
             STAMP_END(2);
             if (EPI_SIDE && (!HOUT || NT > 0)) {  // the last tile's epilogue (tile NT-1 sits in yA if NT is odd)
-                if (NT & 1) epi_fast_now(yA, NHO + NT - 1); else epi_fast_now(yB, NHO + NT - 1);
+                if (RES_SIDE && res_last) {
+                    if (NT & 1) epi_res_last(yA, NHO + NT - 1); else epi_res_last(yB, NHO + NT - 1);
+                } else if (plain_last) {
+                    if (NT & 1) epi_plain_last(yA, NHO + NT - 1); else epi_plain_last(yB, NHO + NT - 1);
+                } else {
+                    if (NT & 1) epi_fast_now(yA, NHO + NT - 1); else epi_fast_now(yB, NHO + NT - 1);
+                }
             }
             }
             // the scratch half of xs is rewritten by the next tile's first layer-1 chunk
