@@ -18,6 +18,8 @@ NAN_SKIP, NAN_PROPAGATE, NAN_OMIT = range(3)
 LAYOUT_COL_LEVEL, LAYOUT_LEVEL_COL = 0, 1
 TRANSFORM_NONE, TRANSFORM_LOG = 0, 1
 ACT_LINEAR, ACT_RELU = 0, 1
+ARITH_EXACT, ARITH_FAST = 0, 1
+ABI_VERSION = 2
 
 OK, EINVAL, EUNSUPPORTED, EHIP, ENOMEM = 0, -1, -2, -3, -4
 
@@ -115,7 +117,7 @@ SIGNATURES = {
     "fv3hip_hydrostatic_balance": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_int64, c_int, c_int64,
                                            c_double, c_void_p, c_void_p, c_void_p]),
     "fv3hip_mappm_multi": (c_int, [c_void_p, c_void_p, c_void_p, c_int, c_void_p, c_int, c_int64, c_int64, c_int, c_int, c_int, c_int,
-                                   c_int, c_void_p, c_size_t, c_void_p]),
+                                   c_int, c_int, c_void_p, c_size_t, c_void_p]),
     "fv3hip_level_scale": (c_int, [c_void_p, c_int, c_void_p, c_int64, c_int, c_int64, c_void_p, c_void_p]),
     "fv3hip_member_reduce": (c_int, [c_void_p, c_int, c_int, c_int, c_int64, c_void_p, c_void_p]),
     "fv3hip_local_pack": (c_int, [c_void_p, c_int, c_int, c_int, c_double, c_void_p, c_void_p, c_int, c_int64, c_void_p, c_void_p]),
@@ -146,7 +148,7 @@ SIGNATURES = {
     "fv3hip_mappm_workspace_bytes": (c_size_t, [c_int64, c_int]),
     "fv3hip_mappm": (
         c_int,
-        [c_void_p, c_void_p, c_void_p, c_int, c_void_p, c_int64, c_int64, c_int, c_int, c_int, c_int, c_int,
+        [c_void_p, c_void_p, c_void_p, c_int, c_void_p, c_int64, c_int64, c_int, c_int, c_int, c_int, c_int, c_int,
          c_void_p, c_size_t, c_void_p],
     ),
     "fv3hip_mlp_create": (c_int, [POINTER(MlpDesc), POINTER(c_void_p)]),
@@ -183,8 +185,8 @@ def load():
         fn = getattr(lib, name)  # AttributeError = the .so does not export a declared symbol
         fn.restype = restype
         fn.argtypes = argtypes
-    if lib.fv3hip_abi_version() != 1:
-        raise ExtensionMissingError(f"{LIB_PATH} has ABI version {lib.fv3hip_abi_version()}, expected 1")
+    if lib.fv3hip_abi_version() != ABI_VERSION:
+        raise ExtensionMissingError(f"{LIB_PATH} has ABI version {lib.fv3hip_abi_version()}, expected {ABI_VERSION}")
     _lib = lib
     return lib
 

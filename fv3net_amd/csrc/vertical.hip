@@ -9,6 +9,7 @@
 // association order of the Fortran, so that its results are bit-identical to the reference
 // built without FMA contraction (and to oracle/mappm_oracle.c).
 #include "common.h"
+#include "remap.h"
 
 namespace fv3hip {
 namespace {
@@ -1168,9 +1169,10 @@ extern "C" size_t fv3hip_mappm_workspace_bytes(int64_t ncol, int km)
 
 extern "C" int fv3hip_mappm(const void *pe1, const void *q1, const void *pe2, int in_dtype, float *q2,
                             int64_t n_batch, int64_t n_inner, int km, int kn, int iv, int kord,
-                            int layout, void *workspace, size_t workspace_bytes, void *stream)
+                            int layout, int arith, void *workspace, size_t workspace_bytes, void *stream)
 {
     FV3HIP_REQUIRE(in_dtype == FV3HIP_F32 || in_dtype == FV3HIP_F64, "in_dtype must be F32 or F64, got %d", in_dtype);
+    FV3HIP_REQUIRE(arith == FV3HIP_ARITH_EXACT || arith == FV3HIP_ARITH_FAST, "unknown arithmetic mode %d", arith);
     FV3HIP_REQUIRE(layout == FV3HIP_LAYOUT_COL_LEVEL || layout == FV3HIP_LAYOUT_LEVEL_COL, "unknown layout %d", layout);
     FV3HIP_REQUIRE(n_batch >= 0 && n_inner >= 0 && kn >= 0, "negative extent");
     FV3HIP_REQUIRE(iv >= -2 && iv <= 2, "iv must be in [-2, 2], got %d", iv);
@@ -1193,6 +1195,8 @@ extern "C" int fv3hip_mappm(const void *pe1, const void *q1, const void *pe2, in
     // up on through the sequential routine; kord == 7 (Huynh's constraint needs a wider stencil)
     // goes through the sequential routine directly
     const bool fast = (kord <= 6);
+    // the sweep kernel (remap.hip) where it applies: native layout, kord <= 3, whole waves per batch plane
+    const bool sweep = mappm_sweep_eligible(n_inner, km, kn, kord, layout, in_dtype);
     for (int64_t col0 = 0; col0 < ncol; col0 += kMappmChunk) {
         const int64_t col_end = (col0 + kMappmChunk < ncol) ? col0 + kMappmChunk : ncol;
         const int64_t blocks = ceil_div(col_end - col0, 256);
@@ -1200,10 +1204,27 @@ extern "C" int fv3hip_mappm(const void *pe1, const void *q1, const void *pe2, in
             FV3HIP_CHECK_HIP(hipMemsetAsync(n_bad, 0, 16, st));
             const int64_t fb_threads = (col_end - col0 < kFallbackSlots) ? (col_end - col0) : kFallbackSlots;
             const int64_t fb_blocks = ceil_div(fb_threads, 256);
+            if (sweep) {
+                SweepArgs sa;
+                memset(&sa, 0, sizeof(sa));
+                sa.pe1 = pe1;
+                sa.pe2 = pe2;
+                sa.q1[0] = q1;
+                sa.q2[0] = q2;
+                sa.col0 = col0;
+                sa.n_inner = n_inner;
+                sa.km = km;
+                sa.kn = kn;
+                sa.iv = iv;
+                sa.n_bad = n_bad;
+                sa.bad_cols = bad_cols;
+                mappm_sweep_launch(sa, 1, in_dtype, col_end, arith == FV3HIP_ARITH_FAST, st);
+            }
 #define LAUNCH_(T)                                                                                       \
-    hipLaunchKernelGGL((mappm_merge_kernel<T>), dim3((unsigned)blocks), dim3(256), 0, st,                \
-                       static_cast<const T *>(pe1), static_cast<const T *>(q1), static_cast<const T *>(pe2), \
-                       q2, col0, col_end, n_inner, km, kn, iv, kord, layout, n_bad, bad_cols);           \
+    if (!sweep)                                                                                          \
+        hipLaunchKernelGGL((mappm_merge_kernel<T>), dim3((unsigned)blocks), dim3(256), 0, st,            \
+                           static_cast<const T *>(pe1), static_cast<const T *>(q1), static_cast<const T *>(pe2), \
+                           q2, col0, col_end, n_inner, km, kn, iv, kord, layout, n_bad, bad_cols);       \
     hipLaunchKernelGGL((mappm_fallback_kernel<T>), dim3((unsigned)fb_blocks), dim3(256), 0, st,          \
                        static_cast<const T *>(pe1), static_cast<const T *>(q1), static_cast<const T *>(pe2), \
                        q2, col0, n_inner, km, kn, iv, kord, layout, n_bad, bad_cols, planes, ws_cols)
@@ -1236,14 +1257,15 @@ void launch_merge_multi(const void *pe1, const MultiFieldPtrs &fp, const void *p
 
 extern "C" int fv3hip_mappm_multi(const void *pe1, const void *const *q1, const void *pe2, int in_dtype, float *const *q2,
                                   int n_fields, int64_t n_batch, int64_t n_inner, int km, int kn, int iv, int kord, int layout,
-                                  void *workspace, size_t workspace_bytes, void *stream)
+                                  int arith, void *workspace, size_t workspace_bytes, void *stream)
 {
+    FV3HIP_REQUIRE(arith == FV3HIP_ARITH_EXACT || arith == FV3HIP_ARITH_FAST, "unknown arithmetic mode %d", arith);
     FV3HIP_REQUIRE(n_fields >= 0, "negative field count");
     if (n_fields == 0) return FV3HIP_OK;
     FV3HIP_REQUIRE(q1 && q2, "null pointer");
     if (kord > 6 || n_fields == 1) {  // kord 7 needs the sequential routine (and kord > 7 is refused there)
         for (int f = 0; f < n_fields; ++f) {
-            const int rc = fv3hip_mappm(pe1, q1[f], pe2, in_dtype, q2[f], n_batch, n_inner, km, kn, iv, kord, layout, workspace,
+            const int rc = fv3hip_mappm(pe1, q1[f], pe2, in_dtype, q2[f], n_batch, n_inner, km, kn, iv, kord, layout, arith, workspace,
                                         workspace_bytes, stream);
             if (rc) return rc;
         }
@@ -1278,8 +1300,27 @@ extern "C" int fv3hip_mappm_multi(const void *pe1, const void *const *q1, const 
                 fp.q2[f] = f < nf ? q2[f0 + f] : nullptr;
             }
             FV3HIP_CHECK_HIP(hipMemsetAsync(n_bad, 0, 16, st));
+            const bool sweep = mappm_sweep_eligible(n_inner, km, kn, kord, layout, in_dtype);
+            if (sweep) {
+                SweepArgs sa;
+                memset(&sa, 0, sizeof(sa));
+                sa.pe1 = pe1;
+                sa.pe2 = pe2;
+                for (int f = 0; f < nf; ++f) {
+                    sa.q1[f] = fp.q1[f];
+                    sa.q2[f] = fp.q2[f];
+                }
+                sa.col0 = col0;
+                sa.n_inner = n_inner;
+                sa.km = km;
+                sa.kn = kn;
+                sa.iv = iv;
+                sa.n_bad = n_bad;
+                sa.bad_cols = bad_cols;
+                mappm_sweep_launch(sa, nf, in_dtype, col_end, arith == FV3HIP_ARITH_FAST, st);
+            }
 #define LAUNCH_(T)                                                                                                          \
-    switch (nf) {                                                                                                           \
+    if (!sweep) switch (nf) {                                                                                               \
         case 1: launch_merge_multi<T, 1>(pe1, fp, pe2, col0, col_end, n_inner, km, kn, iv, kord, layout, n_bad, bad_cols, st); break; \
         case 2: launch_merge_multi<T, 2>(pe1, fp, pe2, col0, col_end, n_inner, km, kn, iv, kord, layout, n_bad, bad_cols, st); break; \
         case 3: launch_merge_multi<T, 3>(pe1, fp, pe2, col0, col_end, n_inner, km, kn, iv, kord, layout, n_bad, bad_cols, st); break; \

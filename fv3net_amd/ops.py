@@ -6,6 +6,7 @@ memory and the stream; no torch kernel does any of the arithmetic.  There is no 
 tensors must live on a ``cuda`` (ROCm) device.
 """
 import ctypes
+import os
 import math
 from typing import Optional, Sequence
 
@@ -446,12 +447,27 @@ _workspaces = {}
 
 
 def _workspace(dev, nbytes: int) -> torch.Tensor:
-    key = (dev.type, dev.index)
+    """Scratch of the remap, one per (device, HIP stream): it holds a call's list of columns to redo and the fallback
+    planes, so calls on different streams must not share it.  A grown workspace replaces the old tensor only for its own
+    stream, whose earlier launches are ordered before the new ones."""
+    key = (dev.type, dev.index, torch.cuda.current_stream(dev).cuda_stream)
     ws = _workspaces.get(key)
     if ws is None or ws.numel() < nbytes:
         ws = torch.empty(max(nbytes, 1), dtype=torch.uint8, device=dev)
         _workspaces[key] = ws
     return ws
+
+
+# Arithmetic of the remap when a call does not say: "fast" (reciprocal-multiply in the sweep kernel, a few ulp from the
+# reference's IEEE divisions -- inside the north star's 1e-5) or "exact" (bit-identical to the compiled Fortran).
+MAPPM_ARITHMETIC = os.environ.get("FV3NET_AMD_MAPPM_ARITH", "fast")
+
+
+def _arith_code(arith: Optional[str]) -> int:
+    mode = MAPPM_ARITHMETIC if arith is None else arith
+    if mode not in ("exact", "fast"):
+        raise ValueError(f"arith must be 'exact' or 'fast', got {mode!r}")
+    return _lib.ARITH_FAST if mode == "fast" else _lib.ARITH_EXACT
 
 
 def mappm(
@@ -461,8 +477,10 @@ def mappm(
     iv: int = 1,
     kord: int = 1,
     z_axis: int = -1,
+    arith: Optional[str] = None,
 ) -> torch.Tensor:
     """PPM vertical remap of ``q1`` from interface pressures ``pe1`` to ``pe2`` (mappm.f90).
+    ``arith``: "exact" | "fast" (default: ``ops.MAPPM_ARITHMETIC``), see ``FV3HIP_ARITH_*`` in include/fv3hip.h.
     ``z_axis`` is the level axis of all three arrays (km+1, km, kn+1 levels); the other dims
     must match.  ``z_axis=-1`` is the [column, level] layout f2py callers use; any other
     position is handled in place as the native [.., level, .. columns ..] layout.
@@ -496,13 +514,13 @@ def mappm(
     ws = _workspace(dev, nbytes)
     _lib.call(
         "fv3hip_mappm", _ptr(pe1), _ptr(q1), _ptr(pe2), _float_code(q1), _ptr(out), nb, ni, km, kn,
-        int(iv), int(kord), layout, _ptr(ws), ws.numel(), _stream(dev),
+        int(iv), int(kord), layout, _arith_code(arith), _ptr(ws), ws.numel(), _stream(dev),
     )
     return out
 
 
 def mappm_multi(pe1: torch.Tensor, fields: Sequence[torch.Tensor], pe2: torch.Tensor, iv: int = 1, kord: int = 1,
-                z_axis: int = -1) -> list:
+                z_axis: int = -1, arith: Optional[str] = None) -> list:
     """``mappm`` of several fields that share ``pe1`` and ``pe2`` (every variable of a dataset in
     regridz.py:163-185): one sweep per four fields computes the control flow and the pressure-only terms
     once.  Each result is bit-identical to ``mappm`` on that field."""
@@ -540,7 +558,7 @@ def mappm_multi(pe1: torch.Tensor, fields: Sequence[torch.Tensor], pe2: torch.Te
     q_ptrs = (ctypes.c_void_p * n)(*[q.data_ptr() for q in fields])
     o_ptrs = (ctypes.c_void_p * n)(*[o.data_ptr() for o in outs])
     _lib.call("fv3hip_mappm_multi", _ptr(pe1), q_ptrs, _ptr(pe2), _float_code(q1), o_ptrs, n, nb, ni, km, kn, int(iv), int(kord),
-              layout, _ptr(ws), ws.numel(), _stream(dev))
+              layout, _arith_code(arith), _ptr(ws), ws.numel(), _stream(dev))
     return outs
 
 

@@ -29,7 +29,7 @@
 extern "C" {
 #endif
 
-#define FV3HIP_ABI_VERSION 1
+#define FV3HIP_ABI_VERSION 2
 
 /* status codes */
 #define FV3HIP_OK 0
@@ -57,6 +57,11 @@ extern "C" {
 #define FV3HIP_NAN_PROPAGATE 1 /* numpy.sum/mean/min/max/median (NaN if any NaN in the window);
                                   scipy.stats.mode(nan_policy="propagate")                   */
 #define FV3HIP_NAN_OMIT 2      /* scipy.stats.mode(nan_policy="omit")                        */
+
+/* arithmetic of the remap (fv3hip_mappm, fv3hip_mappm_multi) */
+#define FV3HIP_ARITH_EXACT 0 /* IEEE division, the Fortran's association order: bit-identical to the compiled reference */
+#define FV3HIP_ARITH_FAST 1  /* a / b = a * v_rcp_f32(b) with shared reciprocals where the sweep kernel applies (LEVEL_COL,
+                                kord <= 3, km >= 8, n_inner % 64 == 0); a few ulp from EXACT; elsewhere the same as EXACT */
 
 /* column layouts (fv3hip_mappm, fv3hip_pressure_at_interface) */
 #define FV3HIP_LAYOUT_COL_LEVEL 0 /* [column][level]: level fastest (what f2py callers pass)  */
@@ -223,11 +228,13 @@ int fv3hip_mask_weights(const void *weights, int w_dtype, const void *p_cmp, int
  *              (n_batch = ncol, n_inner = 1)
  *   LEVEL_COL: pe1 [n_batch][km+1][n_inner], ... ; ncol = n_batch * n_inner
  * kord <= 7 only (ppm_profile); kord > 7 (cs_profile) returns FV3HIP_EUNSUPPORTED.
- * `workspace` must hold fv3hip_mappm_workspace_bytes(...) bytes of device memory.
+ * `arith`: FV3HIP_ARITH_EXACT or FV3HIP_ARITH_FAST (see above).
+ * `workspace` must hold fv3hip_mappm_workspace_bytes(...) bytes of device memory; it carries the call's
+ * list of columns to redo, so concurrent calls (other streams) need workspaces of their own.
  */
 size_t fv3hip_mappm_workspace_bytes(int64_t ncol, int km);
 int fv3hip_mappm(const void *pe1, const void *q1, const void *pe2, int in_dtype, float *q2,
-                 int64_t n_batch, int64_t n_inner, int km, int kn, int iv, int kord, int layout,
+                 int64_t n_batch, int64_t n_inner, int km, int kn, int iv, int kord, int layout, int arith,
                  void *workspace, size_t workspace_bytes, void *stream);
 
 /*
@@ -238,7 +245,7 @@ int fv3hip_mappm(const void *pe1, const void *q1, const void *pe2, int in_dtype,
  */
 int fv3hip_mappm_multi(const void *pe1, const void *const *q1, const void *pe2, int in_dtype,
                        float *const *q2, int n_fields, int64_t n_batch, int64_t n_inner, int km,
-                       int kn, int iv, int kord, int layout, void *workspace,
+                       int kn, int iv, int kord, int layout, int arith, void *workspace,
                        size_t workspace_bytes, void *stream);
 
 /* ------------------------------------------------------------------------------------------
