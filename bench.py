@@ -394,7 +394,8 @@ def secondary_benchmarks(dev, steps):
     })
     del qs
     # (the secondary workloads never cost the headline line: a failure is recorded in place of the numbers)
-    for fn, fn_args in ((dense_local_benchmark, (dev, steps)), (streaming_benchmark, (dev,)), (restart_pipeline_benchmark, (dev,))):
+    for fn, fn_args in ((dense_local_benchmark, (dev, steps)), (streaming_benchmark, (dev,)), (restart_pipeline_benchmark, (dev,)),
+                        (io_pipeline_benchmark, (dev,))):
         try:
             out.extend(fn(*fn_args))
         except Exception as err:  # noqa: BLE001
@@ -463,6 +464,42 @@ def restart_pipeline_benchmark(dev, n=384, f=8, reps=3, tiles=tuple(range(6)), w
                                  "frac": nbytes / ms / 1e6 / PEAK_HBM_GBPS, "traffic": None,
                                  "note": "input bytes / wall time"}})
     return out
+
+
+def io_pipeline_benchmark(dev, n=384, f=8):
+    """SURVEY 8f rank 4 end to end: synthetic C384 diagnostics written as the model writes them (6 tiles x 16 sub-tile
+    netCDF classic files, coarsen.py:27) -> pinned host buffers -> device block average -> coarse zarr store.  File I/O
+    included, so never the headline; the reads of tile t + 1 overlap the device work of tile t."""
+    import shutil
+    import tempfile
+
+    from fv3net_amd.io import coarsen_subtile_files_to_zarr, netcdf
+
+    root = tempfile.mkdtemp(prefix="fv3net_amd_io_")
+    try:
+        rng = np.random.default_rng(7)
+        area = rng.uniform(0.5, 1, (6, n, n)).astype(np.float32)
+        prefix = os.path.join(root, "atmos_8xdaily")
+        t0 = time.perf_counter()
+        for tile in range(1, 7):
+            netcdf.write_subtile_files(prefix, tile, {
+                "T": (["time", "pfull", "yaxis_1", "xaxis_1"], rng.standard_normal((1, NZ, n, n), dtype=np.float32)),
+                "PRATEsfc": (["time", "yaxis_1", "xaxis_1"], rng.standard_normal((1, n, n), dtype=np.float32))}, layout=(4, 4))
+        t_make = time.perf_counter() - t0
+        coarsen_subtile_files_to_zarr(prefix, os.path.join(root, "warm.zarr"), area, f)  # page cache + pinned pools warm
+        t0 = time.perf_counter()
+        st = coarsen_subtile_files_to_zarr(prefix, os.path.join(root, "coarse.zarr"), area, f)
+        wall = time.perf_counter() - t0
+        return [{
+            "kernel": "sub-tile netCDF files -> pinned -> weighted_block_average -> zarr (fv3net_amd.io.coarsen_subtile_files_to_zarr)",
+            "workload": f"C{n}->C{n // f}: 96 classic-netCDF sub-tile files, {st['bytes_in'] / 1e6:.0f} MB in (page cache warm), "
+                        f"{st['bytes_out'] / 1e6:.1f} MB of uncompressed zarr out; synthetic files took {t_make:.1f} s to write",
+            "ms": wall * 1e3, "read_ms": st["read_s"] * 1e3, "device_ms_incl_transfers": st["device_s"] * 1e3, "write_ms": st["write_s"] * 1e3,
+            "GBps_end_to_end": st["bytes_in"] / wall / 1e9,
+            "roofline": {"bound": "file I/O", "achieved": None, "peak": None, "unit": "GB/s", "frac": None, "traffic": None},
+        }]
+    finally:
+        shutil.rmtree(root, ignore_errors=True)
 
 
 def streaming_benchmark(dev, n_snapshots=24):

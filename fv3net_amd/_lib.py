@@ -88,6 +88,10 @@ SIGNATURES = {
         c_int,
         [c_void_p, c_int, c_void_p, c_int, c_int64, c_int, c_int, c_int64, c_int, c_void_p, c_void_p],
     ),
+    "fv3hip_mass_weighted_block_average": (
+        c_int,
+        [c_void_p, c_int, c_int, c_void_p, c_void_p, c_int, c_int64, c_int, c_int, c_int64, c_int, c_void_p, c_void_p],
+    ),
     "fv3hip_edge_weighted_block_average": (
         c_int,
         [c_void_p, c_int, c_void_p, c_int, c_int64, c_int, c_int, c_int64, c_int, c_int, c_void_p, c_void_p],
@@ -199,3 +203,16 @@ def check(code):
 def call(name, *args):
     """Call an int-returning entry point and raise Fv3HipError on a non-zero status."""
     check(getattr(load(), name)(*args))
+
+
+def call_on(where, name, *args):
+    """``call`` with the HIP device of ``where`` (a torch device or tensor) current for the duration of the call, and the
+    caller's device restored afterwards: the library launches on, and allocates its scratch on, the current device."""
+    import torch
+
+    dev = where.device if isinstance(where, torch.Tensor) else where
+    idx = None if dev is None else torch.device(dev).index
+    if idx is None or idx == torch.cuda.current_device():
+        return call(name, *args)
+    with torch.cuda.device(idx):
+        return call(name, *args)

@@ -31,7 +31,9 @@ extern "C" int fv3hip_init(int device)
     int n = 0;
     FV3HIP_CHECK_HIP(hipGetDeviceCount(&n));
     FV3HIP_REQUIRE(device >= 0 && device < n, "device %d out of range (%d visible)", device, n);
-    FV3HIP_CHECK_HIP(hipSetDevice(device));
+    // (a query only: the caller's current device is not changed.  Every other entry point works on the CURRENT device --
+    // launches, scratch allocations -- so callers make the device of their pointers current around a call, as
+    // fv3net_amd/_lib.py:call_on does.)
     hipDeviceProp_t prop;
     FV3HIP_CHECK_HIP(hipGetDeviceProperties(&prop, device));
     if (strncmp(prop.gcnArchName, "gfx950", 6) != 0)

@@ -199,6 +199,185 @@ __global__ __launch_bounds__(256) void wavg_block_kernel(
     }
 }
 
+// ---------------------------------------------------------------------------------------
+// Mass-weighted block average of NF fields that share their weights delp * area
+// (coarsen_restarts.py:335-427, 856-900: W, T, ua, va and the eight non-fraction tracers are averaged with the
+// weights `delp * area`).  The product is formed in registers -- never materialised -- and read once for up to
+// four fields: per launch the traffic is delp + NF fields (+ the 2-D area once per z-chunk) instead of
+// NF x (field + a materialised 3-D weight).  Arithmetic as the reference's: w = delp * area in the promoted type,
+// numerator nansum(obj * w), denominator nansum(w) in the weights' (promoted) type.
+// ---------------------------------------------------------------------------------------
+constexpr int kMassFields = 4;
+struct MassFieldPtrs {
+    const void *obj[kMassFields];
+    void *out[kMassFields];
+};
+
+template <typename Tf, typename Ta, int F, int NF>
+__global__ __launch_bounds__(256) void mass_wavg_block_kernel(
+    const MassFieldPtrs fp, const Tf *__restrict__ delp, const Ta *__restrict__ area, int64_t n_outer, int ny, int nx,
+    int64_t a_repeat, int zsplit, int64_t n_gy)
+{
+    using P = typename Promote<Tf, Ta>::type;
+    constexpr int VEC = 16 / sizeof(P);
+    constexpr int LPB = (F >= VEC) ? F / VEC : 1;
+    constexpr int BPL = (F >= VEC) ? 1 : VEC / F;
+    constexpr int EPB = VEC / BPL;
+
+    const int XV = nx / VEC;
+    const int nyo = ny / F, nxo = nx / F;
+    const int64_t S = (int64_t)nyo * XV;
+    const int64_t s = blockIdx.x * (int64_t)blockDim.x + threadIdx.x;
+    const bool active = s < S;
+    const int Y = active ? (int)(s / XV) : 0;
+    const int xv = active ? (int)(s % XV) : 0;
+    const int64_t sp = (int64_t)Y * F * nx + (int64_t)xv * VEC;
+    const int64_t slice = (int64_t)ny * nx;
+    const int64_t zper = (a_repeat + zsplit - 1) / zsplit;
+
+    for (int64_t gy = blockIdx.y; gy < n_gy; gy += gridDim.y) {
+        const int64_t g = gy / zsplit;
+        const int part = (int)(gy % zsplit);
+        const int64_t o_begin = g * a_repeat + part * zper;
+        int64_t o_end = o_begin + zper;
+        if (o_end > (g + 1) * a_repeat) o_end = (g + 1) * a_repeat;
+        if (o_end > n_outer) o_end = n_outer;
+        // the block's area stays in registers over the levels that share it
+        P areg[F][VEC];
+#pragma unroll
+        for (int dy = 0; dy < F; ++dy) {
+            Vec<Ta, VEC> av;
+            if (active) {
+                av = *reinterpret_cast<const Vec<Ta, VEC> *>(area + g * slice + sp + (int64_t)dy * nx);
+            } else {
+#pragma unroll
+                for (int e = 0; e < VEC; ++e) av[e] = 0;
+            }
+#pragma unroll
+            for (int e = 0; e < VEC; ++e) areg[dy][e] = (P)av[e];
+        }
+        for (int64_t o = o_begin; o < o_end; ++o) {
+            P wreg[F][VEC];
+            P den[BPL];
+#pragma unroll
+            for (int b = 0; b < BPL; ++b) den[b] = 0;
+#pragma unroll
+            for (int dy = 0; dy < F; ++dy) {
+                Vec<Tf, VEC> dv;
+                if (active) {
+                    dv = __builtin_nontemporal_load(reinterpret_cast<const Vec<Tf, VEC> *>(delp + o * slice + sp + (int64_t)dy * nx));
+                } else {
+#pragma unroll
+                    for (int e = 0; e < VEC; ++e) dv[e] = 0;
+                }
+#pragma unroll
+                for (int e = 0; e < VEC; ++e) {
+                    const P w0 = (P)dv[e] * areg[dy][e];
+                    wreg[dy][e] = w0;
+                    den[e / EPB] += is_nan(w0) ? (P)0 : w0;
+                }
+            }
+#pragma unroll
+            for (int m = 1; m < LPB; m <<= 1) den[0] += __shfl_xor(den[0], m);
+#pragma unroll
+            for (int f = 0; f < NF; ++f) {
+                const Tf *po = static_cast<const Tf *>(fp.obj[f]) + o * slice + sp;
+                Vec<Tf, VEC> ov[F];
+#pragma unroll
+                for (int dy = 0; dy < F; ++dy) {
+                    if (active) {
+                        ov[dy] = __builtin_nontemporal_load(reinterpret_cast<const Vec<Tf, VEC> *>(po + (int64_t)dy * nx));
+                    } else {
+#pragma unroll
+                        for (int e = 0; e < VEC; ++e) ov[dy][e] = 0;
+                    }
+                }
+                P num[BPL];
+#pragma unroll
+                for (int b = 0; b < BPL; ++b) num[b] = 0;
+#pragma unroll
+                for (int dy = 0; dy < F; ++dy) {
+#pragma unroll
+                    for (int e = 0; e < VEC; ++e) {
+                        const P p = (P)ov[dy][e] * wreg[dy][e];
+                        num[e / EPB] += is_nan(p) ? (P)0 : p;
+                    }
+                }
+#pragma unroll
+                for (int m = 1; m < LPB; m <<= 1) num[0] += __shfl_xor(num[0], m);
+                if (active && (xv % LPB) == 0) {
+                    P *dst = static_cast<P *>(fp.out[f]) + (o * nyo + Y) * (int64_t)nxo + (int64_t)(xv / LPB) * BPL;
+                    if (BPL == 1) {
+                        dst[0] = num[0] / den[0];
+                    } else {
+                        Vec<P, BPL> r;
+#pragma unroll
+                        for (int b = 0; b < BPL; ++b) r[b] = num[b] / den[b];
+                        *reinterpret_cast<Vec<P, BPL> *>(dst) = r;
+                    }
+                }
+            }
+        }
+    }
+}
+
+template <typename Tf, typename Ta, int F>
+int launch_mass_wavg(const MassFieldPtrs &fp, int nf, const Tf *delp, const Ta *area, int64_t n_outer, int ny, int nx,
+                     int64_t a_repeat, hipStream_t stream)
+{
+    using P = typename Promote<Tf, Ta>::type;
+    constexpr int VEC = 16 / sizeof(P);
+    const int64_t S = (int64_t)(ny / F) * (nx / VEC);
+    const int64_t n_groups = n_outer / a_repeat;
+    const int64_t gx = ceil_div(S, 256);
+    int zsplit = 1;
+    const int64_t want_blocks = 256 * 16;
+    while (gx * n_groups * zsplit < want_blocks && (a_repeat / (zsplit * 2)) >= 4) zsplit *= 2;
+    const int64_t n_gy = n_groups * zsplit;
+    dim3 grid((unsigned)gx, (unsigned)(n_gy < 65535 ? n_gy : 65535));
+    switch (nf) {
+        case 1: hipLaunchKernelGGL((mass_wavg_block_kernel<Tf, Ta, F, 1>), grid, dim3(256), 0, stream, fp, delp, area, n_outer, ny, nx, a_repeat, zsplit, n_gy); break;
+        case 2: hipLaunchKernelGGL((mass_wavg_block_kernel<Tf, Ta, F, 2>), grid, dim3(256), 0, stream, fp, delp, area, n_outer, ny, nx, a_repeat, zsplit, n_gy); break;
+        case 3: hipLaunchKernelGGL((mass_wavg_block_kernel<Tf, Ta, F, 3>), grid, dim3(256), 0, stream, fp, delp, area, n_outer, ny, nx, a_repeat, zsplit, n_gy); break;
+        default: hipLaunchKernelGGL((mass_wavg_block_kernel<Tf, Ta, F, 4>), grid, dim3(256), 0, stream, fp, delp, area, n_outer, ny, nx, a_repeat, zsplit, n_gy); break;
+    }
+    return check_launch("mass_wavg_block_kernel");
+}
+
+template <typename Tf, typename Ta>
+int dispatch_mass_wavg(const void *const *fields, int n_fields, const void *delp_, const void *area_, int64_t n_outer, int ny,
+                       int nx, int64_t a_repeat, int factor, void *const *outs, hipStream_t stream)
+{
+    using P = typename Promote<Tf, Ta>::type;
+    constexpr int VEC = 16 / sizeof(P);
+    const Tf *delp = static_cast<const Tf *>(delp_);
+    const Ta *area = static_cast<const Ta *>(area_);
+    bool ok = (nx % VEC == 0) && (reinterpret_cast<uintptr_t>(delp) % (sizeof(Tf) * VEC) == 0) &&
+              (reinterpret_cast<uintptr_t>(area) % (sizeof(Ta) * VEC) == 0);
+    for (int f = 0; f < n_fields && ok; ++f)
+        ok = (reinterpret_cast<uintptr_t>(fields[f]) % (sizeof(Tf) * VEC) == 0) && (reinterpret_cast<uintptr_t>(outs[f]) % 16 == 0);
+    if (!ok || !(factor == 2 || factor == 4 || factor == 8 || factor == 16))
+        return fail(FV3HIP_EUNSUPPORTED, "fused mass-weighted average needs factor in {2, 4, 8, 16}, nx %% %d == 0 and 16-byte aligned arrays",
+                    VEC);
+    for (int f0 = 0; f0 < n_fields; f0 += kMassFields) {
+        const int nf = (n_fields - f0 < kMassFields) ? n_fields - f0 : kMassFields;
+        MassFieldPtrs fp;
+        for (int f = 0; f < kMassFields; ++f) {
+            fp.obj[f] = f < nf ? fields[f0 + f] : nullptr;
+            fp.out[f] = f < nf ? outs[f0 + f] : nullptr;
+        }
+        int rc;
+        switch (factor) {
+            case 2: rc = launch_mass_wavg<Tf, Ta, 2>(fp, nf, delp, area, n_outer, ny, nx, a_repeat, stream); break;
+            case 4: rc = launch_mass_wavg<Tf, Ta, 4>(fp, nf, delp, area, n_outer, ny, nx, a_repeat, stream); break;
+            case 8: rc = launch_mass_wavg<Tf, Ta, 8>(fp, nf, delp, area, n_outer, ny, nx, a_repeat, stream); break;
+            default: rc = launch_mass_wavg<Tf, Ta, 16>(fp, nf, delp, area, n_outer, ny, nx, a_repeat, stream); break;
+        }
+        if (rc) return rc;
+    }
+    return FV3HIP_OK;
+}
+
 template <typename To, typename Tw, int F>
 int launch_wavg_block(const To *obj, const Tw *w, void *out, int64_t n_outer, int ny, int nx,
                       int64_t w_repeat, hipStream_t stream)
@@ -645,6 +824,32 @@ extern "C" int fv3hip_weighted_block_average(const void *obj, int obj_dtype, con
                    nx, factor);
     return wavg_entry(obj, obj_dtype, weights, w_dtype, n_outer, ny, nx, w_repeat, factor, factor,
                       factor, factor, out, stream);
+}
+
+extern "C" int fv3hip_mass_weighted_block_average(const void *const *fields, int n_fields, int dtype, const void *delp,
+                                                  const void *area, int area_dtype, int64_t n_outer, int ny, int nx,
+                                                  int64_t a_repeat, int factor, void *const *outs, void *stream)
+{
+    FV3HIP_REQUIRE(n_fields >= 0, "negative field count");
+    if (n_fields == 0) return FV3HIP_OK;
+    FV3HIP_REQUIRE(dtype == FV3HIP_F32 || dtype == FV3HIP_F64, "dtype must be F32 or F64, got %d", dtype);
+    FV3HIP_REQUIRE(area_dtype == FV3HIP_F32 || area_dtype == FV3HIP_F64, "area dtype must be F32 or F64, got %d", area_dtype);
+    FV3HIP_REQUIRE(factor >= 1 && n_outer >= 0 && ny >= 0 && nx >= 0, "bad extents");
+    FV3HIP_REQUIRE(ny % factor == 0 && nx % factor == 0, "horizontal extents (%d, %d) are not multiples of the coarsening factor %d",
+                   ny, nx, factor);
+    FV3HIP_REQUIRE(a_repeat >= 1 && n_outer % a_repeat == 0, "n_outer (%lld) is not a multiple of a_repeat (%lld)",
+                   (long long)n_outer, (long long)a_repeat);
+    if (n_outer == 0 || ny == 0 || nx == 0) return FV3HIP_OK;
+    FV3HIP_REQUIRE(fields && outs && delp && area, "null pointer");
+    for (int f = 0; f < n_fields; ++f) FV3HIP_REQUIRE(fields[f] && outs[f], "null field pointer");
+    hipStream_t st = as_stream(stream);
+    if (dtype == FV3HIP_F32 && area_dtype == FV3HIP_F32)
+        return dispatch_mass_wavg<float, float>(fields, n_fields, delp, area, n_outer, ny, nx, a_repeat, factor, outs, st);
+    if (dtype == FV3HIP_F64 && area_dtype == FV3HIP_F64)
+        return dispatch_mass_wavg<double, double>(fields, n_fields, delp, area, n_outer, ny, nx, a_repeat, factor, outs, st);
+    if (dtype == FV3HIP_F64 && area_dtype == FV3HIP_F32)
+        return dispatch_mass_wavg<double, float>(fields, n_fields, delp, area, n_outer, ny, nx, a_repeat, factor, outs, st);
+    return dispatch_mass_wavg<float, double>(fields, n_fields, delp, area, n_outer, ny, nx, a_repeat, factor, outs, st);
 }
 
 extern "C" int fv3hip_edge_weighted_block_average(const void *obj, int obj_dtype,

@@ -1421,6 +1421,12 @@ extern "C" int fv3hip_mlp_predict(fv3hip_mlp_t m, const void *const *sources, co
     FV3HIP_REQUIRE(m, "null model handle");
     FV3HIP_REQUIRE(n_samples >= 0, "negative n_samples");
     if (n_samples == 0) return FV3HIP_OK;
+    {   // the model's tables (and the scratch row this call may grow) live on the device it was created on
+        int cur = -1;
+        FV3HIP_CHECK_HIP(hipGetDevice(&cur));
+        FV3HIP_REQUIRE(cur == m->device, "the model lives on device %d but the current device is %d: make the model's "
+                       "device current around fv3hip_mlp_predict", m->device, cur);
+    }
     FV3HIP_REQUIRE(sources && src_dtype && src_feat_stride && src_sample_stride && outputs &&
                        out_feat_stride && out_sample_stride, "null pointer");
     FV3HIP_REQUIRE(out_dtype == FV3HIP_F32 || out_dtype == FV3HIP_F64, "out_dtype must be F32 or F64");

@@ -7,6 +7,7 @@ Same function names, argument meaning and error behaviour as the reference; obje
 from typing import Callable, Dict, Hashable, List, Mapping, Optional, Union
 
 import numpy as np
+import torch
 
 from .. import ops
 from ..xr_compat import DataArray, Dataset, from_compat, to_compat
@@ -153,6 +154,52 @@ def weighted_block_average(
         o, lambda da: _weighted_block_average_da(da, w, coarsening_factor, x_dim, y_dim, coord_func)
     )
     return from_compat(_propagate_attrs(o, result), obj)
+
+
+def mass_weighted_block_average(
+    obj,
+    delp,
+    area,
+    coarsening_factor: int,
+    x_dim: Hashable = "xaxis_1",
+    y_dim: Hashable = "yaxis_2",
+    coord_func: CoordFunc = coarsen_coords_coord_func,
+):
+    """``weighted_block_average(obj, delp * area, ...)`` -- what the restart pipelines do for W, T, ua, va and the
+    non-fraction tracers (coarsen_restarts.py:384-396, 884-891) -- without materialising ``delp * area``: variables that
+    share ``delp``'s dims and dtype go through the fused kernel four at a time (``ops.mass_weighted_block_average``), any
+    other variable through the product and ``weighted_block_average``.  Same results either way."""
+    o, d, a = to_compat(obj), to_compat(delp), to_compat(area)
+    single = isinstance(o, DataArray)
+    ds = Dataset({o.name or "field": o}) if single else o
+    out = Dataset(attrs=ds.attrs)
+    fused = [n for n, da in ds.items() if da.dims == d.dims and da.dtype == d.dtype and da.shape == d.shape
+             and x_dim in da.dims and y_dim in da.dims]
+    if fused:
+        dt, outer = horizontal_last(d, y_dim, x_dim)
+        w = _weights_tensor(a, outer, y_dim, x_dim, "area")
+        if dt.dtype in (torch.float32, torch.float64) and w.dim() <= dt.dim():
+            tensors = [horizontal_last(ds[n], y_dim, x_dim)[0] for n in fused]
+            results = ops.mass_weighted_block_average(tensors, dt, w, coarsening_factor)
+            for n, res in zip(fused, results):
+                da = ds[n]
+                r = DataArray(like_input(res, da.data), dims=tuple(outer) + (y_dim, x_dim), name=da.name, attrs=da.attrs,
+                              coords=_coarsened_coords(da, {x_dim: coarsening_factor, y_dim: coarsening_factor}, coord_func))
+                out[n] = r.transpose(*da.dims)
+        else:
+            fused = []
+    rest = [n for n in ds if n not in fused]
+    if rest:
+        from .coarsen_restarts import _mul  # (the product kernel; import here: coarsen_restarts imports this module)
+
+        weights = _mul(d, a)
+        for n in rest:
+            out[n] = _weighted_block_average_da(ds[n], to_compat(weights), coarsening_factor, x_dim, y_dim, coord_func)
+    ordered = Dataset(attrs=ds.attrs)
+    for n in ds:
+        ordered[n] = out[n]
+    result = _propagate_attrs(ds, ordered)
+    return from_compat(result[o.name or "field"] if single else result, obj)
 
 
 def _coarsen_downsample_coordinate(reference: DataArray, dim, factor, coord_func):

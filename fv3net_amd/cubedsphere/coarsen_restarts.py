@@ -13,7 +13,8 @@ from typing import Hashable, Mapping
 from .. import ops
 from ..xr_compat import DataArray, Dataset, from_compat, merge, to_compat
 from ._device import like_input, on_device
-from .coarsen import block_coarsen, block_edge_coarsen, edge_weighted_block_average, weighted_block_average
+from .coarsen import (block_coarsen, block_edge_coarsen, edge_weighted_block_average, mass_weighted_block_average,
+                      weighted_block_average)
 from .constants import (
     COORD_X_CENTER,
     COORD_X_OUTER,
@@ -70,8 +71,8 @@ def _coarse_grain_fv_core(ds, delp, area, dx, dy, coarsening_factor, coarsen_agr
         (mass_weighted_vars if mass_weighted else area_weighted_vars).extend(["ua", "va"])
     parts = [weighted_block_average(ds[area_weighted_vars], area, coarsening_factor, x_dim=FV_CORE_X_CENTER, y_dim=FV_CORE_Y_CENTER)]
     if mass_weighted_vars:
-        parts.append(weighted_block_average(ds[mass_weighted_vars], _mul(delp, area), coarsening_factor,
-                                            x_dim=FV_CORE_X_CENTER, y_dim=FV_CORE_Y_CENTER))
+        parts.append(mass_weighted_block_average(ds[mass_weighted_vars], delp, area, coarsening_factor,
+                                                 x_dim=FV_CORE_X_CENTER, y_dim=FV_CORE_Y_CENTER))
     parts.append(edge_weighted_block_average(ds[["u"]], dx, coarsening_factor, x_dim=FV_CORE_X_CENTER, y_dim=FV_CORE_Y_OUTER, edge="x"))
     parts.append(edge_weighted_block_average(ds[["v"]], dy, coarsening_factor, x_dim=FV_CORE_X_OUTER, y_dim=FV_CORE_Y_CENTER, edge="y"))
     return merge(parts)
@@ -85,8 +86,8 @@ def _coarse_grain_fv_tracer(ds, delp, area, coarsening_factor, mass_weighted=Tru
         area_weighted_vars, mass_weighted_vars = FRACTION_TRACERS + NON_FRACTION_TRACERS, []
     parts = [weighted_block_average(ds[area_weighted_vars], area, coarsening_factor, x_dim=FV_TRACER_X_CENTER, y_dim=FV_TRACER_Y_CENTER)]
     if mass_weighted_vars:
-        parts.append(weighted_block_average(ds[mass_weighted_vars], _mul(delp, area), coarsening_factor,
-                                            x_dim=FV_TRACER_X_CENTER, y_dim=FV_TRACER_Y_CENTER))
+        parts.append(mass_weighted_block_average(ds[mass_weighted_vars], delp, area, coarsening_factor,
+                                                 x_dim=FV_TRACER_X_CENTER, y_dim=FV_TRACER_Y_CENTER))
     return merge(parts)
 
 
@@ -314,6 +315,34 @@ def _common(coarsening_factor, grid_spec, restarts):
     return out
 
 
+_SIDE_STREAMS = {}
+
+
+def _common_beside(coarsening_factor, grid_spec, restarts):
+    """``_common`` on a second HIP stream: the surface categories are some 350 launches on 2-D fields (a microsecond or
+    two of device time each) that depend on nothing the 3-D categories produce -- issued after them, on a stream of their
+    own, they run in the shadow of the large kernels instead of behind them.  The calling stream waits for the side
+    stream before the results are handed out."""
+    import torch
+
+    from ._device import compute_device
+
+    dev = compute_device()
+    main = torch.cuda.current_stream(dev)
+    side = _SIDE_STREAMS.get(dev.index)
+    if side is None:
+        side = _SIDE_STREAMS[dev.index] = torch.cuda.Stream(device=dev)
+    side.wait_stream(main)  # inputs produced on the calling stream
+    with torch.cuda.stream(side):
+        out = _common(coarsening_factor, grid_spec, restarts)
+    main.wait_stream(side)
+    for ds in out.values():  # memory allocated on the side stream, used by the caller's stream from here on
+        for da in to_compat(ds).values():
+            if isinstance(da.data, torch.Tensor) and da.data.is_cuda:
+                da.data.record_stream(main)
+    return out
+
+
 def _finish(coarsened, restarts):
     return {category: from_compat(_sync_dimension_order(coarsened[category], restarts[category]), restarts[category])
             for category in CATEGORY_LIST}
@@ -323,7 +352,7 @@ def coarsen_restarts_on_sigma(coarsening_factor: int, grid_spec, restarts: Mappi
                               mass_weighted: bool = True):
     """Coarsen a complete set of restart files on model levels, 'complex' surface method (coarsen_restarts.py:21-95)."""
     core = to_compat(restarts["fv_core.res"])
-    coarsened = _common(coarsening_factor, grid_spec, restarts)
+    coarsened = {}
     coarsened["fv_core.res"] = _coarse_grain_fv_core(
         core, core["delp"], _grid(grid_spec, "area", FV_CORE_X_CENTER, FV_CORE_Y_CENTER),
         _grid(grid_spec, "dx", FV_CORE_X_CENTER, FV_CORE_Y_OUTER), _grid(grid_spec, "dy", FV_CORE_X_OUTER, FV_CORE_Y_CENTER),
@@ -331,6 +360,7 @@ def coarsen_restarts_on_sigma(coarsening_factor: int, grid_spec, restarts: Mappi
     coarsened["fv_tracer.res"] = _coarse_grain_fv_tracer(
         restarts["fv_tracer.res"], core["delp"].rename({FV_CORE_Y_CENTER: FV_TRACER_Y_CENTER}),
         _grid(grid_spec, "area", FV_TRACER_X_CENTER, FV_TRACER_Y_CENTER), coarsening_factor, mass_weighted)
+    coarsened.update(_common_beside(coarsening_factor, grid_spec, restarts))
     return _finish(coarsened, restarts)
 
 
@@ -339,7 +369,7 @@ def coarsen_restarts_on_pressure(coarsening_factor: int, grid_spec, toa_pressure
     """Coarsen a complete set of restart files on surfaces of constant pressure, then impose hydrostatic
     balance (coarsen_restarts.py:98-237)."""
     core = to_compat(restarts["fv_core.res"])
-    coarsened = _common(coarsening_factor, grid_spec, restarts)
+    coarsened = {}
     area = _grid(grid_spec, "area", FV_CORE_X_CENTER, FV_CORE_Y_CENTER)
     core_means, coarsened["fv_tracer.res"] = _area_weighted_pressure_means(
         core, restarts["fv_tracer.res"], core["delp"], area, toa_pressure, coarsening_factor, coarsen_agrid_winds, extrapolate)
@@ -348,6 +378,7 @@ def coarsen_restarts_on_pressure(coarsening_factor: int, grid_spec, toa_pressure
         _grid(grid_spec, "dy", FV_CORE_X_OUTER, FV_CORE_Y_CENTER), toa_pressure, coarsening_factor, coarsen_agrid_winds,
         extrapolate=extrapolate, area_means=core_means)
     coarsened["fv_core.res"] = _impose_hydrostatic_balance(coarsened["fv_core.res"], coarsened["fv_tracer.res"], toa_pressure)
+    coarsened.update(_common_beside(coarsening_factor, grid_spec, restarts))
     return _finish(coarsened, restarts)
 
 
@@ -355,7 +386,7 @@ def coarsen_restarts_via_blended_method(coarsening_factor: int, grid_spec, toa_p
                                         coarsen_agrid_winds: bool = False, mass_weighted: bool = True):
     """Blended pressure-level / model-level coarse-graining of the 3-D fields (coarsen_restarts.py:240-332)."""
     core = to_compat(restarts["fv_core.res"])
-    coarsened = _common(coarsening_factor, grid_spec, restarts)
+    coarsened = {}
     area = _grid(grid_spec, "area", FV_CORE_X_CENTER, FV_CORE_Y_CENTER)
     core_means, tracer_means = _area_weighted_pressure_means(
         core, restarts["fv_tracer.res"], core["delp"], area, toa_pressure, coarsening_factor, coarsen_agrid_winds, False)
@@ -368,4 +399,5 @@ def coarsen_restarts_via_blended_method(coarsening_factor: int, grid_spec, toa_p
         _grid(grid_spec, "area", FV_TRACER_X_CENTER, FV_TRACER_Y_CENTER), toa_pressure, coarsening_factor, mass_weighted,
         pressure_level=tracer_means)
     coarsened["fv_core.res"] = _impose_hydrostatic_balance(coarsened["fv_core.res"], coarsened["fv_tracer.res"], toa_pressure)
+    coarsened.update(_common_beside(coarsening_factor, grid_spec, restarts))
     return _finish(coarsened, restarts)

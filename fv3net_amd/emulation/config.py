@@ -7,6 +7,7 @@ model, as they are part of the reference's SavedModel graph.  Config-level tenso
 section (the zarr / netCDF monitor) is accepted with a warning and its hook does nothing."""
 import dataclasses
 import logging
+import os
 from typing import Dict, Iterable, Mapping, Optional
 
 import yaml
@@ -142,6 +143,7 @@ class ModelConfig:
 class EmulationConfig:
     model: Optional[ModelConfig] = None
     gscond: Optional[ModelConfig] = None
+    storage: Optional[object] = None  # monitor.StorageConfig (config.py:224-229 of the reference)
 
     @staticmethod
     def _build_model(model: Optional[ModelConfig]):
@@ -157,23 +159,30 @@ class EmulationConfig:
         return self._build_model(self.gscond)
 
     def build_storage_hook(self):
-        return do_nothing
+        if self.storage is None:
+            return do_nothing
+        from .monitor import StorageHook
+
+        return StorageHook.from_config(self.storage, n_ranks=int(os.environ.get("FV3NET_AMD_N_RANKS", "1"))).store
 
     @staticmethod
     def from_dict(dict_: dict) -> "EmulationConfig":
+        from .monitor import StorageConfig
+
         unknown = [k for k in dict_ if k not in ("model", "gscond", "storage")]
         if unknown:
             raise ValueError(f"unknown zhao_carr_emulation keys: {unknown}")
+        storage = None
         if dict_.get("storage"):
-            # the reference's production configs carry a `storage` section (projects/microphysics/configs/*.yaml); its
-            # zarr / netCDF monitor (emulation/_monitor) needs writers this build does not have.  Refusing the whole
-            # configuration would stop the model run over a diagnostic; the emulation hooks are built and the store hook
-            # does nothing -- loudly.
-            logger.warning("zhao_carr_emulation.storage is configured, but this build has no zarr / netCDF monitor: "
-                           "the `store` hook does nothing and the microphysics state is NOT saved.")
+            known = {f.name for f in dataclasses.fields(StorageConfig)}
+            bad = [k for k in dict_["storage"] if k not in known]
+            if bad:
+                raise ValueError(f"unknown zhao_carr_emulation.storage keys: {bad}")
+            storage = StorageConfig(**dict_["storage"])
         return EmulationConfig(
             model=ModelConfig.from_dict(dict_["model"]) if dict_.get("model") else None,
             gscond=ModelConfig.from_dict(dict_["gscond"]) if dict_.get("gscond") else None,
+            storage=storage,
         )
 
 

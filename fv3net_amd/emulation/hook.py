@@ -9,6 +9,13 @@ FortranState = MutableMapping[str, np.ndarray]
 Mask = Callable[[FortranState, FortranState], FortranState]
 
 
+HOST_ENTRIES = ("model_time", "rank")  # (_emulate/microphysics.py:92-93 drops them from the model inputs)
+
+
+def _is_field(name, value) -> bool:
+    return (isinstance(value, np.ndarray) and value.ndim >= 1 and value.dtype.kind == "f" and name not in HOST_ENTRIES)
+
+
 def always_emulator(state: FortranState, emulator: FortranState):
     return emulator
 
@@ -45,7 +52,9 @@ class MicrophysicsHook:
         if getattr(self.model, "device_resident", False):
             from ..cubedsphere._device import download_all, on_device
 
-            dev_state = {name: on_device(v) if isinstance(v, np.ndarray) else v for name, v in state.items()}
+            # only the floating-point fields go to the device: the bookkeeping entries (`model_time`, `rank`; integers and
+            # scalars, whatever container call_py_fort hands them over in) stay on the host, where TimeMask reads them
+            dev_state = {name: on_device(v) if _is_field(name, v) else v for name, v in state.items()}
             inputs = {name: v.t() if v.dim() == 2 else v for name, v in dev_state.items() if hasattr(v, "dim")}
             predictions = self.model(inputs)
             # numpy's .T: reverse all axes ([sample, z, class] logits -> [class, z, sample])

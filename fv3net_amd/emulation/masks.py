@@ -53,7 +53,7 @@ class RangeMask:
             return out
         t = _float_dev(x)
         res = torch.empty_like(t)
-        _lib.call("fv3hip_clamp", _ptr(t), _CODE[t.dtype], t.numel(), float(self.min if self.min is not None else 0.0),
+        _lib.call_on(t.device, "fv3hip_clamp", _ptr(t), _CODE[t.dtype], t.numel(), float(self.min if self.min is not None else 0.0),
                   float(self.max if self.max is not None else 0.0), int(self.min is not None), int(self.max is not None),
                   _ptr(res), _stream(t.device))
         out[self.key] = like_input(res, x)
@@ -85,6 +85,6 @@ class LevelMask:
         if src is not None and tuple(src.shape) != tuple(field.shape):
             raise ValueError(f"shape mismatch: {tuple(src.shape)} vs {tuple(field.shape)}")
         out = torch.empty(field.shape, dtype=torch.float64, device=field.device)
-        _lib.call("fv3hip_level_fill", _ptr(field), _CODE[field.dtype], _ptr(src), _CODE[src.dtype] if src is not None else 0,
+        _lib.call_on(field.device, "fv3hip_level_fill", _ptr(field), _CODE[field.dtype], _ptr(src), _CODE[src.dtype] if src is not None else 0,
                   fill, n0, n1, start, stop, _ptr(out), _stream(field.device))
         return {**emulator, self.key: like_input(out, emulator[self.key])}

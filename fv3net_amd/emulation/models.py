@@ -199,7 +199,7 @@ def _get_classify_output(logit_classes, one_hot_axis: int = 0) -> Dict[str, obje
         dev = _require_device(logits)
         onehot = torch.empty(logits.shape, dtype=torch.uint8, device=dev)
         both = torch.empty(logits.shape[1:], dtype=torch.uint8, device=dev)
-        _lib.call("fv3hip_classify_onehot", _ptr(logits), _lib.F64 if logits.dtype == torch.float64 else _lib.F32, n_class,
+        _lib.call_on(dev, "fv3hip_classify_onehot", _ptr(logits), _lib.F64 if logits.dtype == torch.float64 else _lib.F32, n_class,
                   both.numel(), _ptr(onehot), _ptr(both), names.index(zhao_carr.POSITIVE_TENDENCY),
                   names.index(zhao_carr.NEGATIVE_TENDENCY), _stream(dev))
         inverse = [order.index(d) for d in range(1, moved.dim())]  # back to the plane's own dim order (views)

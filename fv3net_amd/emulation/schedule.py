@@ -61,7 +61,10 @@ class TimeMask:
     schedule: Callable[[TimeLike], float]
 
     def __call__(self, state, emulator):
-        alpha = self.schedule(translate_time(state["model_time"]))
+        model_time = state["model_time"]
+        if hasattr(model_time, "is_cuda"):  # (a caller that uploaded it anyway: one transfer, not one per element)
+            model_time = model_time.cpu().tolist()
+        alpha = self.schedule(translate_time([int(x) for x in model_time]))
         common_keys = set(state) & set(emulator)
         return {key: _blend(state[key], emulator[key], alpha) for key in common_keys}
 
@@ -76,7 +79,9 @@ def _blend(left, right, alpha: float):
         a, b = on_device(left), on_device(right)
         if a.dtype != b.dtype:  # numpy promotion
             a, b = a.double(), b.double()
-        if alpha == 1.0 or alpha == 0.0:  # x * 1 + y * 0: the selected side as it is, without a pass over the data
+        # alpha is exactly 0 or 1 with an IntervalSchedule: the selected side as it is, without a pass over the data.
+        # (One difference from `x * 1 + y * 0`: a NaN or infinity of the UNSELECTED side does not leak into the result.)
+        if alpha == 1.0 or alpha == 0.0:
             return (a if alpha == 1.0 else b).contiguous()
         return ops.ew("add", ops.ew("mul_s", a.contiguous(), scalar=alpha), ops.ew("mul_s", b.contiguous(), scalar=1 - alpha))
     return left * alpha + right * (1 - alpha)

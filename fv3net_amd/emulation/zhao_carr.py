@@ -83,7 +83,7 @@ def squash_water_water_conserving(cloud, humidity, bound: float):
     odt = _out_dtype(c.dtype, h.dtype)
     cloud_out = torch.empty_like(c)
     qv_out = torch.empty(c.shape, dtype=odt, device=c.device)
-    _lib.call("fv3hip_zc_squash", _ptr(c), _CODE[c.dtype], _ptr(h), _CODE[h.dtype], c.numel(), float(bound), _CODE[odt],
+    _lib.call_on(c.device, "fv3hip_zc_squash", _ptr(c), _CODE[c.dtype], _ptr(h), _CODE[h.dtype], c.numel(), float(bound), _CODE[odt],
               _ptr(cloud_out), _ptr(qv_out), _stream(c.device))
     return like_input(cloud_out, cloud), like_input(qv_out, cloud)
 
@@ -111,7 +111,7 @@ def infer_gscond_cloud_from_conservation(state, emulator):
     qv_e = _dev(emulator[GscondOutput.humidity])
     odt = _out_dtype(sdt, qv_e.dtype)
     out = torch.empty(c_in.shape, dtype=odt, device=c_in.device)
-    _lib.call("fv3hip_zc_infer_cloud", _ptr(c_in), _ptr(qv_in), _CODE[sdt], _ptr(qv_e), _CODE[qv_e.dtype], c_in.numel(),
+    _lib.call_on(c_in.device, "fv3hip_zc_infer_cloud", _ptr(c_in), _ptr(qv_in), _CODE[sdt], _ptr(qv_e), _CODE[qv_e.dtype], c_in.numel(),
               _CODE[odt], _ptr(out), _stream(c_in.device))
     return {**emulator, GscondOutput.cloud_water: like_input(out, emulator[GscondOutput.humidity])}
 
@@ -138,7 +138,7 @@ def _gscond_conserve(state, emulator, mode: str, phase_dependent: bool):
     odt = _out_dtype(*dts)
     n0, n1 = _n01(c_in)
     outs = [torch.empty(c_in.shape, dtype=odt, device=c_in.device) for _ in range(3)]
-    _lib.call("fv3hip_zc_gscond_conserve", _ptr(c_in), _ptr(qv_in), _ptr(t_in), _CODE[sdt], _ptr(c_e), _CODE[c_e.dtype],
+    _lib.call_on(c_in.device, "fv3hip_zc_gscond_conserve", _ptr(c_in), _ptr(qv_in), _ptr(t_in), _CODE[sdt], _ptr(c_e), _CODE[c_e.dtype],
               _MODES[mode], _ptr(aux), _CODE[aux.dtype] if aux is not None else 0, n_class, cls, n0, n1,
               1 if phase_dependent else 0, _CODE[odt], _ptr(outs[0]), _ptr(outs[1]), _ptr(outs[2]), _stream(c_in.device))
     ref = emulator[GscondOutput.cloud_water]
@@ -174,7 +174,7 @@ def mask_zero_cloud_classifier_precpd(state, emulator):
     x = _dev(emulator[PrecpdOutput.cloud_water])
     logits = _dev(emulator["precpd_classes"])
     out = torch.empty_like(x)
-    _lib.call("fv3hip_zc_class_zero", _ptr(x), _CODE[x.dtype], _ptr(logits), _CODE[logits.dtype], int(logits.shape[0]),
+    _lib.call_on(x.device, "fv3hip_zc_class_zero", _ptr(x), _CODE[x.dtype], _ptr(logits), _CODE[logits.dtype], int(logits.shape[0]),
               CLASS_NAMES.index(ZERO_CLOUD), x.numel(), _ptr(out), _stream(x.device))
     return {**emulator, PrecpdOutput.cloud_water: like_input(out, emulator[PrecpdOutput.cloud_water])}
 
@@ -189,7 +189,7 @@ def enforce_conservative_precpd(state, emulator):
     n0, n1 = int(c_g.shape[0]), int(c_g.shape[1])
     outs = [torch.empty(c_g.shape, dtype=odt, device=c_g.device) for _ in range(3)]
     precip = torch.empty((n1,), dtype=odt, device=c_g.device)
-    _lib.call("fv3hip_zc_precpd_conserve", _ptr(c_g), _ptr(qv_g), _ptr(t_g), _ptr(delp), _CODE[sdt], _ptr(c_p), _ptr(qv_p),
+    _lib.call_on(c_g.device, "fv3hip_zc_precpd_conserve", _ptr(c_g), _ptr(qv_g), _ptr(t_g), _ptr(delp), _CODE[sdt], _ptr(c_p), _ptr(qv_p),
               _CODE[edt], n0, n1, _CODE[odt], _ptr(outs[0]), _ptr(outs[1]), _ptr(outs[2]), _ptr(precip), _stream(c_g.device))
     ref = emulator[PrecpdOutput.cloud_water]
     return {**emulator, PrecpdOutput.cloud_water: like_input(outs[0], ref), PrecpdOutput.humidity: like_input(outs[1], ref),
@@ -205,7 +205,7 @@ def conservative_precip_simple(state, emulator, sum_axis=0):
     odt = _out_dtype(sdt, edt)
     n0, n1 = int(c_g.shape[0]), int(np.prod(c_g.shape[1:]))
     precip = torch.empty(tuple(c_g.shape[1:]), dtype=odt, device=c_g.device)
-    _lib.call("fv3hip_zc_precip_simple", _ptr(c_g), _ptr(qv_g), _ptr(delp), _CODE[sdt], _ptr(c_p), _ptr(qv_p), _CODE[edt],
+    _lib.call_on(c_g.device, "fv3hip_zc_precip_simple", _ptr(c_g), _ptr(qv_g), _ptr(delp), _CODE[sdt], _ptr(c_p), _ptr(qv_p), _CODE[edt],
               n0, n1, _CODE[odt], _ptr(precip), _stream(c_g.device))
     return {**emulator, PrecpdOutput.precip: like_input(precip, emulator[PrecpdOutput.cloud_water])}
 

@@ -1,87 +1,82 @@
-"""Model io registry keyed by the ``name`` file of a model directory
-(external/fv3fit/fv3fit/_shared/io.py:17-100): ``fv3fit.load(path)`` reads ``<path>/name`` and
-dispatches to the class registered under that name; ``dump`` writes the name then the model."""
+"""Saving and loading predictors by the ``name`` file of a model directory.
+
+The contract kept from the reference (external/fv3fit/fv3fit/_shared/io.py:17-100; ``fv3fit.load`` is what
+``machine_learning.py:156`` calls): a model directory holds a UTF-8 file ``name`` whose content selects the class that
+reads the rest of the directory; ``@register("name")`` binds a class (with ``dump(path)`` / ``load(path)``) to such a name;
+``dump(obj, path)`` writes the name and then the object; ``load(path)`` dispatches on it.  Everything else here is this
+package's own: a plain table and three functions.
+"""
 import os
-import warnings
-from functools import partial
-from typing import Callable, MutableMapping, Type
 
-from .predictor import Reloadable
+NAME_FILE = "name"
 
-_NAME_PATH = "name"
-_NAME_ENCODING = "UTF-8"
+# directory name -> class, in registration order
+_TABLE = {}
 
-# names of reference artifacts this build cannot read (TensorFlow SavedModels etc.)
-UNREADABLE_REFERENCE_NAMES = ("all-keras", "all-keras-dict", "packed-keras", "sklearn", "sklearn_random_forest")
+# artifact types of the reference that need its TensorFlow / sklearn stack to be read
+_FOREIGN = frozenset({"all-keras", "all-keras-dict", "packed-keras", "sklearn", "sklearn_random_forest"})
 
 
-class _Register:
-    def __init__(self) -> None:
-        self._model_types: MutableMapping[str, Type[Reloadable]] = {}
+def register(name):
+    """Class decorator: objects of the class are saved to and loaded from directories named ``name``."""
+    if name in _TABLE:
+        raise ValueError(f"{name} is already registered by {_TABLE[name]}.")
 
-    def __call__(self, name: str) -> Callable:
-        if name in self._model_types:
-            raise ValueError(f"{name} is already registered by {self._model_types[name]}.")
-        return partial(self._register_class, name=name)
-
-    def _register_class(self, cls, name: str):
-        self._model_types[name] = cls
+    def bind(cls):
+        _TABLE[name] = cls
         return cls
 
-    def _load_by_name(self, name: str, path: str) -> Reloadable:
-        if name in UNREADABLE_REFERENCE_NAMES and name not in self._model_types:
+    return bind
+
+
+def registered_name(obj):
+    """The name ``obj`` is saved under: that of the most derived registered class it is an instance of."""
+    best = None
+    for name, cls in _TABLE.items():
+        if isinstance(obj, cls) and (best is None or issubclass(cls, _TABLE[best])):
+            best = name
+    if best is None:
+        raise ValueError(f"{type(obj)} is not registered. Consider decorating with @io.register(\"name\")")
+    return best
+
+
+def _open(path, leaf, mode):
+    """Local directories directly; anything with a protocol (gs://, memory://) through fsspec when it is installed."""
+    if "://" not in str(path):
+        return open(os.path.join(path, leaf), mode)
+    import fsspec
+
+    return fsspec.open(str(path).rstrip("/") + "/" + leaf, mode).open()
+
+
+def dump(obj, path):
+    """Write ``<path>/name`` and let the object write the rest."""
+    name = registered_name(obj)
+    if "://" not in str(path):
+        os.makedirs(path, exist_ok=True)
+    with _open(path, NAME_FILE, "wb") as f:
+        f.write(name.encode("utf-8"))
+    obj.dump(path)
+
+
+def load(path):
+    """Read ``<path>/name`` and hand the directory to the class registered under it.  A directory without the file is
+    offered to every registered class in turn (the reference does the same for artifacts older than the name file)."""
+    try:
+        with _open(path, NAME_FILE, "rb") as f:
+            name = f.read().decode("utf-8").strip()
+    except (FileNotFoundError, KeyError) as missing:
+        for cls in _TABLE.values():
+            try:
+                return cls.load(path)
+            except Exception:  # noqa: BLE001  (not this class's artifact)
+                continue
+        raise FileNotFoundError(f"no '{NAME_FILE}' file in {path} and no registered class can read it") from missing
+    if name not in _TABLE:
+        if name in _FOREIGN:
             raise ValueError(
                 f"model artifact of type '{name}' needs the reference's TensorFlow/sklearn stack to read; export it "
                 "to the 'hip-dense' format (weights.npz + spec.yaml, see INTEGRATION.md) where that stack exists."
             )
-        return self._model_types[name].load(path)
-
-    def get_name(self, obj: Reloadable) -> str:
-        return_name, name_cls = None, None
-        for name, cls in self._model_types.items():
-            if isinstance(obj, cls):
-                if name_cls is None or issubclass(cls, name_cls):
-                    return_name, name_cls = name, cls
-        if return_name is None:
-            raise ValueError(f"{type(obj)} is not registered. Consider decorating with @io.register(\"name\")")
-        return return_name
-
-    @staticmethod
-    def _get_name_from_path(path: str) -> str:
-        import fsspec
-
-        return fsspec.get_mapper(path)[_NAME_PATH].decode(_NAME_ENCODING).strip()
-
-    def _dump_class_name(self, obj: Reloadable, path: str):
-        import fsspec
-
-        fsspec.get_mapper(path)[_NAME_PATH] = self.get_name(obj).encode(_NAME_ENCODING)
-
-    def load(self, path: str) -> Reloadable:
-        """Load a serialized Reloadable from `path`."""
-        try:
-            name = self._get_name_from_path(path)
-        except KeyError as e:
-            warnings.warn(
-                f"Model type is not located at {os.path.join(path, _NAME_PATH)}. Trying all known models one-by-one.",
-                UserWarning,
-            )
-            for name in self._model_types:
-                try:
-                    return self._load_by_name(name, path)
-                except Exception:  # noqa
-                    pass
-            raise e
-        else:
-            return self._load_by_name(name, path)
-
-    def dump(self, obj: Reloadable, path: str):
-        """Dump a Reloadable to a path"""
-        os.makedirs(path, exist_ok=True) if "://" not in path else None
-        self._dump_class_name(obj, path)
-        obj.dump(path)
-
-
-register = _Register()
-dump = register.dump
-load = register.load
+        raise ValueError(f"unknown model type '{name}' in {path}; registered: {sorted(_TABLE)}")
+    return _TABLE[name].load(path)

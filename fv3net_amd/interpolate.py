@@ -58,11 +58,15 @@ def _interpolate_constant_levels(xp: DataArray, x: DataArray, y: DataArray, dim:
     """interpolate.py:153-179: the same output levels for every column; the output dimension takes ``dim``'s place
     and carries the levels as its coordinate."""
     out_dim = xp.dims[0]
-    if set(y.dims) != set(x.dims):
+    if not set(y.dims) >= set(x.dims):
         raise ValueError("the field must share dimensions with x")
     order = list(y.dims)
     axis = order.index(dim)
-    xt = on_device(x.transpose(*order).data)
+    # x is broadcast against the field along the dims only the field has (a time axis on the field but not on delp),
+    # as xr.apply_ufunc does for the reference (interpolate.py:165-179)
+    xt = on_device(x.transpose(*[d for d in order if d in x.dims]).data)
+    if len(x.dims) != len(order):
+        xt = xt.reshape([y.sizes[d] if d in x.dims else 1 for d in order]).expand(*[y.sizes[d] for d in order]).contiguous()
     levels = on_device(xp.data).to(xt.dtype)
     shape = [1] * len(order)
     shape[axis] = levels.numel()

@@ -325,7 +325,7 @@ class _PointModel:
     def _pack_into(self, arrs, nz: int, ncol: int, dev, x: torch.Tensor) -> None:
         for n, i in enumerate(self.spec.inputs):
             t = arrs[i.source]
-            _lib.call("fv3hip_local_pack", _ptr(t), _dt(t), int(t.shape[0] != 1),
+            _lib.call_on(dev, "fv3hip_local_pack", _ptr(t), _dt(t), int(t.shape[0] != 1),
                       _lib.TRANSFORM_LOG if i.transform == "log" else _lib.TRANSFORM_NONE, float(i.eps),
                       _ptr(self._table(f"in{n}_center", i.center, nz, 0.0)), _ptr(self._table(f"in{n}_scale", i.scale, nz, 1.0)),
                       nz, ncol, _ptr(x[n]), _stream(dev))
@@ -348,7 +348,7 @@ class _PointModel:
             before_args = [_ptr(arrs[o.before]), _dt(arrs[o.before])]
         bounds = list(o.value_limit) + list(o.after_limit)
         flags = sum(1 << b for b, v in enumerate(bounds) if v is not None)
-        _lib.call("fv3hip_local_unpack", _ptr(rows), int(level_stride),
+        _lib.call_on(dev, "fv3hip_local_unpack", _ptr(rows), int(level_stride),
                   _ptr(self._table(f"out{n}_scale", o.scale, nz, 1.0)) if o.scale is not None else None,
                   _ptr(self._table(f"out{n}_center", o.center, nz, 0.0)) if o.center is not None else None,
                   *cond_args, *before_args, flags, *[0.0 if v is None else float(v) for v in bounds], nz, ncol,

@@ -371,7 +371,7 @@ class MlpModel:
         out_ptrs = (ctypes.c_void_p * n_out)(*[t.data_ptr() for t in out_list])
         out_fs = (ctypes.c_int64 * n_out)(*[t.stride(fs_ax) for t in out_list])
         out_ss = (ctypes.c_int64 * n_out)(*[t.stride(ss_ax) for t in out_list])
-        _lib.call(
+        _lib.call_on(dev,
             "fv3hip_mlp_predict", self._handle, src_ptrs, src_dt, src_fs, src_ss, n_samples, out_ptrs,
             _lib.F64 if out_dtype == torch.float64 else _lib.F32, out_fs, out_ss, _stream(dev),
         )

@@ -72,7 +72,16 @@ def _ptr(t: Optional[torch.Tensor]):
     return ctypes.c_void_p(t.data_ptr()) if t is not None else ctypes.c_void_p(0)
 
 
+try:  # the raw handle of torch's current stream without building a Stream object (several microseconds per launch)
+    _raw_stream = torch._C._cuda_getCurrentRawStream
+except AttributeError:  # pragma: no cover
+    _raw_stream = None
+
+
 def _stream(dev) -> ctypes.c_void_p:
+    if _raw_stream is not None:
+        idx = None if dev is None else torch.device(dev).index
+        return ctypes.c_void_p(_raw_stream(torch.cuda.current_device() if idx is None else idx))
     return ctypes.c_void_p(torch.cuda.current_stream(dev).cuda_stream)
 
 
@@ -121,11 +130,53 @@ def weighted_block_average(obj: torch.Tensor, weights: torch.Tensor, factor: int
     out = torch.empty(
         tuple(obj.shape[:-2]) + (ny // factor, nx // factor), dtype=_promoted(obj, weights), device=dev
     )
-    _lib.call(
+    _lib.call_on(dev,
         "fv3hip_weighted_block_average", _ptr(obj), _float_code(obj), _ptr(weights), _float_code(weights),
         n_outer, ny, nx, w_repeat, factor, _ptr(out), _stream(dev),
     )
     return out
+
+
+def mass_weighted_block_average(fields: Sequence[torch.Tensor], delp: torch.Tensor, area: torch.Tensor, factor: int) -> list:
+    """``weighted_block_average(field, delp * area, factor)`` for several fields that share ``delp`` [.., ny, nx] (the
+    fields' shape and dtype) and ``area`` (2-D weights shared by trailing outer dims, as in ``weighted_block_average``): the
+    product is formed in registers and read once per four fields (coarsen_restarts.py:335-427, 856-900).  Falls back to the
+    product + ``weighted_block_average`` kernels for shapes the fused kernel does not take."""
+    fields = [f.contiguous() for f in fields]
+    if not fields:
+        return []
+    dev = _require_device(delp, area, *fields)
+    factor = int(factor)
+    f0 = fields[0]
+    if any(f.shape != f0.shape or f.dtype != f0.dtype for f in fields) or delp.shape != f0.shape:
+        raise ValueError("fields and delp must share one shape and dtype")
+    delp = delp.to(f0.dtype).contiguous()
+    area_b, a_repeat = _weights_repeat(f0, area)
+    ny, nx = int(f0.shape[-2]), int(f0.shape[-1])
+    if factor < 1 or ny % factor or nx % factor:
+        raise ValueError(f"horizontal extents ({ny}, {nx}) are not multiples of the coarsening factor {factor}")
+    n_outer = _prod(f0.shape[:-2])
+    out_dtype = _promoted(f0, area_b)
+    outs = [torch.empty(tuple(f0.shape[:-2]) + (ny // factor, nx // factor), dtype=out_dtype, device=dev) for _ in fields]
+    n = len(fields)
+    f_ptrs = (ctypes.c_void_p * n)(*[f.data_ptr() for f in fields])
+    o_ptrs = (ctypes.c_void_p * n)(*[o.data_ptr() for o in outs])
+    try:
+        _lib.call_on(dev, "fv3hip_mass_weighted_block_average", f_ptrs, n, _float_code(f0), _ptr(delp), _ptr(area_b),
+                     _float_code(area_b), n_outer, ny, nx, a_repeat, factor, o_ptrs, _stream(dev))
+    except _lib.Fv3HipError as err:
+        if err.code != _lib.EUNSUPPORTED:
+            raise
+        # the same result from the product kernel and the single-field average
+        lead = area_b.dim() - 2
+        if a_repeat > 1:
+            w = ew("mul", delp.reshape(tuple(delp.shape[:lead]) + (-1, ny, nx)), area_b).reshape(delp.shape)
+        else:
+            w = ew("mul", delp, area_b)
+        if w.dtype != out_dtype:
+            w = w.to(out_dtype)
+        return [weighted_block_average(f, w, factor) for f in fields]
+    return outs
 
 
 def edge_weighted_block_average(
@@ -150,7 +201,7 @@ def edge_weighted_block_average(
             raise ValueError(f"y extent {ny} is not a multiple of the coarsening factor {factor}")
         oshape = (ny // factor, -(-nx // factor))
     out = torch.empty(tuple(obj.shape[:-2]) + oshape, dtype=_promoted(obj, spacing), device=dev)
-    _lib.call(
+    _lib.call_on(dev,
         "fv3hip_edge_weighted_block_average", _ptr(obj), _float_code(obj), _ptr(spacing),
         _float_code(spacing), _prod(obj.shape[:-2]), ny, nx, w_repeat, factor, 0 if edge == "x" else 1,
         _ptr(out), _stream(dev),
@@ -180,7 +231,7 @@ def block_reduce(
         raise ValueError(f"window ({by}, {bx}) is larger than the field ({ny}, {nx})")
     nyo, nxo = (ny - by) // sy + 1, (nx - bx) // sx + 1
     out = torch.empty(tuple(x.shape[:-2]) + (nyo, nxo), dtype=x.dtype, device=dev)
-    _lib.call(
+    _lib.call_on(dev,
         "fv3hip_block_reduce", _ptr(x), _code(x), _prod(x.shape[:-2]), ny, nx, by, bx, sy, sx, _OPS[op],
         policy, _ptr(out), _stream(dev),
     )
@@ -199,7 +250,7 @@ def block_upsample(x: torch.Tensor, factor: int) -> torch.Tensor:
     nyo = (ny - 1) * factor + 1 if ny % 2 == 1 else ny * factor
     nxo = (nx - 1) * factor + 1 if nx % 2 == 1 else nx * factor
     out = torch.empty(tuple(x.shape[:-2]) + (nyo, nxo), dtype=x.dtype, device=dev)
-    _lib.call(
+    _lib.call_on(dev,
         "fv3hip_block_upsample", _ptr(x), x.element_size(), _prod(x.shape[:-2]), ny, nx, factor, _ptr(out),
         _stream(dev),
     )
@@ -218,7 +269,7 @@ def column_sum(x: torch.Tensor, z_axis: int, addend: float = 0.0) -> torch.Tenso
     x = x.contiguous()
     z_axis, nb, nz, ni = _column_view(x, z_axis)
     out = torch.empty(tuple(x.shape[:z_axis]) + tuple(x.shape[z_axis + 1:]), dtype=x.dtype, device=dev)
-    _lib.call("fv3hip_column_sum", _ptr(x), code, nb, nz, ni, float(addend), _ptr(out), _stream(dev))
+    _lib.call_on(dev, "fv3hip_column_sum", _ptr(x), code, nb, nz, ni, float(addend), _ptr(out), _stream(dev))
     return out
 
 
@@ -234,7 +285,7 @@ def blend_weights(blending_pressure: torch.Tensor, ps_coarse: torch.Tensor, pful
     if tuple(pb.shape) != want or tuple(ps.shape) != want:
         raise ValueError(f"blending and surface pressures must have shape {want}")
     out = torch.empty_like(p)
-    _lib.call("fv3hip_blend_weights", _ptr(pb), _ptr(ps), _ptr(p), code, nb, nz, ni, _ptr(out), _stream(dev))
+    _lib.call_on(dev, "fv3hip_blend_weights", _ptr(pb), _ptr(ps), _ptr(p), code, nb, nz, ni, _ptr(out), _stream(dev))
     return out
 
 
@@ -252,7 +303,7 @@ def hydrostatic_balance(dz: torch.Tensor, phis: torch.Tensor, t: torch.Tensor, q
     if tuple(phis.shape) != tuple(dz.shape[:z_axis]) + tuple(dz.shape[z_axis + 1:]):
         raise ValueError("phis must have DZ's shape without the vertical axis")
     dz_out, phis_out = torch.empty_like(dz), torch.empty_like(phis)
-    _lib.call("fv3hip_hydrostatic_balance", _ptr(dz), _ptr(phis), _ptr(t), _ptr(q), _ptr(delp), _DTYPE_CODE[dt], nb, nz, ni,
+    _lib.call_on(dev, "fv3hip_hydrostatic_balance", _ptr(dz), _ptr(phis), _ptr(t), _ptr(q), _ptr(delp), _DTYPE_CODE[dt], nb, nz, ni,
               float(toa_pressure), _ptr(dz_out), _ptr(phis_out), _stream(dev))
     return dz_out, phis_out
 
@@ -267,7 +318,7 @@ def level_scale(x: torch.Tensor, scale: torch.Tensor, z_axis: int) -> torch.Tens
     if tuple(scale.shape) != (nz,):
         raise ValueError(f"scale must have shape ({nz},), got {tuple(scale.shape)}")
     out = torch.empty(x.shape, dtype=torch.float64, device=dev)
-    _lib.call("fv3hip_level_scale", _ptr(x), code, _ptr(scale), nb, nz, ni, _ptr(out), _stream(dev))
+    _lib.call_on(dev, "fv3hip_level_scale", _ptr(x), code, _ptr(scale), nb, nz, ni, _ptr(out), _stream(dev))
     return out
 
 
@@ -282,7 +333,7 @@ def member_reduce(members: Sequence[torch.Tensor], op: str) -> torch.Tensor:
         raise NotImplementedError(f"Got reduction {op}: only mean, median supported")
     out = torch.empty_like(ms[0])
     ptrs = (ctypes.c_void_p * len(ms))(*[m.data_ptr() for m in ms])
-    _lib.call("fv3hip_member_reduce", ptrs, len(ms), _DTYPE_CODE[dt], _OPS[op], out.numel(), _ptr(out), _stream(dev))
+    _lib.call_on(dev, "fv3hip_member_reduce", ptrs, len(ms), _DTYPE_CODE[dt], _OPS[op], out.numel(), _ptr(out), _stream(dev))
     return out
 
 
@@ -303,7 +354,7 @@ def interpolate_2d(xp: torch.Tensor, x: torch.Tensor, y: torch.Tensor, fill_valu
     n_batch, n_inner = _prod(x.shape[:z_axis]), _prod(x.shape[z_axis + 1:])
     layout = _lib.LAYOUT_LEVEL_COL if n_inner > 1 else _lib.LAYOUT_COL_LEVEL
     out = torch.empty_like(xp)
-    _lib.call("fv3hip_interpolate_2d", _ptr(xp), _ptr(x), _ptr(y), n_batch, n_inner, n_in, n_out, float(fill_value), layout,
+    _lib.call_on(dev, "fv3hip_interpolate_2d", _ptr(xp), _ptr(x), _ptr(y), n_batch, n_inner, n_in, n_out, float(fill_value), layout,
               _ptr(out), _stream(dev))
     return out
 
@@ -335,7 +386,7 @@ def ew(op: str, a: torch.Tensor, b: Optional[torch.Tensor] = None, c: Optional[t
     b, b_rep = operand(b)
     c, c_rep = operand(c)
     out = torch.empty_like(a)
-    _lib.call("fv3hip_ew", EW_OPS[op], _ptr(a), _ptr(b), _ptr(c), float(scalar), code, a.numel(), inner, b_rep, c_rep,
+    _lib.call_on(dev, "fv3hip_ew", EW_OPS[op], _ptr(a), _ptr(b), _ptr(c), float(scalar), code, a.numel(), inner, b_rep, c_rep,
               _ptr(out), _stream(dev))
     return out
 
@@ -353,7 +404,7 @@ def cube_edge_rows(x: torch.Tensor) -> torch.Tensor:
     n_tiles, n = int(x.shape[0]), int(x.shape[-1])
     mid = tuple(x.shape[1:-2])
     rows = torch.empty((n_tiles, 4) + mid + (n,), dtype=x.dtype, device=dev)
-    _lib.call("fv3hip_cube_edge_rows", _ptr(x), x.element_size(), n_tiles, _prod(mid), n, _ptr(rows), _stream(dev))
+    _lib.call_on(dev, "fv3hip_cube_edge_rows", _ptr(x), x.element_size(), n_tiles, _prod(mid), n, _ptr(rows), _stream(dev))
     return rows
 
 
@@ -371,7 +422,7 @@ def interp_center_to_outer(x: torch.Tensor, lo: torch.Tensor, hi: torch.Tensor, 
     if tuple(lo.shape) != want or tuple(hi.shape) != want:
         raise ValueError(f"halo shape must be {want}, got {tuple(lo.shape)} and {tuple(hi.shape)}")
     out = torch.empty(tuple(x.shape[:-2]) + (ny + (axis == 1), nx + (axis == 0)), dtype=x.dtype, device=dev)
-    _lib.call("fv3hip_interp_center_to_outer", _ptr(x), code, _prod(x.shape[:-2]), ny, nx, int(axis),
+    _lib.call_on(dev, "fv3hip_interp_center_to_outer", _ptr(x), code, _prod(x.shape[:-2]), ny, nx, int(axis),
               _ptr(lo), _ptr(hi), _ptr(out), _stream(dev))
     return out
 
@@ -387,7 +438,7 @@ def pressure_at_interface(delp: torch.Tensor, toa_pressure: float, z_axis: int) 
     shape = list(delp.shape)
     shape[z_axis] = nz + 1
     out = torch.empty(shape, dtype=delp.dtype, device=dev)
-    _lib.call(
+    _lib.call_on(dev,
         "fv3hip_pressure_at_interface", _ptr(delp), _float_code(delp), n_batch, nz, n_inner,
         float(toa_pressure), _ptr(out), _stream(dev),
     )
@@ -402,7 +453,7 @@ def pressure_at_midpoint_log(delp: torch.Tensor, toa_pressure: float, z_axis: in
     nz = int(delp.shape[z_axis])
     n_batch, n_inner = _prod(delp.shape[:z_axis]), _prod(delp.shape[z_axis + 1:])
     out = torch.empty_like(delp)
-    _lib.call(
+    _lib.call_on(dev,
         "fv3hip_pressure_at_midpoint_log", _ptr(delp), _float_code(delp), n_batch, nz, n_inner,
         float(toa_pressure), _ptr(out), _stream(dev),
     )
@@ -436,7 +487,7 @@ def mask_weights(
             f"{batch_shape + inner_shape}"
         )
     out = torch.empty(batch_shape + (nz,) + inner_shape, dtype=weights.dtype, device=dev)
-    _lib.call(
+    _lib.call_on(dev,
         "fv3hip_mask_weights", _ptr(weights), _float_code(weights), _ptr(p_coarse), cmp_levels, cmp_offset,
         _ptr(p_fine), _float_code(p_fine), n_batch, nz, n_inner, 1, _ptr(out), _stream(dev),
     )
@@ -512,7 +563,7 @@ def mappm(
     ncol = nb * ni
     nbytes = int(_lib.load().fv3hip_mappm_workspace_bytes(ncol, km))
     ws = _workspace(dev, nbytes)
-    _lib.call(
+    _lib.call_on(dev,
         "fv3hip_mappm", _ptr(pe1), _ptr(q1), _ptr(pe2), _float_code(q1), _ptr(out), nb, ni, km, kn,
         int(iv), int(kord), layout, _arith_code(arith), _ptr(ws), ws.numel(), _stream(dev),
     )
@@ -557,7 +608,7 @@ def mappm_multi(pe1: torch.Tensor, fields: Sequence[torch.Tensor], pe2: torch.Te
     n = len(fields)
     q_ptrs = (ctypes.c_void_p * n)(*[q.data_ptr() for q in fields])
     o_ptrs = (ctypes.c_void_p * n)(*[o.data_ptr() for o in outs])
-    _lib.call("fv3hip_mappm_multi", _ptr(pe1), q_ptrs, _ptr(pe2), _float_code(q1), o_ptrs, n, nb, ni, km, kn, int(iv), int(kord),
+    _lib.call_on(dev, "fv3hip_mappm_multi", _ptr(pe1), q_ptrs, _ptr(pe2), _float_code(q1), o_ptrs, n, nb, ni, km, kn, int(iv), int(kord),
               layout, _arith_code(arith), _ptr(ws), ws.numel(), _stream(dev))
     return outs
 
@@ -570,10 +621,10 @@ class HipTimer:
         _lib.call("fv3hip_timer_create", ctypes.byref(self._h))
 
     def start(self, dev=None):
-        _lib.call("fv3hip_timer_start", self._h, _stream(dev))
+        _lib.call_on(dev, "fv3hip_timer_start", self._h, _stream(dev))
 
     def stop(self, dev=None):
-        _lib.call("fv3hip_timer_stop", self._h, _stream(dev))
+        _lib.call_on(dev, "fv3hip_timer_stop", self._h, _stream(dev))
 
     def elapsed_ms(self) -> float:
         ms = ctypes.c_float()

@@ -66,7 +66,7 @@ def _limiter(sphum, q1, q2, dt: float, mse_conserving: bool):
         raise ValueError("sphum and the tendencies must have the same dimensions")
     out2 = torch.empty_like(tb)
     out1 = torch.empty_like(ta) if ta is not None else None
-    _lib.call("fv3hip_non_negative_sphum", ops._ptr(ts), ops._ptr(ta), ops._ptr(tb), _lib.F64 if dt_ == torch.float64 else _lib.F32,
+    _lib.call_on(ts.device, "fv3hip_non_negative_sphum", ops._ptr(ts), ops._ptr(ta), ops._ptr(tb), _lib.F64 if dt_ == torch.float64 else _lib.F32,
               ts.numel(), float(dt), int(mse_conserving), ops._ptr(out1), ops._ptr(out2), ops._stream(ts.device))
     wrap = lambda t, ref, orig: from_compat(DataArray(like_input(t, s.data), dims=dims, coords=dict(s.coords)), orig)
     return (wrap(out1, a, q1) if out1 is not None else None), wrap(out2, b, q2)

@@ -70,7 +70,10 @@ extern "C" {
 const char *fv3hip_last_error(void);
 int fv3hip_abi_version(void);
 
-/* Select the device for the calling thread and cache its properties. */
+/* Check that `device` exists and is a gfx950 part.  The calling thread's current device is NOT changed.
+ * DEVICE RULE for every other entry point: kernels are launched on, and scratch memory is allocated on, the CURRENT
+ * HIP device, which must be the device of the pointers passed (callers holding several GPUs make it current around
+ * the call; fv3hip_mlp_predict returns FV3HIP_EINVAL when the model was created on another device). */
 int fv3hip_init(int device);
 
 typedef struct {
@@ -101,6 +104,20 @@ int fv3hip_device_info(fv3hip_device_info_t *out);
 int fv3hip_weighted_block_average(const void *obj, int obj_dtype, const void *weights,
                                   int w_dtype, int64_t n_outer, int ny, int nx,
                                   int64_t w_repeat, int factor, void *out, void *stream);
+
+/*
+ * The mass-weighted means of the restart pipelines (external/vcm/vcm/cubedsphere/coarsen_restarts.py:335-427, 856-900:
+ * weighted_block_average(ds[mass_weighted_vars], delp * area, ...)) for n_fields fields that share their weights:
+ *     out_f[o][Y][X] = nansum_block(field_f * (delp * area)) / nansum_block(delp * area)
+ * with the product delp * area formed in registers (never written) and read once per four fields.  `fields` / `outs` are
+ * HOST arrays of device pointers; fields and delp [n_outer][ny][nx] in `dtype`, area [n_outer / a_repeat][ny][nx] in
+ * `area_dtype`, outputs [n_outer][ny / f][nx / f] in the promoted type (F64 unless both are F32).  factor in
+ * {2, 4, 8, 16} with 16-byte aligned rows; anything else returns FV3HIP_EUNSUPPORTED (callers then form the product with
+ * fv3hip_ew and use fv3hip_weighted_block_average).
+ */
+int fv3hip_mass_weighted_block_average(const void *const *fields, int n_fields, int dtype, const void *delp,
+                                       const void *area, int area_dtype, int64_t n_outer, int ny, int nx,
+                                       int64_t a_repeat, int factor, void *const *outs, void *stream);
 
 /*
  * Replaces vcm.cubedsphere.edge_weighted_block_average

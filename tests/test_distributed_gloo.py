@@ -100,3 +100,62 @@ def test_two_rank_cube_halo_exchange(tmp_path):
                 edge1 = ref[t][:, :, -1] if axis == "x" else ref[t][:, -1, :]
                 np.testing.assert_array_equal(np.float32(0.5) * (lo[i] + first), edge0)
                 np.testing.assert_array_equal(np.float32(0.5) * (last + hi[i]), edge1)
+
+
+def _band_worker(rank, size, port, out_dir):
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=size)
+    from fv3net_amd import ops, parallel
+    from oracle import coarsen_np as onp
+
+    # (the device kernel needs a GPU; what is under test here is the partition, the gather and the sub-group plumbing)
+    ops.weighted_block_average = lambda o, w, f: torch.from_numpy(onp.weighted_block_average(o.numpy(), w.numpy(), f))
+    n, f = 16, 4
+    rng = np.random.default_rng(9)
+    field = rng.uniform(-1, 1, (6, 3, n, n)).astype(np.float32)  # the same cube on every rank; each keeps its bands
+    area = rng.uniform(0.5, 1, (6, n, n)).astype(np.float32)
+    units = parallel.units_of_rank(6, n, f, size, rank)
+    objs = [torch.from_numpy(field[t, :, r0:r1]) for t, r0, r1 in units]
+    wts = [torch.from_numpy(area[t, r0:r1]) for t, r0, r1 in units]
+    bands = parallel.weighted_block_average_banded(objs, wts, f)
+    assert [tuple(b.shape) for b in bands] == [(3, (r1 - r0) // f, n // f) for _, r0, r1 in units]
+    cube = parallel.weighted_block_average_banded(objs, wts, f, ny=n, gather=True)
+    if rank == 0:
+        np.save(os.path.join(out_dir, "cube.npy"), cube.numpy())
+        np.save(os.path.join(out_dir, "units.npy"), np.asarray(parallel.tile_bands(6, n, f, size), dtype=object), allow_pickle=True)
+    else:
+        assert cube is None
+    # a sub-group (the six tile owners of an 8-rank job are one): ranks 0..size-2 exchange, the last rank stays out
+    group = dist.new_group(list(range(size - 1)))
+    if rank < size - 1:
+        parallel.use_group(group)
+        assert parallel.world() == (rank, size - 1)
+        mine = parallel.tiles_of_rank(size - 1, rank)
+        local = torch.from_numpy(field[mine])
+        rows = torch.stack([local[..., :, 0], local[..., :, -1], local[..., 0, :], local[..., -1, :]], dim=1)
+        assert parallel.exchange_edge_rows(rows).shape == (6, 4, 3, n)
+        parallel.use_group(None)
+    assert parallel.world() == (rank, size)
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_band_sharded_cube_on_four_ranks(tmp_path):
+    """BASELINE configs[4]'s partition on CPU ranks: 6 tiles x row bands over 4 ranks (2 bands per tile, 3 units per
+    rank), every band coarsened where it lives with no exchange, the coarse cube gathered on rank 0 equals the
+    whole-cube result; a process sub-group carries the tile-sharded halo exchange while the other ranks stay out."""
+    from oracle import coarsen_np as onp
+
+    size, n, f = 4, 16, 4
+    mp.spawn(_band_worker, args=(size, _free_port(), str(tmp_path)), nprocs=size, join=True)
+    rng = np.random.default_rng(9)
+    field = rng.uniform(-1, 1, (6, 3, n, n)).astype(np.float32)
+    area = rng.uniform(0.5, 1, (6, n, n)).astype(np.float32)
+    want = onp.weighted_block_average(field, area[:, None], f)
+    np.testing.assert_array_equal(np.load(tmp_path / "cube.npy"), want)
+    from fv3net_amd import parallel
+
+    plan = parallel.tile_bands(6, n, f, size)
+    assert [len(u) for u in plan] == [3, 3, 3, 3] and sorted(sum(plan, [])) == [(t, b * 8, b * 8 + 8) for t in range(6) for b in range(2)]
+    assert [len(u) for u in parallel.tile_bands(6, 3072, 8, 8)] == [3] * 8  # configs[4]: 4 bands of 768 rows per tile

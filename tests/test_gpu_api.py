@@ -587,3 +587,34 @@ def test_microphysics_hook_keeps_masks_on_the_device(tmp_path):
         assert np.max(np.abs(got - ref)) <= 1e-5 * np.max(np.abs(ref)), name
     np.testing.assert_array_equal(state["air_temperature_after_precpd"][74:], fortran["air_temperature_after_precpd"][74:])
     assert state["air_temperature_after_precpd"].dtype == np.float64 and np.all(state["total_precipitation"] >= 0)
+
+
+def test_calls_work_when_another_device_is_current():
+    """The library launches and allocates on the CURRENT device (include/fv3hip.h, DEVICE RULE): the Python layer makes the
+    tensors' device current around every call and restores the caller's; fv3hip_init does not switch devices.  Needs two
+    visible GPUs (the 8-GPU node of the scaling runs); skipped on a one-GPU box."""
+    import torch
+
+    if torch.cuda.device_count() < 2:
+        pytest.skip("needs two visible GPUs")
+    from fv3net_amd import ops
+
+    d1 = torch.device("cuda:1")
+    torch.cuda.set_device(0)
+    x = torch.rand((2, 3, 16, 16), device=d1)
+    w = torch.rand((2, 16, 16), device=d1) + 0.5
+    got = ops.weighted_block_average(x, w, 4)
+    assert got.device == d1 and torch.cuda.current_device() == 0
+    with torch.cuda.device(1):
+        want = ops.weighted_block_average(x, w, 4)
+    assert torch.equal(got, want)
+    import bench
+    from fv3net_amd.mlp import MlpModel
+
+    model = MlpModel(bench.zc_spec(0), device=d1)
+    src = bench.zc_inputs_device(d1, 4096, seed=3)
+    out = model.predict(src)
+    assert torch.cuda.current_device() == 0 and all(v.device == d1 for v in out.values())
+    with torch.cuda.device(1):
+        again = model.predict(src)
+    assert all(torch.equal(out[k], again[k]) for k in out)

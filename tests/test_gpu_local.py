@@ -303,8 +303,11 @@ def test_online_schedule_switches_between_physics_and_emulator(tmp_path):
     fortran = {E.QV_G: st[cases.QV_IN] * 0.99, E.T_G: st[cases.T_IN] + 0.25}
     for minute, emulated in ((30, False), (90, True)):
         state = {**{k: v.copy() for k, v in st.items()}, **{k: v.copy() for k, v in fortran.items()}}
-        state["model_time"] = [2016, 8, 1, 0, minute // 60, minute % 60]
+        # (call_py_fort hands the bookkeeping entries over as integer arrays: they stay on the host)
+        state["model_time"] = np.array([2016, 8, 1, 0, minute // 60, minute % 60], dtype=np.int32)
+        state["rank"] = np.array([3], dtype=np.int32)
         hook.microphysics(state)
+        assert isinstance(state["model_time"], np.ndarray) and state["rank"][0] == 3
         for name in (E.QV_G, E.T_G):
             if emulated:
                 _check(state[name], truth[name].T, name)

@@ -452,6 +452,16 @@ def test_interpolate_1d_constant_levels_and_pressure_levels_known_answers(device
         for i in range(5):
             want[:, j, i] = np.interp(PRESSURE_GRID.values, mid[:, j, i], t.values[:, j, i], left=np.nan, right=np.nan)
     np.testing.assert_allclose(out.values, want, rtol=1e-12, equal_nan=True)
+    # a field with a leading dim the pressure thickness does not have (time on the field, not on delp): x is broadcast,
+    # as xr.apply_ufunc does in the reference (interpolate.py:165-179) -- in a Dataset too
+    t2 = DataArray(np.stack([t.values, 2 * t.values]), dims=["time", "pfull", "y", "x"])
+    out2 = interpolate_to_pressure_levels(t2, delp)
+    assert out2.dims == ("time", "pressure", "y", "x")
+    np.testing.assert_allclose(out2.values[0], want, rtol=1e-12, equal_nan=True)
+    np.testing.assert_allclose(out2.values[1], 2 * want, rtol=1e-12, equal_nan=True)
+    ds2 = interpolate_to_pressure_levels(Dataset({"t2": t2, "t": t}), delp)
+    np.testing.assert_allclose(ds2["t2"].values[1], 2 * want, rtol=1e-12, equal_nan=True)
+    np.testing.assert_allclose(ds2["t"].values, want, rtol=1e-12, equal_nan=True)
 
 
 def _native(a, nt, ny, nx):  # [ncol, lev] -> [tile, lev, y, x]

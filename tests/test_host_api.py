@@ -23,7 +23,7 @@ def test_library_exports_every_symbol_in_the_header():
     lib = _lib.load()
     for name in declared:
         assert hasattr(lib, name), name
-    assert lib.fv3hip_abi_version() == 1
+    assert lib.fv3hip_abi_version() == _lib.ABI_VERSION == 2
     assert lib.fv3hip_mappm_workspace_bytes(10, 79) >= 5 * 79 * 10 * 4
 
 
@@ -32,7 +32,7 @@ def test_library_reports_errors_without_touching_the_gpu():
     rc = lib.fv3hip_weighted_block_average(None, 7, None, 0, 1, 4, 4, 1, 2, None, None)
     assert rc == _lib.EINVAL
     assert b"dtype" in lib.fv3hip_last_error()
-    rc = lib.fv3hip_mappm(None, None, None, 0, None, 1, 1, 79, 79, 1, 9, 0, None, 0, None)
+    rc = lib.fv3hip_mappm(None, None, None, 0, None, 1, 1, 79, 79, 1, 9, 0, 0, None, 0, None)
     assert rc == _lib.EUNSUPPORTED and b"cs_profile" in lib.fv3hip_last_error()
 
 
@@ -173,25 +173,15 @@ def test_emulation_config(tmp_path):
                                                "mask_emulator_levels": {"air_temperature_after_precpd": {"start": 74}}}})
     # the reference's composition order (config.py:178-221): range, squash x2, conservation, level mask
     assert len(list(cfg.model._build_masks())) == 5
-    # the reference's production configs carry a storage section: accepted with a warning, its hook does nothing
-    import logging
-
-    class _Catch(logging.Handler):
-        def __init__(self):
-            super().__init__()
-            self.messages = []
-
-        def emit(self, record):
-            self.messages.append(record.getMessage())
-
-    catch = _Catch()
-    logging.getLogger("emulation").addHandler(catch)
-    try:
-        cfg2 = EmulationConfig.from_dict({"storage": {"output_freq_sec": 10800, "save_zarr": True}})
-    finally:
-        logging.getLogger("emulation").removeHandler(catch)
-    assert any("NOT saved" in m for m in catch.messages)
-    assert cfg2.build_storage_hook()({"a": np.zeros(3)}) is None
+    # the reference's production configs carry a storage section (projects/microphysics/configs/*.yaml): it builds the
+    # store hook (tests/test_io.py exercises it); unknown keys and TFRecord output are refused
+    cfg2 = EmulationConfig.from_dict({"storage": {"output_freq_sec": 10800, "save_zarr": True}})
+    assert cfg2.storage.output_freq_sec == 10800 and callable(cfg2.build_storage_hook())
+    assert EmulationConfig.from_dict({}).build_storage_hook()({"a": np.zeros(3)}) is None
+    with pytest.raises(ValueError, match="unknown"):
+        EmulationConfig.from_dict({"storage": {"output_frequency": 1}})
+    with pytest.raises(ValueError, match="TensorFlow"):
+        EmulationConfig.from_dict({"storage": {"save_tfrecord": True}}).build_storage_hook()
     with pytest.raises(ValueError, match="mutually exclusive"):
         EmulationConfig.from_dict({"model": {"enforce_conservative": True, "enforce_conservative_phase_dependent": True}})
     with pytest.raises(ValueError, match="unknown"):
