@@ -181,8 +181,8 @@ def pmc_traffic(kernel_key):
 
 def pmc_valu(kernel_key):
     """VALU issue-bound fraction of a remap kernel from the committed PMC passes (profiles/r01_pmc_mappm_valu.json), a
-    recorded measurement like ``pmc_traffic``; None if absent."""
-    path = os.path.join(os.path.dirname(os.path.abspath(__file__)), "profiles", "r01_pmc_mappm_valu.json")
+    recorded measurement (rocprofv3 --pmc passes of benchmarks/mappm_one.py) like ``pmc_traffic``; None if absent."""
+    path = os.path.join(os.path.dirname(os.path.abspath(__file__)), "profiles", "r02_pmc_mappm_valu.json")
     try:
         with open(path) as f:
             return json.load(f)["kernels"][kernel_key]["valu_issue_bound_fraction"]
@@ -364,34 +364,41 @@ def secondary_benchmarks(dev, steps):
     )
     ncol = 6 * n * n
     alg_bytes = ncol * 1272.0
+    reps = max(3, min(steps, 10))
     for label, pe2 in targets:
-        fn = lambda: ops.mappm(pe1, q, pe2, z_axis=1)
-        fn()
-        torch.cuda.synchronize(dev)
-        ms = time_kernel(fn, max(3, min(steps, 10)), dev)
-        out.append({
-            "kernel": "mappm", "workload": f"C384 884736 columns, km=kn=79, iv=1 kord=1, [tile,z,y,x] f32, {label}",
-            "ms": ms, "columns_per_s": ncol / ms * 1e3,
-            "roofline": {"bound": "hbm", "achieved": alg_bytes / ms / 1e6, "peak": PEAK_HBM_GBPS, "unit": "GB/s",
-                         "frac": alg_bytes / ms / 1e6 / PEAK_HBM_GBPS, "traffic": None,
-                         "note": "VALU-issue-bound (bit-exact IEEE divisions): see valu_issue_bound_frac",
-                         "valu_issue_bound_frac": pmc_valu("mappm_merge_kernel<float>")},
-        })
+        for arith in ("fast", "exact"):
+            fn = lambda: ops.mappm(pe1, q, pe2, z_axis=1, arith=arith)
+            fn()
+            torch.cuda.synchronize(dev)
+            ms = time_kernel(fn, reps, dev)
+            out.append({
+                "kernel": f"mappm_sweep_kernel<float,1,1,{'true' if arith == 'fast' else 'false'}> (arith={arith})",
+                "workload": f"C384 884736 columns, km=kn=79, iv=1 kord=1, [tile,z,y,x] f32, {label}",
+                "ms": ms, "columns_per_s": ncol / ms * 1e3,
+                "roofline": {"bound": "hbm", "achieved": alg_bytes / ms / 1e6, "peak": PEAK_HBM_GBPS, "unit": "GB/s",
+                             "frac": alg_bytes / ms / 1e6 / PEAK_HBM_GBPS, "traffic": None,
+                             "note": "VALU-issue-bound, not HBM-bound: see valu_issue_bound_frac (recorded PMC pass); 'fast' = "
+                                     "reciprocal arithmetic (the default of the Python layer, <= 1e-5 of the column's range from "
+                                     "'exact'), 'exact' = IEEE division, bit-identical to the compiled reference",
+                             "valu_issue_bound_frac": pmc_valu(f"mappm_sweep_kernel<float, 1, 1, {'true' if arith == 'fast' else 'false'}>")},
+            })
     # the same remap for 4 fields that share their pressures (one fv_core / tracer group of the pipeline)
     qs = [q] + [torch.rand((6, NZ, n, n), device=dev, generator=g) * 2000 - 1000 for _ in range(3)]
     pe2 = targets[0][1]
-    fn = lambda: ops.mappm_multi(pe1, qs, pe2, z_axis=1)
-    fn()
-    torch.cuda.synchronize(dev)
-    ms = time_kernel(fn, max(3, min(steps, 10)), dev)
-    alg_bytes = ncol * (160 * 4 + 4 * 158 * 4.0)
-    out.append({
-        "kernel": "mappm_multi (4 fields per sweep)", "workload": "C384 884736 columns x 4 fields sharing pe1/pe2, km=kn=79, "
-        "iv=1 kord=1, coarse-pressure target (config 3)", "ms": ms, "columns_per_s": 4 * ncol / ms * 1e3,
-        "roofline": {"bound": "hbm", "achieved": alg_bytes / ms / 1e6, "peak": PEAK_HBM_GBPS, "unit": "GB/s",
-                     "frac": alg_bytes / ms / 1e6 / PEAK_HBM_GBPS, "traffic": None,
-                     "valu_issue_bound_frac": pmc_valu("mappm_merge_multi_kernel<float,4>")},
-    })
+    for arith in ("fast", "exact"):
+        fn = lambda: ops.mappm_multi(pe1, qs, pe2, z_axis=1, arith=arith)
+        fn()
+        torch.cuda.synchronize(dev)
+        ms = time_kernel(fn, reps, dev)
+        alg4 = ncol * (160 * 4 + 4 * 158 * 4.0)
+        out.append({
+            "kernel": f"mappm_sweep_kernel<float,2,2,{'true' if arith == 'fast' else 'false'}> (4 fields per sweep, arith={arith})",
+            "workload": "C384 884736 columns x 4 fields sharing pe1/pe2, km=kn=79, iv=1 kord=1, coarse-pressure target (config 3)",
+            "ms": ms, "ms_per_field": ms / 4, "columns_per_s": 4 * ncol / ms * 1e3,
+            "roofline": {"bound": "hbm", "achieved": alg4 / ms / 1e6, "peak": PEAK_HBM_GBPS, "unit": "GB/s",
+                         "frac": alg4 / ms / 1e6 / PEAK_HBM_GBPS, "traffic": None,
+                         "valu_issue_bound_frac": pmc_valu(f"mappm_sweep_kernel<float, 2, 2, {'true' if arith == 'fast' else 'false'}>")},
+        })
     del qs
     # (the secondary workloads never cost the headline line: a failure is recorded in place of the numbers)
     for fn, fn_args in ((dense_local_benchmark, (dev, steps)), (streaming_benchmark, (dev,)), (restart_pipeline_benchmark, (dev,)),

@@ -134,6 +134,8 @@ SIGNATURES = {
     "fv3hip_ew": (c_int, [c_int, c_void_p, c_void_p, c_void_p, c_double, c_int, c_int64, c_int64, c_int64, c_int64, c_void_p,
                           c_void_p]),
     "fv3hip_cube_edge_rows": (c_int, [c_void_p, c_int, c_int, c_int64, c_int, c_void_p, c_void_p]),
+    "fv3hip_halo_pick": (c_int, [c_void_p, c_int, c_int, c_int64, c_int, POINTER(c_int), POINTER(c_int), POINTER(c_int), c_void_p, c_void_p]),
+    "fv3hip_cast": (c_int, [c_void_p, c_int, c_void_p, c_int, c_int64, c_void_p]),
     "fv3hip_interp_center_to_outer": (c_int, [c_void_p, c_int, c_int64, c_int, c_int, c_int, c_void_p, c_void_p,
                                               c_void_p, c_void_p]),
     "fv3hip_pressure_at_interface": (

@@ -731,6 +731,35 @@ __global__ void cube_edge_rows_kernel(const U *__restrict__ in, U *__restrict__ 
     }
 }
 
+// lo / hi halo vectors of the listed tiles from the table of ALL tiles' boundary vectors (cube_edge_rows_kernel):
+// out[side][i][o][j] = rows[nbr(i, side)][row(i, side)][o][flip(i, side) ? n - 1 - j : j] -- the pick-and-orient step of
+// xgcm's face connections (xgcm.py:7-34) without torch flip / stack kernels.
+struct HaloPick {
+    int nbr[2][6], row[2][6], flip[2][6];
+};
+
+template <typename U>
+__global__ void halo_pick_kernel(const U *__restrict__ rows, U *__restrict__ out, const HaloPick hp, int n_local, int64_t n_mid, int n)
+{
+    const int64_t total = 2 * (int64_t)n_local * n_mid * n;
+    for (int64_t idx = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; idx < total; idx += (int64_t)gridDim.x * blockDim.x) {
+        const int j = (int)(idx % n);
+        int64_t r = idx / n;
+        const int64_t o = r % n_mid;
+        r /= n_mid;
+        const int i = (int)(r % n_local), side = (int)(r / n_local);
+        const int jj = hp.flip[side][i] ? n - 1 - j : j;
+        out[idx] = rows[(((int64_t)hp.nbr[side][i] * 4 + hp.row[side][i]) * n_mid + o) * n + jj];
+    }
+}
+
+// element-wise dtype conversion (the surface-data arithmetic runs in one dtype; restart files mix float32 and float64)
+template <typename Tin, typename Tout>
+__global__ void cast_kernel(const Tin *__restrict__ in, Tout *__restrict__ out, int64_t n)
+{
+    for (int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x) out[i] = (Tout)in[i];
+}
+
 // out[o][y][x'] = 0.5 * (left + right) along `axis` (0 = x: nx+1 points, 1 = y: ny+1 points); beyond the
 // tile the neighbours come from lo / hi [o][along-edge index]
 template <typename T>
@@ -937,6 +966,66 @@ extern "C" int fv3hip_cube_edge_rows(const void *in, int elem_size, int n_tiles,
         hipLaunchKernelGGL((cube_edge_rows_kernel<uint64_t>), dim3((unsigned)blocks), dim3(256), 0, st,
                            static_cast<const uint64_t *>(in), static_cast<uint64_t *>(rows), n_tiles, n_mid, n);
     return check_launch("cube_edge_rows_kernel");
+}
+
+extern "C" int fv3hip_halo_pick(const void *rows, int elem_size, int n_local, int64_t n_mid, int n, const int *nbr, const int *row,
+                                const int *flip, void *out, void *stream)
+{
+    FV3HIP_REQUIRE(elem_size == 4 || elem_size == 8, "elem_size must be 4 or 8, got %d", elem_size);
+    FV3HIP_REQUIRE(n_local >= 0 && n_local <= 6 && n_mid >= 0 && n >= 0, "bad extents");
+    if (n_local == 0 || n_mid == 0 || n == 0) return FV3HIP_OK;
+    FV3HIP_REQUIRE(rows && out && nbr && row && flip, "null pointer");
+    HaloPick hp;
+    memset(&hp, 0, sizeof(hp));
+    for (int side = 0; side < 2; ++side)
+        for (int i = 0; i < n_local; ++i) {
+            const int k = side * n_local + i;
+            FV3HIP_REQUIRE(nbr[k] >= 0 && nbr[k] < 6 && row[k] >= 0 && row[k] < 4, "bad neighbour entry %d", k);
+            hp.nbr[side][i] = nbr[k];
+            hp.row[side][i] = row[k];
+            hp.flip[side][i] = flip[k] ? 1 : 0;
+        }
+    const int64_t total = 2 * (int64_t)n_local * n_mid * n;
+    int64_t blocks = ceil_div(total, 256);
+    if (blocks > 256 * 64) blocks = 256 * 64;
+    hipStream_t st = as_stream(stream);
+    if (elem_size == 4)
+        hipLaunchKernelGGL((halo_pick_kernel<uint32_t>), dim3((unsigned)blocks), dim3(256), 0, st, static_cast<const uint32_t *>(rows),
+                           static_cast<uint32_t *>(out), hp, n_local, n_mid, n);
+    else
+        hipLaunchKernelGGL((halo_pick_kernel<uint64_t>), dim3((unsigned)blocks), dim3(256), 0, st, static_cast<const uint64_t *>(rows),
+                           static_cast<uint64_t *>(out), hp, n_local, n_mid, n);
+    return check_launch("halo_pick_kernel");
+}
+
+namespace {
+template <typename Tin>
+int launch_cast(const void *in, int out_dtype, void *out, int64_t n, hipStream_t st)
+{
+    int64_t blocks = ceil_div(n, 256);
+    if (blocks > 256 * 64) blocks = 256 * 64;
+    if (out_dtype == FV3HIP_F32)
+        hipLaunchKernelGGL((cast_kernel<Tin, float>), dim3((unsigned)blocks), dim3(256), 0, st, static_cast<const Tin *>(in), static_cast<float *>(out), n);
+    else
+        hipLaunchKernelGGL((cast_kernel<Tin, double>), dim3((unsigned)blocks), dim3(256), 0, st, static_cast<const Tin *>(in), static_cast<double *>(out), n);
+    return check_launch("cast_kernel");
+}
+}  // namespace
+
+extern "C" int fv3hip_cast(const void *in, int in_dtype, void *out, int out_dtype, int64_t n, void *stream)
+{
+    FV3HIP_REQUIRE(out_dtype == FV3HIP_F32 || out_dtype == FV3HIP_F64, "out_dtype must be F32 or F64, got %d", out_dtype);
+    FV3HIP_REQUIRE(n >= 0, "negative length");
+    if (n == 0) return FV3HIP_OK;
+    FV3HIP_REQUIRE(in && out, "null pointer");
+    hipStream_t st = as_stream(stream);
+    switch (in_dtype) {
+        case FV3HIP_F32: return launch_cast<float>(in, out_dtype, out, n, st);
+        case FV3HIP_F64: return launch_cast<double>(in, out_dtype, out, n, st);
+        case FV3HIP_I32: return launch_cast<int32_t>(in, out_dtype, out, n, st);
+        case FV3HIP_I64: return launch_cast<int64_t>(in, out_dtype, out, n, st);
+        default: return fail(FV3HIP_EINVAL, "unknown in_dtype %d", in_dtype);
+    }
 }
 
 extern "C" int fv3hip_interp_center_to_outer(const void *in, int dtype, int64_t n_outer, int ny, int nx, int axis,

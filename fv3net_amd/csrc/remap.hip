@@ -16,6 +16,8 @@
 //   * kord, the limiter and the a6 recomputation are compile-time facts (lmt = 0 everywhere), the limiter is select-only;
 //   * every pressure-only subexpression (d4, the five denominators of a level) is formed once per level and shared by
 //     dc(k), al(k) and all NF fields; d4(k+1) and its reciprocal are carried to the next level;
+//   * with 2 or 4 fields per launch the per-field arithmetic runs two fields to an instruction (v_pk_add_f32 / v_pk_mul_f32
+//     on float2 register pairs);
 //   * ARITHMETIC MODES.  EXACT: IEEE division and the Fortran's association order -> bit-identical to the compiled
 //     reference (tests/test_gpu_vertical.py).  FAST: a / b = a * v_rcp_f32(b) (1 ulp) with shared reciprocals; the result
 //     differs from EXACT by a few ulp of the layer's values (<= 1e-5 relative to the column's range is asserted in the
@@ -28,35 +30,60 @@
 namespace fv3hip {
 namespace {
 
-__device__ __forceinline__ float s_sign(float a, float b) { return copysignf(fabsf(a), b); }
-__device__ __forceinline__ float s_min2(float a, float b) { return (a < b) ? a : b; }
-__device__ __forceinline__ float s_max2(float a, float b) { return (a > b) ? a : b; }
-__device__ __forceinline__ float s_min3(float a, float b, float c) { return s_min2(s_min2(a, b), c); }
-__device__ __forceinline__ float s_max3(float a, float b, float c) { return s_max2(s_max2(a, b), c); }
+// Per-field quantities are held W fields to a register tuple: W = 1 (float) or W = 2 (two fields in an ext_vector float2, whose
+// adds and multiplies the compiler emits as v_pk_add_f32 / v_pk_mul_f32 -- two fields per VALU instruction; compares and
+// selects stay per component).  Every operation is component-wise IEEE, so a packed field is bit-identical to a lone one.
+typedef float f32x2 __attribute__((ext_vector_type(2)));
+typedef int i32x2 __attribute__((ext_vector_type(2)));
+template <int W> struct FieldVec;
+template <> struct FieldVec<1> { using type = float; };
+template <> struct FieldVec<2> { using type = f32x2; };
 
-// A denominator: EXACT keeps the value and divides (IEEE) at every use, FAST takes the reciprocal once.
+__device__ __forceinline__ float v_sel(bool c, float a, float b) { return c ? a : b; }
+__device__ __forceinline__ f32x2 v_sel(i32x2 c, f32x2 a, f32x2 b) { return c ? a : b; }
+__device__ __forceinline__ float v_min2(float a, float b) { return (a < b) ? a : b; }
+__device__ __forceinline__ f32x2 v_min2(f32x2 a, f32x2 b) { return (a < b) ? a : b; }
+__device__ __forceinline__ float v_max2(float a, float b) { return (a > b) ? a : b; }
+__device__ __forceinline__ f32x2 v_max2(f32x2 a, f32x2 b) { return (a > b) ? a : b; }
+template <typename V> __device__ __forceinline__ V v_min3(V a, V b, V c) { return v_min2(v_min2(a, b), c); }
+template <typename V> __device__ __forceinline__ V v_max3(V a, V b, V c) { return v_max2(v_max2(a, b), c); }
+__device__ __forceinline__ float v_abs(float a) { return fabsf(a); }
+__device__ __forceinline__ f32x2 v_abs(f32x2 a) { return f32x2{fabsf(a[0]), fabsf(a[1])}; }
+__device__ __forceinline__ float v_sign(float a, float b) { return copysignf(fabsf(a), b); }
+__device__ __forceinline__ f32x2 v_sign(f32x2 a, f32x2 b) { return f32x2{copysignf(fabsf(a[0]), b[0]), copysignf(fabsf(a[1]), b[1])}; }
+__device__ __forceinline__ float v_splat(float, float x) { return x; }
+__device__ __forceinline__ f32x2 v_splat(f32x2, float x) { return f32x2{x, x}; }
+__device__ __forceinline__ float v_get(float a, int) { return a; }
+__device__ __forceinline__ float v_get(f32x2 a, int i) { return a[i]; }
+__device__ __forceinline__ void v_set(float &a, int, float x) { a = x; }
+__device__ __forceinline__ void v_set(f32x2 &a, int i, float x) { a[i] = x; }
+
+// A denominator (always a pressure-only scalar): EXACT keeps the value and divides (IEEE) at every use, FAST takes the
+// reciprocal once.
 template <bool FAST>
 struct Den {
     float v;
     __device__ __forceinline__ explicit Den(float d) : v(FAST ? __builtin_amdgcn_rcpf(d) : d) {}
     __device__ __forceinline__ float under(float num) const { return FAST ? num * v : num / v; }
+    __device__ __forceinline__ f32x2 under(f32x2 num) const { return FAST ? num * v : num / v; }
 };
 
 // mappm.f90:875-894 (lmt = 0), select-only
-__device__ __forceinline__ void limit0(float dm, float q, float &al, float &ar, float &a6)
+template <typename V>
+__device__ __forceinline__ void limit0(V dm, V q, V &al, V &ar, V &a6)
 {
-    const float da1 = ar - al;
-    const float da2 = da1 * da1;
-    const float a6da = a6 * da1;
-    const bool lo = a6da < -da2, hi = a6da > da2, flat = (dm == 0.f);
-    const float a6_lo = 3.f * (al - q), a6_hi = 3.f * (ar - q);
-    const float ar_lo = al - a6_lo, al_hi = ar - a6_hi;
-    float nal = (!lo && hi) ? al_hi : al;
-    float nar = lo ? ar_lo : ar;
-    float na6 = lo ? a6_lo : (hi ? a6_hi : a6);
-    al = flat ? q : nal;
-    ar = flat ? q : nar;
-    a6 = flat ? 0.f : na6;
+    const V da1 = ar - al;
+    const V da2 = da1 * da1;
+    const V a6da = a6 * da1;
+    const auto lo = a6da < -da2, hi = a6da > da2, flat = (dm == v_splat(dm, 0.f));
+    const V a6_lo = 3.f * (al - q), a6_hi = 3.f * (ar - q);
+    const V ar_lo = al - a6_lo, al_hi = ar - a6_hi;
+    const V nal = v_sel(lo, al, v_sel(hi, al_hi, al));
+    const V nar = v_sel(lo, ar_lo, ar);
+    const V na6 = v_sel(lo, a6_lo, v_sel(hi, a6_hi, a6));
+    al = v_sel(flat, q, nal);
+    ar = v_sel(flat, q, nar);
+    a6 = v_sel(flat, v_splat(q, 0.f), na6);
 }
 
 template <typename Tin>
@@ -65,9 +92,11 @@ __device__ __forceinline__ float ld(const char *base, unsigned int boff)
     return (float)*reinterpret_cast<const Tin *>(base + boff);
 }
 
-template <typename Tin, int NF, bool FAST>
+template <typename Tin, int NV, int W, bool FAST>
 __global__ __launch_bounds__(64) void mappm_sweep_kernel(const SweepArgs a)
 {
+    using V = typename FieldVec<W>::type;
+    constexpr int NF = NV * W;
     constexpr unsigned int ESZ = sizeof(Tin);
     const int lane = threadIdx.x;
     const int64_t wcol = a.col0 + (int64_t)blockIdx.x * 64;  // first column of the wave (uniform)
@@ -75,7 +104,7 @@ __global__ __launch_bounds__(64) void mappm_sweep_kernel(const SweepArgs a)
     const int km = a.km, kn = a.kn, iv = a.iv;
     const int64_t plane = a.n_inner;
     // uniform row bases of the wave's batch, first column of the wave
-    const char *pe1_row = static_cast<const char *>(a.pe1) + (b * (km + 1) * plane + c0) * ESZ;  // row L+4 (0-based), walks down
+    const char *pe1_row = static_cast<const char *>(a.pe1) + (b * (km + 1) * plane + c0) * ESZ;  // walks down the levels
     const char *pe2_b = static_cast<const char *>(a.pe2) + (b * (kn + 1) * plane + c0) * ESZ;
     const char *q1_row[NF];
     char *q2_b[NF];
@@ -89,23 +118,30 @@ __global__ __launch_bounds__(64) void mappm_sweep_kernel(const SweepArgs a)
     const unsigned int row_out = (unsigned int)plane * 4u;
     const float r3 = 1.f / 3.f, r23 = 2.f / 3.f;
     const int km1 = km - 1;
+    auto ldq = [&](int v, size_t row_off) {  // the W fields of slot v at a row of q1
+        V x;
+#pragma unroll
+        for (int w = 0; w < W; ++w) v_set(x, w, ld<Tin>(q1_row[v * W + w] + row_off, lin));
+        return x;
+    };
 
     // ---- head of the column: pe1(1..5), q1(1..4) ----
     float pe_a = ld<Tin>(pe1_row, lin), pe_b = ld<Tin>(pe1_row + row_in, lin), pe_c = ld<Tin>(pe1_row + 2 * (size_t)row_in, lin),
           pe_d = ld<Tin>(pe1_row + 3 * (size_t)row_in, lin), pe_e = ld<Tin>(pe1_row + 4 * (size_t)row_in, lin);
     const float pe1_top = pe_a, pe1_bot = ld<Tin>(pe1_row + (size_t)km * row_in, lin);
     pe1_row += 5 * (size_t)row_in;  // -> pe1(6)
-    float q0[NF], qp1[NF], qp2[NF], qp3[NF], q_top[NF], q_bot[NF];
+    V q0[NV], qp1[NV], qp2[NV], qp3[NV], q_top[NV], q_bot[NV];
 #pragma unroll
-    for (int f = 0; f < NF; ++f) {
-        q0[f] = ld<Tin>(q1_row[f], lin);
-        qp1[f] = ld<Tin>(q1_row[f] + row_in, lin);
-        qp2[f] = ld<Tin>(q1_row[f] + 2 * (size_t)row_in, lin);
-        qp3[f] = ld<Tin>(q1_row[f] + 3 * (size_t)row_in, lin);
-        q_top[f] = q0[f];
-        q_bot[f] = ld<Tin>(q1_row[f] + (size_t)km1 * row_in, lin);
-        q1_row[f] += 4 * (size_t)row_in;  // -> q1(5)
+    for (int v = 0; v < NV; ++v) {
+        q0[v] = ldq(v, 0);
+        qp1[v] = ldq(v, row_in);
+        qp2[v] = ldq(v, 2 * (size_t)row_in);
+        qp3[v] = ldq(v, 3 * (size_t)row_in);
+        q_top[v] = q0[v];
+        q_bot[v] = ldq(v, (size_t)km1 * row_in);
     }
+#pragma unroll
+    for (int f = 0; f < NF; ++f) q1_row[f] += 4 * (size_t)row_in;  // -> q1(5)
     bool bad = !(pe_b >= pe_a) | !(pe_c >= pe_b) | !(pe_d >= pe_c) | !(pe_e >= pe_d);
     float d0 = pe_b - pe_a, dp1 = pe_c - pe_b, dp2 = pe_d - pe_c, dp3 = pe_e - pe_d;  // dp(L..L+3)
 
@@ -113,8 +149,8 @@ __global__ __launch_bounds__(64) void mappm_sweep_kernel(const SweepArgs a)
     // (z, x, y, w), q(kk-1..kk+1) and dc(kk-1).  The pressure-only terms are formed once for all fields; d4c and its
     // reciprocal are next level's d4b.
     float d4b = d0 + dp1;  // d4(2) = dp(1) + dp(2): becomes d4(kk) of the first reconstructed level below
-    auto level = [&](float z, float x, float y, float w, float d4b_, const Den<FAST> r4b, const float *qa, const float *qb,
-                     const float *qc, const float *dca, float *dcb, float *alb, float &d4c_out, Den<FAST> &r4c_out) {
+    auto level = [&](float z, float x, float y, float w, float d4b_, const Den<FAST> r4b, const V *qa, const V *qb,
+                     const V *qc, const V *dca, V *dcb, V *alb, float &d4c_out, Den<FAST> &r4c_out) {
         const float d4a = z + x, d4c = y + w;
         const Den<FAST> r4c(d4c);
         const float c1 = r4c.under(x + 0.5f * y);          // (dp(k-1) + 0.5 dp(k)) / d4(k+1)
@@ -123,21 +159,21 @@ __global__ __launch_bounds__(64) void mappm_sweep_kernel(const SweepArgs a)
         const float a1 = Den<FAST>(d4b_ + x).under(d4a);   // d4(k-1) / (d4(k) + dp(k-1))
         const float a2 = Den<FAST>(d4b_ + y).under(d4c);   // d4(k+1) / (d4(k) + dp(k))
         const float g = Den<FAST>(d4a + d4c).under(2.f);   // 2 / (d4(k-1) + d4(k+1))
-        const float a12 = a1 - a2;
+        const float a12 = a1 - a2, xa1 = x * a1;
 #pragma unroll
-        for (int f = 0; f < NF; ++f) {
-            const float df2 = r3p.under(y * (c1 * (qc[f] - qb[f]) + c2 * (qb[f] - qa[f])));
-            const float dc = s_sign(s_min3(fabsf(df2), s_max3(qa[f], qb[f], qc[f]) - qb[f], qb[f] - s_min3(qa[f], qb[f], qc[f])), df2);
-            const float c1f = r4b.under((qb[f] - qa[f]) * x);
-            alb[f] = qa[f] + c1f + g * (y * (c1f * a12 + a2 * dca[f]) - x * a1 * dc);
-            dcb[f] = dc;
+        for (int v = 0; v < NV; ++v) {
+            const V df2 = r3p.under(y * (c1 * (qc[v] - qb[v]) + c2 * (qb[v] - qa[v])));
+            const V dc = v_sign(v_min3(v_abs(df2), v_max3(qa[v], qb[v], qc[v]) - qb[v], qb[v] - v_min3(qa[v], qb[v], qc[v])), df2);
+            const V c1f = r4b.under((qb[v] - qa[v]) * x);
+            alb[v] = qa[v] + c1f + g * (y * (c1f * a12 + a2 * dca[v]) - xa1 * dc);
+            dcb[v] = dc;
         }
         d4c_out = d4c;
         r4c_out = r4c;
     };
 
     // ---- prologue: dc(2), dc(3), al(3), then the top boundary (mappm.f90:689-725) ----
-    float al0[NF], al1[NF], al2[NF], dc0[NF], dc1[NF], dc2[NF], ar_km[NF];
+    V al0[NV], al1[NV], al2[NV], dc0[NV], dc1[NV], dc2[NV], ar_km[NV];
     float d4c = dp1 + dp2;  // d4(3)
     Den<FAST> r4c(d4c);
     {
@@ -147,42 +183,45 @@ __global__ __launch_bounds__(64) void mappm_sweep_kernel(const SweepArgs a)
         const float c2 = r4b.under(dp2 + 0.5f * dp1);
         const Den<FAST> r3p(d4b + dp2);
 #pragma unroll
-        for (int f = 0; f < NF; ++f) {
-            const float df2 = r3p.under(dp1 * (c1 * (qp2[f] - qp1[f]) + c2 * (qp1[f] - q0[f])));
-            dc1[f] = s_sign(s_min3(fabsf(df2), s_max3(q0[f], qp1[f], qp2[f]) - qp1[f], qp1[f] - s_min3(q0[f], qp1[f], qp2[f])), df2);
+        for (int v = 0; v < NV; ++v) {
+            const V df2 = r3p.under(dp1 * (c1 * (qp2[v] - qp1[v]) + c2 * (qp1[v] - q0[v])));
+            dc1[v] = v_sign(v_min3(v_abs(df2), v_max3(q0[v], qp1[v], qp2[v]) - qp1[v], qp1[v] - v_min3(q0[v], qp1[v], qp2[v])), df2);
         }
     }
     {
-        float dc_3[NF], al_3[NF], d4n;
+        V dc_3[NV], al_3[NV];
+        float d4n;
         Den<FAST> r4n(1.f);
         level(d0, dp1, dp2, dp3, d4c, r4c, qp1, qp2, qp3, dc1, dc_3, al_3, d4n, r4n);  // kk = 3 (recomputed by the loop's L = 1)
         const float d1 = d0, d2 = dp1;
         const Den<FAST> r12(d1 + d2);
         const Den<FAST> rcub(d2 * (2.f * d2 * d2 + d1 * (d2 + 3.f * d1)));
+        const float poly = d2 * (5.f * d1 + d2) - 3.f * d1 * d1, d2p = d2 + 3.f * d1, d1sq = d1 * d1;
 #pragma unroll
-        for (int f = 0; f < NF; ++f) {
-            const float qm = r12.under(d2 * q0[f] + d1 * qp1[f]);
-            const float dq = r12.under(2.f * (qp1[f] - q0[f]));
-            const float c1 = rcub.under(4.f * (al_3[f] - qm - d2 * dq));
-            const float c3 = dq - 0.5f * c1 * (d2 * (5.f * d1 + d2) - 3.f * d1 * d1);
-            float a2 = qm - 0.25f * c1 * d1 * d2 * (d2 + 3.f * d1);
-            float a1 = d1 * (2.f * c1 * (d1 * d1) - c3) + a2;
-            a2 = s_max2(a2, s_min2(q0[f], qp1[f]));
-            a2 = s_min2(a2, s_max2(q0[f], qp1[f]));
-            dc0[f] = 0.5f * (a2 - q0[f]);
+        for (int v = 0; v < NV; ++v) {
+            const V zero = v_splat(q0[v], 0.f);
+            const V qm = r12.under(d2 * q0[v] + d1 * qp1[v]);
+            const V dq = r12.under(2.f * (qp1[v] - q0[v]));
+            const V c1 = rcub.under(4.f * (al_3[v] - qm - d2 * dq));
+            const V c3 = dq - 0.5f * c1 * poly;
+            V a2 = qm - 0.25f * c1 * d1 * d2 * d2p;
+            V a1 = d1 * (2.f * c1 * d1sq - c3) + a2;
+            a2 = v_max2(a2, v_min2(q0[v], qp1[v]));
+            a2 = v_min2(a2, v_max2(q0[v], qp1[v]));
+            dc0[v] = 0.5f * (a2 - q0[v]);
             if (iv == 0) {
-                a1 = s_max2(0.f, a1);
-                a2 = s_max2(0.f, a2);
+                a1 = v_max2(zero, a1);
+                a2 = v_max2(zero, a2);
             } else if (iv == -1) {
-                if (a1 * q0[f] <= 0.f) a1 = 0.f;
+                a1 = v_sel(a1 * q0[v] <= zero, zero, a1);
             } else if (iv == 2 || iv == -2) {
-                a1 = q0[f];
+                a1 = q0[v];
             }
-            al0[f] = a1;
-            al1[f] = a2;
-            al2[f] = 0.f;
-            dc2[f] = 0.f;
-            ar_km[f] = 0.f;
+            al0[v] = a1;
+            al1[v] = a2;
+            al2[v] = zero;
+            dc2[v] = zero;
+            ar_km[v] = zero;
         }
     }
     // the loop's first level is kk = 3: its d4(kk) = d4(3), already in (d4c, r4c)
@@ -225,9 +264,10 @@ __global__ __launch_bounds__(64) void mappm_sweep_kernel(const SweepArgs a)
     int k = 1;
     float p2k = PE2(0), p2k1 = PE2(1);  // pe2(k), pe2(k+1)   (kn >= 1)
     bool accum = false;
-    float qsum[NF], dpsum = 0.f;
+    V qsum[NV];
+    float dpsum = 0.f;
 #pragma unroll
-    for (int f = 0; f < NF; ++f) qsum[f] = 0.f;
+    for (int v = 0; v < NV; ++v) qsum[v] = v_splat(q0[v], 0.f);
     auto advance = [&]() {
         ++k;
         if (!(p2k1 >= p2k)) bad = true;  // also catches NaN
@@ -244,17 +284,15 @@ __global__ __launch_bounds__(64) void mappm_sweep_kernel(const SweepArgs a)
     // row `rf` out -- one coalesced row per field, scalar address -- once every lane is past it, at the top of an
     // iteration, right after the wait.  `rl` (per lane) = rows [0, rl) of this lane no longer live in the ring: a lane
     // that runs kOut rows ahead of the slowest one writes its own oldest row out first.  Ill-formed lanes count as past
-    // every row; whatever the flush writes for them is overwritten by the fallback pass.
-#ifndef SWEEP_KOUT
-#define SWEEP_KOUT 8
-#endif
-    constexpr int kOut = SWEEP_KOUT;
+    // every row; whatever the flush writes for them is overwritten by the fallback pass.  (kOut = 16 and 32 were slower:
+    // the ring's LDS footprint costs occupancy.)
+    constexpr int kOut = 8;
     __shared__ float oring_lds[NF * kOut * 64];
     float *oring = oring_lds + lane;
     int rf = 0;  // uniform: rows [0, rf) are in memory for every lane
     int rl = 0;  // per lane (>= rf where it matters)
-    float out_v[NF];
-    auto OUT = [&](int f, float v) { out_v[f] = v; };
+    V out_v[NV];
+    auto OUT = [&](int v, V x) { out_v[v] = x; };
     auto out_end = [&]() {  // after the OUTs of target k (before advance())
         const int r = k - 1, slot = r & (kOut - 1);
         if (r - kOut >= (rl > rf ? rl : rf)) {  // the slot still holds this lane's row r - kOut: write it out now
@@ -264,7 +302,7 @@ __global__ __launch_bounds__(64) void mappm_sweep_kernel(const SweepArgs a)
             rl = r - kOut + 1;
         }
 #pragma unroll
-        for (int f = 0; f < NF; ++f) oring[(f * kOut + slot) * 64] = out_v[f];
+        for (int f = 0; f < NF; ++f) oring[(f * kOut + slot) * 64] = v_get(out_v[f / W], f % W);
     };
     auto flush_rows = [&](int max_rows) {  // uniform: rows every lane has written go to memory
 #pragma unroll 1
@@ -283,15 +321,16 @@ __global__ __launch_bounds__(64) void mappm_sweep_kernel(const SweepArgs a)
     if (!(p2k1 >= p2k)) bad = true;
     while (k <= kn && !bad && p2k <= pe1_top) {  // targets that start at or above the old top (mappm.f90:62-64)
 #pragma unroll
-        for (int f = 0; f < NF; ++f) OUT(f, q_top[f]);
+        for (int v = 0; v < NV; ++v) OUT(v, q_top[v]);
         out_end();
         advance();
     }
     bool live = (k <= kn) && !bad && !(p2k >= pe1_bot);
 
-    float q_in[NF], pe_in = pe_e;
+    V q_in[NV];
+    float pe_in = pe_e;
 #pragma unroll
-    for (int f = 0; f < NF; ++f) q_in[f] = 0.f;
+    for (int v = 0; v < NV; ++v) q_in[v] = v_splat(q0[v], 0.f);
     for (int L = 1; L <= km; ++L) {
         // ---- the interface rows requested during the previous iteration land in the ring ----
         if (jr > jl) ring[(jl & (kRing - 1)) * 64] = pv0;
@@ -301,25 +340,23 @@ __global__ __launch_bounds__(64) void mappm_sweep_kernel(const SweepArgs a)
         if (L > 1) {  // level L becomes the current one
             if (!(pe_in >= pe_e)) bad = true;
 #pragma unroll
-            for (int f = 0; f < NF; ++f) {
-                q0[f] = qp1[f]; qp1[f] = qp2[f]; qp2[f] = qp3[f]; qp3[f] = q_in[f];
-                al0[f] = al1[f]; al1[f] = al2[f];
-                dc0[f] = dc1[f]; dc1[f] = dc2[f];
+            for (int v = 0; v < NV; ++v) {
+                q0[v] = qp1[v]; qp1[v] = qp2[v]; qp2[v] = qp3[v]; qp3[v] = q_in[v];
+                al0[v] = al1[v]; al1[v] = al2[v];
+                dc0[v] = dc1[v]; dc1[v] = dc2[v];
             }
             d0 = dp1; dp1 = dp2; dp2 = dp3; dp3 = pe_in - pe_e;
             pe_a = pe_b; pe_b = pe_c; pe_c = pe_d; pe_d = pe_e; pe_e = pe_in;
         }
         // Order inside an iteration: the requests for the next iteration first, then layer L's finalisation and its
-        // emits (the q2 stores), then the reconstruction of level L + 2 -- vmcnt is one in-order counter for loads and
-        // stores, so the wait at the top of the next iteration also waits for these stores: with the reconstruction
-        // behind them they have that long to complete instead of no time at all.
+        // emits, then the reconstruction of level L + 2 -- the wait at the top of the next iteration also waits for
+        // whatever was stored here, so the reconstruction sits behind the stores.
         // ---- requests for the next iteration: q(L+4), pe1(L+5) ----
         if (L + 4 <= km) {
 #pragma unroll
-            for (int f = 0; f < NF; ++f) {
-                q_in[f] = ld<Tin>(q1_row[f], lin);
-                q1_row[f] += row_in;
-            }
+            for (int v = 0; v < NV; ++v) q_in[v] = ldq(v, 0);
+#pragma unroll
+            for (int f = 0; f < NF; ++f) q1_row[f] += row_in;
             pe_in = ld<Tin>(pe1_row, lin);
             pe1_row += row_in;
         }
@@ -335,13 +372,13 @@ __global__ __launch_bounds__(64) void mappm_sweep_kernel(const SweepArgs a)
             }
         }
         // ---- finalise layer L: A6 and the monotonicity constraint (mappm.f90:773-849 with lmt = 0) ----
-        float al[NF], ar[NF], a6[NF];
+        V al[NV], ar[NV], a6[NV];
 #pragma unroll
-        for (int f = 0; f < NF; ++f) {
-            al[f] = al0[f];
-            ar[f] = (L == km) ? ar_km[f] : al1[f];
-            a6[f] = 3.f * (2.f * q0[f] - (al[f] + ar[f]));
-            limit0(dc0[f], q0[f], al[f], ar[f], a6[f]);
+        for (int v = 0; v < NV; ++v) {
+            al[v] = al0[v];
+            ar[v] = (L == km) ? ar_km[v] : al1[v];
+            a6[v] = 3.f * (2.f * q0[v] - (al[v] + ar[v]));
+            limit0(dc0[v], q0[v], al[v], ar[v], a6[v]);
         }
         const float pL = pe_a, pL1 = pe_b;
         const Den<FAST> rd0(d0);
@@ -352,10 +389,11 @@ __global__ __launch_bounds__(64) void mappm_sweep_kernel(const SweepArgs a)
             const float PR = rd0.under(delp);
             dpsum = dpsum + delp;
             const Den<FAST> rs(dpsum);
-    #pragma unroll
-            for (int f = 0; f < NF; ++f) {
-                qsum[f] = qsum[f] + delp * (al[f] + 0.5f * PR * (ar[f] - al[f] + a6[f] * (1.f - r23 * PR)));
-                OUT(f, rs.under(qsum[f]));
+            const float hp = 0.5f * PR, tp = 1.f - r23 * PR;
+#pragma unroll
+            for (int v = 0; v < NV; ++v) {
+                qsum[v] = qsum[v] + delp * (al[v] + hp * (ar[v] - al[v] + a6[v] * tp));
+                OUT(v, rs.under(qsum[v]));
             }
             out_end();
             accum = false;
@@ -365,9 +403,9 @@ __global__ __launch_bounds__(64) void mappm_sweep_kernel(const SweepArgs a)
         while (live && !accum && (p2k >= pL && p2k <= pL1) && (p2k1 <= pL1)) {
             const float PR = rd0.under(p2k1 - pL);
             const float PL = rd0.under(p2k - pL);
-            const float TT = r3 * (PR * (PR + PL) + PL * PL);
-    #pragma unroll
-            for (int f = 0; f < NF; ++f) OUT(f, al[f] + 0.5f * (a6[f] + ar[f] - al[f]) * (PR + PL) - a6[f] * TT);
+            const float TT = r3 * (PR * (PR + PL) + PL * PL), sp = PR + PL;
+#pragma unroll
+            for (int v = 0; v < NV; ++v) OUT(v, al[v] + 0.5f * (a6[v] + ar[v] - al[v]) * sp - a6[v] * TT);
             out_end();
             advance();
             live = (k <= kn) && !bad && !(p2k >= pe1_bot);
@@ -375,15 +413,15 @@ __global__ __launch_bounds__(64) void mappm_sweep_kernel(const SweepArgs a)
         if (live) {
             if (accum) {  // whole layer (mappm.f90:99-104)
 #pragma unroll
-                for (int f = 0; f < NF; ++f) qsum[f] = qsum[f] + d0 * q0[f];
+                for (int v = 0; v < NV; ++v) qsum[v] = qsum[v] + d0 * q0[v];
                 dpsum = dpsum + d0;
             } else if (p2k >= pL && p2k <= pL1) {  // fractional area (mappm.f90:85-92)
                 const float PL = rd0.under(p2k - pL);
                 const float delp = pL1 - p2k;
-                const float TT = r3 * (1.f + PL * (1.f + PL));
+                const float TT = r3 * (1.f + PL * (1.f + PL)), sp = 1.f + PL;
 #pragma unroll
-                for (int f = 0; f < NF; ++f)
-                    qsum[f] = delp * (al[f] + 0.5f * (a6[f] + ar[f] - al[f]) * (1.f + PL) - a6[f] * TT);
+                for (int v = 0; v < NV; ++v)
+                    qsum[v] = delp * (al[v] + 0.5f * (a6[v] + ar[v] - al[v]) * sp - a6[v] * TT);
                 dpsum = delp;
                 accum = true;
             }
@@ -401,26 +439,28 @@ __global__ __launch_bounds__(64) void mappm_sweep_kernel(const SweepArgs a)
             const float d1 = dp2, d2 = dp1;  // dp(km), dp(km-1)
             const Den<FAST> r12(d1 + d2);
             const Den<FAST> rcub(d2 * (2.f * d2 * d2 + d1 * (d2 + 3.f * d1)));
+            const float poly = d2 * (5.f * d1 + d2) - 3.f * d1 * d1, d2p = d2 + 3.f * d1, d1sq = d1 * d1;
 #pragma unroll
-            for (int f = 0; f < NF; ++f) {
-                const float qk = qp2[f], qk1 = qp1[f];  // q(km), q(km-1)
-                const float qm = r12.under(d2 * qk + d1 * qk1);
-                const float dq = r12.under(2.f * (qk1 - qk));
-                const float c1 = rcub.under(al1[f] - qm - d2 * dq);
-                const float c3 = dq - 2.0f * c1 * (d2 * (5.f * d1 + d2) - 3.f * d1 * d1);
-                float alk = qm - c1 * d1 * d2 * (d2 + 3.f * d1);
-                float ark = d1 * (8.f * c1 * (d1 * d1) - c3) + alk;
-                alk = s_max2(alk, s_min2(qk, qk1));
-                alk = s_min2(alk, s_max2(qk, qk1));
-                dc2[f] = 0.5f * (qk - alk);
+            for (int v = 0; v < NV; ++v) {
+                const V zero = v_splat(q0[v], 0.f);
+                const V qk = qp2[v], qk1 = qp1[v];  // q(km), q(km-1)
+                const V qm = r12.under(d2 * qk + d1 * qk1);
+                const V dq = r12.under(2.f * (qk1 - qk));
+                const V c1 = rcub.under(al1[v] - qm - d2 * dq);
+                const V c3 = dq - 2.0f * c1 * poly;
+                V alk = qm - c1 * d1 * d2 * d2p;
+                V ark = d1 * (8.f * c1 * d1sq - c3) + alk;
+                alk = v_max2(alk, v_min2(qk, qk1));
+                alk = v_min2(alk, v_max2(qk, qk1));
+                dc2[v] = 0.5f * (qk - alk);
                 if (iv == 0) {
-                    alk = s_max2(0.f, alk);
-                    ark = s_max2(0.f, ark);
+                    alk = v_max2(zero, alk);
+                    ark = v_max2(zero, ark);
                 } else if (iv < 0) {
-                    if (qk * ark <= 0.f) ark = 0.f;
+                    ark = v_sel(qk * ark <= zero, zero, ark);
                 }
-                al2[f] = alk;
-                ar_km[f] = ark;
+                al2[v] = alk;
+                ar_km[v] = ark;
             }
         }
     }
@@ -430,19 +470,19 @@ __global__ __launch_bounds__(64) void mappm_sweep_kernel(const SweepArgs a)
         const float delp = p2k1 - pe1_bot;
         if (delp > 0.f) {
 #pragma unroll
-            for (int f = 0; f < NF; ++f) qsum[f] = qsum[f] + delp * q_bot[f];
+            for (int v = 0; v < NV; ++v) qsum[v] = qsum[v] + delp * q_bot[v];
             dpsum = dpsum + delp;
         }
         const Den<FAST> rs(dpsum);
 #pragma unroll
-        for (int f = 0; f < NF; ++f) OUT(f, rs.under(qsum[f]));
+        for (int v = 0; v < NV; ++v) OUT(v, rs.under(qsum[v]));
         out_end();
         advance();
     }
     while (k <= kn && !bad) {
         if (p2k >= pe1_bot) {
-    #pragma unroll
-            for (int f = 0; f < NF; ++f) OUT(f, q_bot[f]);
+#pragma unroll
+            for (int v = 0; v < NV; ++v) OUT(v, q_bot[v]);
             out_end();
             advance();
         } else {
@@ -453,23 +493,24 @@ __global__ __launch_bounds__(64) void mappm_sweep_kernel(const SweepArgs a)
     if (bad) a.bad_cols[atomicAdd(a.n_bad, 1u)] = (unsigned int)(blockIdx.x * 64 + lane);  // redone by mappm_fallback_kernel
 }
 
-template <typename Tin, int NF>
+template <typename Tin, int NV, int W>
 void launch_sweep2(const SweepArgs &a, int64_t n_waves, bool fast, hipStream_t st)
 {
     if (fast)
-        hipLaunchKernelGGL((mappm_sweep_kernel<Tin, NF, true>), dim3((unsigned)n_waves), dim3(64), 0, st, a);
+        hipLaunchKernelGGL((mappm_sweep_kernel<Tin, NV, W, true>), dim3((unsigned)n_waves), dim3(64), 0, st, a);
     else
-        hipLaunchKernelGGL((mappm_sweep_kernel<Tin, NF, false>), dim3((unsigned)n_waves), dim3(64), 0, st, a);
+        hipLaunchKernelGGL((mappm_sweep_kernel<Tin, NV, W, false>), dim3((unsigned)n_waves), dim3(64), 0, st, a);
 }
 
+// fields per launch -> (register slots, fields per slot): pairs of fields share packed-math instructions
 template <typename Tin>
 void launch_sweep1(const SweepArgs &a, int nf, int64_t n_waves, bool fast, hipStream_t st)
 {
     switch (nf) {
-        case 1: launch_sweep2<Tin, 1>(a, n_waves, fast, st); break;
-        case 2: launch_sweep2<Tin, 2>(a, n_waves, fast, st); break;
-        case 3: launch_sweep2<Tin, 3>(a, n_waves, fast, st); break;
-        default: launch_sweep2<Tin, 4>(a, n_waves, fast, st); break;
+        case 1: launch_sweep2<Tin, 1, 1>(a, n_waves, fast, st); break;
+        case 2: launch_sweep2<Tin, 1, 2>(a, n_waves, fast, st); break;
+        case 3: launch_sweep2<Tin, 3, 1>(a, n_waves, fast, st); break;
+        default: launch_sweep2<Tin, 2, 2>(a, n_waves, fast, st); break;
     }
 }
 

@@ -38,15 +38,20 @@ _ROW = {("x", "first"): 0, ("x", "last"): 1, ("y", "first"): 2, ("y", "last"): 3
 
 def halos_from_rows(rows: torch.Tensor, tiles, axis: str):
     """(lo, hi) [len(tiles), ..., n] for ``axis`` from the boundary vectors of ALL six tiles
-    (``rows`` [6, 4, ..., n] as returned by ``ops.cube_edge_rows``)."""
-    lo, hi = [], []
+    (``rows`` [6, 4, ..., n] as returned by ``ops.cube_edge_rows``): one pick-and-orient kernel, no copies."""
+    nbr, row, flip = [[], []], [[], []], [[], []]
     for t in tiles:
         (ln, la), (rn, ra) = FV3_FACE_CONNECTIONS[int(t)][axis]
-        left = rows[ln, _ROW[(la, "last")]]
-        right = rows[rn, _ROW[(ra, "first")]]
-        lo.append(left if la == axis else left.flip(-1))
-        hi.append(right if ra == axis else right.flip(-1))
-    return torch.stack(lo), torch.stack(hi)
+        for side, (n_, a_, which) in enumerate(((ln, la, "last"), (rn, ra, "first"))):
+            nbr[side].append(n_)
+            row[side].append(_ROW[(a_, which)])
+            flip[side].append(0 if a_ == axis else 1)
+    if not rows.is_cuda:  # (CPU-backend tests of the exchange: the same picks with array indexing)
+        pick = lambda side: torch.stack([rows[n_, r_].flip(-1) if f_ else rows[n_, r_]
+                                         for n_, r_, f_ in zip(nbr[side], row[side], flip[side])])
+        return pick(0), pick(1)
+    both = ops.halo_pick(rows, nbr[0] + nbr[1], row[0] + row[1], flip[0] + flip[1])
+    return both[0], both[1]
 
 
 def interp_tiles_to_edges(field: torch.Tensor, axis: str) -> torch.Tensor:

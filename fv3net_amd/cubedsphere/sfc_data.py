@@ -42,8 +42,8 @@ def coarse_grain_sfc_data_tensors(fields: Mapping[str, torch.Tensor], area: torc
     """The method on device tensors whose last two dims are (y, x): 2-D fields share their leading
     dims with ``area``; 3-D (soil level) fields have one extra axis before (y, x)."""
     dt = torch.float64 if any(t.dtype == torch.float64 for t in fields.values()) or area.dtype == torch.float64 else torch.float32
-    fields = {k: v.to(dt) for k, v in fields.items()}
-    area = area.to(dt)
+    fields = {k: ops.cast(v, dt) for k, v in fields.items()}
+    area = ops.cast(area, dt)
     slmsk_c = _mode(fields["slmsk"], f)
     dom_sfc = ops.ew("isclose", fields["slmsk"], ops.block_upsample(slmsk_c, f))
     vtype_c = _mode(ops.ew("where_nan", fields["vtype"], dom_sfc), f)
@@ -100,7 +100,7 @@ def coarse_grain_sfc_data_tensors(fields: Mapping[str, torch.Tensor], area: torc
         out["canopy"] = ops.ew("select_s", out["canopy"], ops.ew("lt_s", out["shdmin"], scalar=SHDMIN_THRESHOLD), scalar=0.0)
     if "shdmin" in out:
         out["shdmin"] = ops.ew("select_s", out["shdmin"], land_ice, scalar=0.0)
-    return {k: v.to(torch.float32) for k, v in out.items()}  # _doubles_to_floats
+    return {k: ops.cast(v, torch.float32) for k, v in out.items()}  # _doubles_to_floats
 
 
 def _coarse_grain_sfc_data_complex(ds, area, coarsening_factor: int):

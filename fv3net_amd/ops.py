@@ -150,7 +150,7 @@ def mass_weighted_block_average(fields: Sequence[torch.Tensor], delp: torch.Tens
     f0 = fields[0]
     if any(f.shape != f0.shape or f.dtype != f0.dtype for f in fields) or delp.shape != f0.shape:
         raise ValueError("fields and delp must share one shape and dtype")
-    delp = delp.to(f0.dtype).contiguous()
+    delp = cast(delp, f0.dtype).contiguous()
     area_b, a_repeat = _weights_repeat(f0, area)
     ny, nx = int(f0.shape[-2]), int(f0.shape[-1])
     if factor < 1 or ny % factor or nx % factor:
@@ -376,7 +376,7 @@ def ew(op: str, a: torch.Tensor, b: Optional[torch.Tensor] = None, c: Optional[t
     def operand(t):
         if t is None:
             return None, 1
-        t = t.to(dtype=a.dtype).contiguous()
+        t = cast(t, a.dtype).contiguous()
         if tuple(t.shape) == tuple(a.shape):
             return t, 1
         if a.dim() >= 3 and tuple(t.shape) == tuple(a.shape[:-3]) + tuple(a.shape[-2:]):
@@ -388,6 +388,38 @@ def ew(op: str, a: torch.Tensor, b: Optional[torch.Tensor] = None, c: Optional[t
     out = torch.empty_like(a)
     _lib.call_on(dev, "fv3hip_ew", EW_OPS[op], _ptr(a), _ptr(b), _ptr(c), float(scalar), code, a.numel(), inner, b_rep, c_rep,
               _ptr(out), _stream(dev))
+    return out
+
+
+_CAST_IN = {torch.float32: _lib.F32, torch.float64: _lib.F64, torch.int32: _lib.I32, torch.int64: _lib.I64}
+
+
+def cast(x: torch.Tensor, dtype: torch.dtype) -> torch.Tensor:
+    """``x`` in ``dtype`` (float32 / float64): the tensor itself when it already is, else one pass of ``cast_kernel``."""
+    if x.dtype == dtype:
+        return x
+    if x.dtype not in _CAST_IN or dtype not in (torch.float32, torch.float64):
+        return x.to(dtype)  # (bool / half etc.: not on the restart path)
+    dev = _require_device(x)
+    x = x.contiguous()
+    out = torch.empty(x.shape, dtype=dtype, device=dev)
+    _lib.call_on(dev, "fv3hip_cast", _ptr(x), _CAST_IN[x.dtype], _ptr(out), _CAST_IN[dtype], x.numel(), _stream(dev))
+    return out
+
+
+def halo_pick(rows: torch.Tensor, nbr, row, flip) -> torch.Tensor:
+    """(lo, hi) stacked as [2, n_local, ..., n] from the boundary-vector table ``rows`` [6, 4, ..., n] (``cube_edge_rows``):
+    entry ``side * n_local + i`` of the host lists names the neighbour tile, which of its four vectors, and whether it is
+    read reversed (cubedsphere/grid.py holds the connectivity)."""
+    dev = _require_device(rows)
+    rows = rows.contiguous()
+    n_local = len(nbr) // 2
+    n = int(rows.shape[-1])
+    mid = tuple(rows.shape[2:-1])
+    out = torch.empty((2, n_local) + mid + (n,), dtype=rows.dtype, device=dev)
+    arr = lambda v: (ctypes.c_int * len(v))(*[int(x) for x in v])
+    _lib.call_on(dev, "fv3hip_halo_pick", _ptr(rows), rows.element_size(), n_local, _prod(mid), n, arr(nbr), arr(row), arr(flip),
+                 _ptr(out), _stream(dev))
     return out
 
 
@@ -415,8 +447,8 @@ def interp_center_to_outer(x: torch.Tensor, lo: torch.Tensor, hi: torch.Tensor, 
     dev = _require_device(x)
     code = _float_code(x)
     x = x.contiguous()
-    lo = lo.to(dtype=x.dtype).contiguous()
-    hi = hi.to(dtype=x.dtype).contiguous()
+    lo = cast(lo, x.dtype).contiguous()
+    hi = cast(hi, x.dtype).contiguous()
     ny, nx = int(x.shape[-2]), int(x.shape[-1])
     want = tuple(x.shape[:-2]) + ((ny,) if axis == 0 else (nx,))
     if tuple(lo.shape) != want or tuple(hi.shape) != want:

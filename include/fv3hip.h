@@ -179,6 +179,19 @@ int fv3hip_ew(int op, const void *a, const void *b, const void *c, double scalar
               int64_t n, int64_t inner, int64_t b_rep, int64_t c_rep, void *out, void *stream);
 
 /*
+ * Pick and orient the halo vectors of `n_local` tiles from the boundary-vector table of all six tiles (fv3hip_cube_edge_rows,
+ * [6][4][n_mid][n]): out[side][i][o][j] = rows[nbr[side * n_local + i]][row[...]][o][flip[...] ? n - 1 - j : j], side 0 = the
+ * neighbour below the first cell, 1 = beyond the last.  The connectivity of external/vcm/vcm/cubedsphere/xgcm.py:7-34
+ * is the caller's (fv3net_amd/cubedsphere/grid.py); nbr / row / flip are HOST arrays of 2 * n_local ints.
+ */
+int fv3hip_halo_pick(const void *rows, int elem_size, int n_local, int64_t n_mid, int n, const int *nbr, const int *row,
+                     const int *flip, void *out, void *stream);
+
+/* out[i] = (out_dtype) in[i]: F32 / F64 / I32 / I64 -> F32 / F64 (the surface-data arithmetic of
+ * coarsen_restarts.py:1140-1470 runs in one dtype; restart files mix them). */
+int fv3hip_cast(const void *in, int in_dtype, void *out, int out_dtype, int64_t n, void *stream);
+
+/*
  * Cell centres -> cell edges across the faces of the cube: the device half of what
  * xgcm.Grid.interp(delp, axis) does for vcm.cubedsphere.regridz.regrid_to_edge_weighted_pressure and
  * coarsen_restarts.compute_edge_delp (external/vcm/vcm/cubedsphere/regridz.py:123-135,
