@@ -136,6 +136,7 @@ SIGNATURES = {
     "fv3hip_cube_edge_rows": (c_int, [c_void_p, c_int, c_int, c_int64, c_int, c_void_p, c_void_p]),
     "fv3hip_halo_pick": (c_int, [c_void_p, c_int, c_int, c_int64, c_int, POINTER(c_int), POINTER(c_int), POINTER(c_int), c_void_p, c_void_p]),
     "fv3hip_cast": (c_int, [c_void_p, c_int, c_void_p, c_int, c_int64, c_void_p]),
+    "fv3hip_cast_many": (c_int, [c_void_p, POINTER(c_int), c_void_p, c_int, POINTER(c_int64), c_int, c_void_p]),
     "fv3hip_interp_center_to_outer": (c_int, [c_void_p, c_int, c_int64, c_int, c_int, c_int, c_void_p, c_void_p,
                                               c_void_p, c_void_p]),
     "fv3hip_pressure_at_interface": (
@@ -207,14 +208,24 @@ def call(name, *args):
     check(getattr(load(), name)(*args))
 
 
+_torch = None
+
+
 def call_on(where, name, *args):
     """``call`` with the HIP device of ``where`` (a torch device or tensor) current for the duration of the call, and the
     caller's device restored afterwards: the library launches on, and allocates its scratch on, the current device."""
-    import torch
+    global _torch
+    if _torch is None:
+        import torch as _torch_module
 
-    dev = where.device if isinstance(where, torch.Tensor) else where
-    idx = None if dev is None else torch.device(dev).index
-    if idx is None or idx == torch.cuda.current_device():
-        return call(name, *args)
-    with torch.cuda.device(idx):
-        return call(name, *args)
+        _torch = _torch_module
+    dev = getattr(where, "device", where)
+    idx = None if dev is None else getattr(dev, "index", None)
+    lib = _lib or load()
+    if idx is None or idx == _torch.cuda.current_device():
+        code = getattr(lib, name)(*args)
+        if code != OK:
+            check(code)
+        return
+    with _torch.cuda.device(idx):
+        check(getattr(lib, name)(*args))

@@ -264,7 +264,7 @@ __global__ __launch_bounds__(256) void mass_wavg_block_kernel(
 #pragma unroll
             for (int dy = 0; dy < F; ++dy) {
                 Vec<Tf, VEC> dv;
-                if (active) {
+                if (active && delp) {
                     dv = __builtin_nontemporal_load(reinterpret_cast<const Vec<Tf, VEC> *>(delp + o * slice + sp + (int64_t)dy * nx));
                 } else {
 #pragma unroll
@@ -272,7 +272,8 @@ __global__ __launch_bounds__(256) void mass_wavg_block_kernel(
                 }
 #pragma unroll
                 for (int e = 0; e < VEC; ++e) {
-                    const P w0 = (P)dv[e] * areg[dy][e];
+                    // (delp == nullptr: plain 2-D weights shared by the NF fields -- the surface-data means)
+                    const P w0 = delp ? (P)dv[e] * areg[dy][e] : (active ? areg[dy][e] : (P)0);
                     wreg[dy][e] = w0;
                     den[e / EPB] += is_nan(w0) ? (P)0 : w0;
                 }
@@ -352,7 +353,7 @@ int dispatch_mass_wavg(const void *const *fields, int n_fields, const void *delp
     constexpr int VEC = 16 / sizeof(P);
     const Tf *delp = static_cast<const Tf *>(delp_);
     const Ta *area = static_cast<const Ta *>(area_);
-    bool ok = (nx % VEC == 0) && (reinterpret_cast<uintptr_t>(delp) % (sizeof(Tf) * VEC) == 0) &&
+    bool ok = (nx % VEC == 0) && (!delp || reinterpret_cast<uintptr_t>(delp) % (sizeof(Tf) * VEC) == 0) &&
               (reinterpret_cast<uintptr_t>(area) % (sizeof(Ta) * VEC) == 0);
     for (int f = 0; f < n_fields && ok; ++f)
         ok = (reinterpret_cast<uintptr_t>(fields[f]) % (sizeof(Tf) * VEC) == 0) && (reinterpret_cast<uintptr_t>(outs[f]) % 16 == 0);
@@ -869,7 +870,7 @@ extern "C" int fv3hip_mass_weighted_block_average(const void *const *fields, int
     FV3HIP_REQUIRE(a_repeat >= 1 && n_outer % a_repeat == 0, "n_outer (%lld) is not a multiple of a_repeat (%lld)",
                    (long long)n_outer, (long long)a_repeat);
     if (n_outer == 0 || ny == 0 || nx == 0) return FV3HIP_OK;
-    FV3HIP_REQUIRE(fields && outs && delp && area, "null pointer");
+    FV3HIP_REQUIRE(fields && outs && area, "null pointer");  // (delp may be null: the weights are `area` alone)
     for (int f = 0; f < n_fields; ++f) FV3HIP_REQUIRE(fields[f] && outs[f], "null field pointer");
     hipStream_t st = as_stream(stream);
     if (dtype == FV3HIP_F32 && area_dtype == FV3HIP_F32)
@@ -996,6 +997,69 @@ extern "C" int fv3hip_halo_pick(const void *rows, int elem_size, int n_local, in
         hipLaunchKernelGGL((halo_pick_kernel<uint64_t>), dim3((unsigned)blocks), dim3(256), 0, st, static_cast<const uint64_t *>(rows),
                            static_cast<uint64_t *>(out), hp, n_local, n_mid, n);
     return check_launch("halo_pick_kernel");
+}
+
+namespace {
+constexpr int kCastMany = 48;
+struct CastTable {
+    const void *in[kCastMany];
+    void *out[kCastMany];
+    int64_t n[kCastMany];
+    signed char in_dtype[kCastMany];
+};
+
+template <typename Tout>
+__global__ void cast_many_kernel(const CastTable t)
+{
+    const int k = blockIdx.y;
+    const int64_t n = t.n[k];
+    Tout *out = static_cast<Tout *>(t.out[k]);
+    for (int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x) {
+        switch (t.in_dtype[k]) {
+            case FV3HIP_F32: out[i] = (Tout) static_cast<const float *>(t.in[k])[i]; break;
+            case FV3HIP_F64: out[i] = (Tout) static_cast<const double *>(t.in[k])[i]; break;
+            case FV3HIP_I32: out[i] = (Tout) static_cast<const int32_t *>(t.in[k])[i]; break;
+            default: out[i] = (Tout) static_cast<const int64_t *>(t.in[k])[i]; break;
+        }
+    }
+}
+}  // namespace
+
+extern "C" int fv3hip_cast_many(const void *const *in, const int *in_dtype, void *const *out, int out_dtype, const int64_t *n,
+                                int count, void *stream)
+{
+    FV3HIP_REQUIRE(out_dtype == FV3HIP_F32 || out_dtype == FV3HIP_F64, "out_dtype must be F32 or F64, got %d", out_dtype);
+    FV3HIP_REQUIRE(count >= 0, "negative count");
+    if (count == 0) return FV3HIP_OK;
+    FV3HIP_REQUIRE(in && in_dtype && out && n, "null pointer");
+    hipStream_t st = as_stream(stream);
+    for (int k0 = 0; k0 < count; k0 += kCastMany) {
+        const int m = (count - k0 < kCastMany) ? count - k0 : kCastMany;
+        CastTable t;
+        memset(&t, 0, sizeof(t));
+        int64_t nmax = 0;
+        for (int k = 0; k < m; ++k) {
+            FV3HIP_REQUIRE(n[k0 + k] >= 0 && (n[k0 + k] == 0 || (in[k0 + k] && out[k0 + k])), "bad entry %d", k0 + k);
+            FV3HIP_REQUIRE(in_dtype[k0 + k] >= FV3HIP_F32 && in_dtype[k0 + k] <= FV3HIP_I64, "unknown in_dtype %d", in_dtype[k0 + k]);
+            t.in[k] = in[k0 + k];
+            t.out[k] = out[k0 + k];
+            t.n[k] = n[k0 + k];
+            t.in_dtype[k] = (signed char)in_dtype[k0 + k];
+            if (n[k0 + k] > nmax) nmax = n[k0 + k];
+        }
+        if (nmax == 0) continue;
+        int64_t bx = ceil_div(nmax, 256 * 4);
+        if (bx > 4096) bx = 4096;
+        if (bx < 1) bx = 1;
+        dim3 grid((unsigned)bx, (unsigned)m);
+        if (out_dtype == FV3HIP_F32)
+            hipLaunchKernelGGL((cast_many_kernel<float>), grid, dim3(256), 0, st, t);
+        else
+            hipLaunchKernelGGL((cast_many_kernel<double>), grid, dim3(256), 0, st, t);
+        const int rc = check_launch("cast_many_kernel");
+        if (rc) return rc;
+    }
+    return FV3HIP_OK;
 }
 
 namespace {

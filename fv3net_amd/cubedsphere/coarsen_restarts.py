@@ -318,11 +318,24 @@ def _common(coarsening_factor, grid_spec, restarts):
 _SIDE_STREAMS = {}
 
 
-def _common_beside(coarsening_factor, grid_spec, restarts):
-    """``_common`` on a second HIP stream: the surface categories are some 350 launches on 2-D fields (a microsecond or
-    two of device time each) that depend on nothing the 3-D categories produce -- issued after them, on a stream of their
-    own, they run in the shadow of the large kernels instead of behind them.  The calling stream waits for the side
-    stream before the results are handed out."""
+def _entry_event():
+    """An event on the calling stream at the moment a pipeline is entered: what the surface categories' side stream has to
+    wait for (the caller's inputs) -- not the 3-D work the pipeline enqueues afterwards."""
+    import torch
+
+    from ._device import compute_device
+
+    dev = compute_device()
+    ev = torch.cuda.Event()
+    ev.record(torch.cuda.current_stream(dev))
+    return ev
+
+
+def _common_beside(coarsening_factor, grid_spec, restarts, entry_event):
+    """``_common`` on a second HIP stream: the surface categories are some 150 launches on 2-D fields (a few microseconds of
+    device time each) that depend on nothing the 3-D categories produce -- issued after them, on a stream of their own that
+    only waits for the pipeline's inputs, they run in the shadow of the large kernels instead of behind them.  The calling
+    stream waits for the side stream before the results are handed out."""
     import torch
 
     from ._device import compute_device
@@ -332,7 +345,7 @@ def _common_beside(coarsening_factor, grid_spec, restarts):
     side = _SIDE_STREAMS.get(dev.index)
     if side is None:
         side = _SIDE_STREAMS[dev.index] = torch.cuda.Stream(device=dev)
-    side.wait_stream(main)  # inputs produced on the calling stream
+    side.wait_event(entry_event)
     with torch.cuda.stream(side):
         out = _common(coarsening_factor, grid_spec, restarts)
     main.wait_stream(side)
@@ -352,7 +365,7 @@ def coarsen_restarts_on_sigma(coarsening_factor: int, grid_spec, restarts: Mappi
                               mass_weighted: bool = True):
     """Coarsen a complete set of restart files on model levels, 'complex' surface method (coarsen_restarts.py:21-95)."""
     core = to_compat(restarts["fv_core.res"])
-    coarsened = {}
+    coarsened, entered = {}, _entry_event()
     coarsened["fv_core.res"] = _coarse_grain_fv_core(
         core, core["delp"], _grid(grid_spec, "area", FV_CORE_X_CENTER, FV_CORE_Y_CENTER),
         _grid(grid_spec, "dx", FV_CORE_X_CENTER, FV_CORE_Y_OUTER), _grid(grid_spec, "dy", FV_CORE_X_OUTER, FV_CORE_Y_CENTER),
@@ -360,7 +373,7 @@ def coarsen_restarts_on_sigma(coarsening_factor: int, grid_spec, restarts: Mappi
     coarsened["fv_tracer.res"] = _coarse_grain_fv_tracer(
         restarts["fv_tracer.res"], core["delp"].rename({FV_CORE_Y_CENTER: FV_TRACER_Y_CENTER}),
         _grid(grid_spec, "area", FV_TRACER_X_CENTER, FV_TRACER_Y_CENTER), coarsening_factor, mass_weighted)
-    coarsened.update(_common_beside(coarsening_factor, grid_spec, restarts))
+    coarsened.update(_common_beside(coarsening_factor, grid_spec, restarts, entered))
     return _finish(coarsened, restarts)
 
 
@@ -369,7 +382,7 @@ def coarsen_restarts_on_pressure(coarsening_factor: int, grid_spec, toa_pressure
     """Coarsen a complete set of restart files on surfaces of constant pressure, then impose hydrostatic
     balance (coarsen_restarts.py:98-237)."""
     core = to_compat(restarts["fv_core.res"])
-    coarsened = {}
+    coarsened, entered = {}, _entry_event()
     area = _grid(grid_spec, "area", FV_CORE_X_CENTER, FV_CORE_Y_CENTER)
     core_means, coarsened["fv_tracer.res"] = _area_weighted_pressure_means(
         core, restarts["fv_tracer.res"], core["delp"], area, toa_pressure, coarsening_factor, coarsen_agrid_winds, extrapolate)
@@ -378,7 +391,7 @@ def coarsen_restarts_on_pressure(coarsening_factor: int, grid_spec, toa_pressure
         _grid(grid_spec, "dy", FV_CORE_X_OUTER, FV_CORE_Y_CENTER), toa_pressure, coarsening_factor, coarsen_agrid_winds,
         extrapolate=extrapolate, area_means=core_means)
     coarsened["fv_core.res"] = _impose_hydrostatic_balance(coarsened["fv_core.res"], coarsened["fv_tracer.res"], toa_pressure)
-    coarsened.update(_common_beside(coarsening_factor, grid_spec, restarts))
+    coarsened.update(_common_beside(coarsening_factor, grid_spec, restarts, entered))
     return _finish(coarsened, restarts)
 
 
@@ -386,7 +399,7 @@ def coarsen_restarts_via_blended_method(coarsening_factor: int, grid_spec, toa_p
                                         coarsen_agrid_winds: bool = False, mass_weighted: bool = True):
     """Blended pressure-level / model-level coarse-graining of the 3-D fields (coarsen_restarts.py:240-332)."""
     core = to_compat(restarts["fv_core.res"])
-    coarsened = {}
+    coarsened, entered = {}, _entry_event()
     area = _grid(grid_spec, "area", FV_CORE_X_CENTER, FV_CORE_Y_CENTER)
     core_means, tracer_means = _area_weighted_pressure_means(
         core, restarts["fv_tracer.res"], core["delp"], area, toa_pressure, coarsening_factor, coarsen_agrid_winds, False)
@@ -399,5 +412,5 @@ def coarsen_restarts_via_blended_method(coarsening_factor: int, grid_spec, toa_p
         _grid(grid_spec, "area", FV_TRACER_X_CENTER, FV_TRACER_Y_CENTER), toa_pressure, coarsening_factor, mass_weighted,
         pressure_level=tracer_means)
     coarsened["fv_core.res"] = _impose_hydrostatic_balance(coarsened["fv_core.res"], coarsened["fv_tracer.res"], toa_pressure)
-    coarsened.update(_common_beside(coarsening_factor, grid_spec, restarts))
+    coarsened.update(_common_beside(coarsening_factor, grid_spec, restarts, entered))
     return _finish(coarsened, restarts)

@@ -42,7 +42,8 @@ def coarse_grain_sfc_data_tensors(fields: Mapping[str, torch.Tensor], area: torc
     """The method on device tensors whose last two dims are (y, x): 2-D fields share their leading
     dims with ``area``; 3-D (soil level) fields have one extra axis before (y, x)."""
     dt = torch.float64 if any(t.dtype == torch.float64 for t in fields.values()) or area.dtype == torch.float64 else torch.float32
-    fields = {k: ops.cast(v, dt) for k, v in fields.items()}
+    names = list(fields)
+    fields = dict(zip(names, ops.cast_many([fields[n] for n in names], dt)))  # (one launch for all that need it)
     area = ops.cast(area, dt)
     slmsk_c = _mode(fields["slmsk"], f)
     dom_sfc = ops.ew("isclose", fields["slmsk"], ops.block_upsample(slmsk_c, f))
@@ -54,28 +55,41 @@ def coarse_grain_sfc_data_tensors(fields: Mapping[str, torch.Tensor], area: torc
     sfc_and_v = ops.ew("and", dom_sfc, dom_v)
     sfc_and_s = ops.ew("and", dom_sfc, dom_s)
     area_sfc = ops.ew("where_nan", area, dom_sfc)
+    area_sv = area_ss = None
 
-    def masked_mean(x, mask, weights):
-        return ops.weighted_block_average(ops.ew("where_nan", x, mask), weights, f)
+    # Masked means: the reference averages `x.where(mask)` with the weights `w.where(mask)`.  A NaN weight makes the product
+    # NaN whatever x holds, and NaN products are skipped, so masking the WEIGHTS is enough -- no masked copy of every field.
+    # Fields that share their weights (and shape) go four to a launch (`weighted_block_average_multi`).
+    def group(field_names, weights):
+        by_shape = {}
+        for n in field_names:
+            by_shape.setdefault(tuple(fields[n].shape), []).append(n)
+        for ns in by_shape.values():
+            for n, res in zip(ns, ops.weighted_block_average_multi([fields[n] for n in ns], weights, f)):
+                out[n] = res
 
+    present = lambda seq: [n for n in seq if n in fields]
+    group(present(_AREA_WEIGHTED), area)
+    group(present(_OVER_DOMINANT_SFC), area_sfc)
+    if present(_OVER_SFC_AND_STYPE):
+        area_ss = ops.ew("where_nan", area, sfc_and_s)
+        group(present(_OVER_SFC_AND_STYPE), area_ss)
+    if present(_VFRAC_OVER_SFC_AND_VTYPE):
+        area_sv = ops.ew("where_nan", area, sfc_and_v)
+        av = ops.ew("where_nan", ops.ew("mul", area, fields["vfrac"]), sfc_and_v)
+        av_sum = ops.block_reduce(av, (f, f), op="sum")
+        for name in present(_VFRAC_OVER_SFC_AND_VTYPE):
+            x = fields[name]
+            a_mean = ops.weighted_block_average(x, area_sv, f)
+            av_mean = ops.weighted_block_average(x, av, f)
+            s_ = av_sum
+            if s_.shape != av_mean.shape:  # (a field with a level axis: the 2-D sum applies to every level)
+                s_ = torch.broadcast_to(s_.unsqueeze(-3), av_mean.shape).contiguous()
+            out[name] = ops.ew("select", av_mean, a_mean, ops.ew("gt_s", s_, scalar=0.0))
     for name, x in fields.items():
         if name in out:
             continue
-        if name in _AREA_WEIGHTED:
-            out[name] = ops.weighted_block_average(x, area, f)
-        elif name in _OVER_DOMINANT_SFC:
-            out[name] = masked_mean(x, dom_sfc, area_sfc)
-        elif name in _VFRAC_OVER_SFC_AND_VTYPE:
-            av = ops.ew("where_nan", ops.ew("mul", area, fields["vfrac"]), sfc_and_v)
-            a_mean = masked_mean(x, sfc_and_v, ops.ew("where_nan", area, sfc_and_v))
-            av_mean = masked_mean(x, sfc_and_v, av)
-            av_sum = ops.block_reduce(av, (f, f), op="sum")
-            if av_sum.shape != av_mean.shape:  # (a field with a level axis: the 2-D sum applies to every level)
-                av_sum = torch.broadcast_to(av_sum.unsqueeze(-3), av_mean.shape).contiguous()
-            out[name] = ops.ew("select", av_mean, a_mean, ops.ew("gt_s", av_sum, scalar=0.0))
-        elif name in _OVER_SFC_AND_STYPE:
-            out[name] = masked_mean(x, sfc_and_s, ops.ew("where_nan", area, sfc_and_s))
-        elif name == "srflag":
+        if name == "srflag":
             out[name] = _mode(x, f)
         elif name == "slope":
             out[name] = _mode(ops.ew("where_nan", x, dom_sfc), f)
@@ -84,11 +98,12 @@ def coarse_grain_sfc_data_tensors(fields: Mapping[str, torch.Tensor], area: torc
         elif name == "hice":
             out[name] = ops.ew("fillna_s", ops.weighted_block_average(x, ops.ew("mul", area, fields["fice"]), f), scalar=0.0)
         elif name == "tisfc":
-            sea_ice = masked_mean(x, dom_sfc, ops.ew("where_nan", ops.ew("mul", area, fields["fice"]), dom_sfc))
-            other = masked_mean(x, dom_sfc, area_sfc)
+            sea_ice = ops.weighted_block_average(x, ops.ew("where_nan", ops.ew("mul", area, fields["fice"]), dom_sfc), f)
+            other = ops.weighted_block_average(x, area_sfc, f)
             out[name] = ops.ew("select", sea_ice, other, ops.ew("isclose_s", slmsk_c, scalar=2.0))
         else:
             raise KeyError(f"no coarsening method for sfc_data variable {name!r}")
+    out = {n: out[n] for n in names}  # (the inputs' order)
     # surface_chgres corrections (coarsen_restarts.py:1403-1470), in the reference's order
     land_ice = ops.ew("isclose_s", out["vtype"], scalar=VTYPE_LAND_ICE)
     if "tsea" in out:
@@ -100,7 +115,8 @@ def coarse_grain_sfc_data_tensors(fields: Mapping[str, torch.Tensor], area: torc
         out["canopy"] = ops.ew("select_s", out["canopy"], ops.ew("lt_s", out["shdmin"], scalar=SHDMIN_THRESHOLD), scalar=0.0)
     if "shdmin" in out:
         out["shdmin"] = ops.ew("select_s", out["shdmin"], land_ice, scalar=0.0)
-    return {k: ops.cast(v, torch.float32) for k, v in out.items()}  # _doubles_to_floats
+    keys = list(out)
+    return dict(zip(keys, ops.cast_many([out[k] for k in keys], torch.float32)))  # _doubles_to_floats, one launch
 
 
 def _coarse_grain_sfc_data_complex(ds, area, coarsening_factor: int):

@@ -137,6 +137,35 @@ def weighted_block_average(obj: torch.Tensor, weights: torch.Tensor, factor: int
     return out
 
 
+def weighted_block_average_multi(fields: Sequence[torch.Tensor], weights: torch.Tensor, factor: int) -> list:
+    """``weighted_block_average(field, weights, factor)`` for several fields of one shape and dtype that share their weights
+    (2-D, or the fields' shape): four fields per launch read the weights once.  Same results as the single-field call when
+    fields and weights have one dtype (the surface-data arithmetic does)."""
+    fields = [f.contiguous() for f in fields]
+    if not fields:
+        return []
+    f0 = fields[0]
+    if len(fields) == 1 or any(f.shape != f0.shape or f.dtype != f0.dtype for f in fields) or weights.dtype != f0.dtype:
+        return [weighted_block_average(f, weights, factor) for f in fields]
+    dev = _require_device(weights, *fields)
+    factor = int(factor)
+    w, w_repeat = _weights_repeat(f0, weights)
+    ny, nx = int(f0.shape[-2]), int(f0.shape[-1])
+    if factor < 1 or ny % factor or nx % factor:
+        raise ValueError(f"horizontal extents ({ny}, {nx}) are not multiples of the coarsening factor {factor}")
+    outs = [torch.empty(tuple(f0.shape[:-2]) + (ny // factor, nx // factor), dtype=f0.dtype, device=dev) for _ in fields]
+    n = len(fields)
+    try:
+        _lib.call_on(dev, "fv3hip_mass_weighted_block_average", (ctypes.c_void_p * n)(*[f.data_ptr() for f in fields]), n,
+                     _float_code(f0), None, _ptr(w), _float_code(w), _prod(f0.shape[:-2]), ny, nx, w_repeat, factor,
+                     (ctypes.c_void_p * n)(*[o.data_ptr() for o in outs]), _stream(dev))
+    except _lib.Fv3HipError as err:
+        if err.code != _lib.EUNSUPPORTED:
+            raise
+        return [weighted_block_average(f, weights, factor) for f in fields]
+    return outs
+
+
 def mass_weighted_block_average(fields: Sequence[torch.Tensor], delp: torch.Tensor, area: torch.Tensor, factor: int) -> list:
     """``weighted_block_average(field, delp * area, factor)`` for several fields that share ``delp`` [.., ny, nx] (the
     fields' shape and dtype) and ``area`` (2-D weights shared by trailing outer dims, as in ``weighted_block_average``): the
@@ -405,6 +434,25 @@ def cast(x: torch.Tensor, dtype: torch.dtype) -> torch.Tensor:
     out = torch.empty(x.shape, dtype=dtype, device=dev)
     _lib.call_on(dev, "fv3hip_cast", _ptr(x), _CAST_IN[x.dtype], _ptr(out), _CAST_IN[dtype], x.numel(), _stream(dev))
     return out
+
+
+def cast_many(tensors: Sequence[torch.Tensor], dtype: torch.dtype) -> list:
+    """``cast`` of several tensors with one launch for all that need converting (``fv3hip_cast_many``)."""
+    tensors = list(tensors)
+    todo = [i for i, t in enumerate(tensors) if t.dtype != dtype and t.dtype in _CAST_IN]
+    if dtype not in (torch.float32, torch.float64) or len(todo) < 2:
+        return [cast(t, dtype) for t in tensors]
+    dev = _require_device(*[tensors[i] for i in todo])
+    src = [tensors[i].contiguous() for i in todo]
+    dst = [torch.empty(t.shape, dtype=dtype, device=dev) for t in src]
+    n = len(src)
+    _lib.call_on(dev, "fv3hip_cast_many", (ctypes.c_void_p * n)(*[t.data_ptr() for t in src]),
+                 (ctypes.c_int * n)(*[_CAST_IN[t.dtype] for t in src]), (ctypes.c_void_p * n)(*[t.data_ptr() for t in dst]),
+                 _CAST_IN[dtype], (ctypes.c_int64 * n)(*[t.numel() for t in src]), n, _stream(dev))
+    out = list(tensors)
+    for i, d in zip(todo, dst):
+        out[i] = d
+    return [t if t.dtype == dtype else cast(t, dtype) for t in out]  # (anything left: exotic dtypes, one by one)
 
 
 def halo_pick(rows: torch.Tensor, nbr, row, flip) -> torch.Tensor:

@@ -111,7 +111,9 @@ int fv3hip_weighted_block_average(const void *obj, int obj_dtype, const void *we
  *     out_f[o][Y][X] = nansum_block(field_f * (delp * area)) / nansum_block(delp * area)
  * with the product delp * area formed in registers (never written) and read once per four fields.  `fields` / `outs` are
  * HOST arrays of device pointers; fields and delp [n_outer][ny][nx] in `dtype`, area [n_outer / a_repeat][ny][nx] in
- * `area_dtype`, outputs [n_outer][ny / f][nx / f] in the promoted type (F64 unless both are F32).  factor in
+ * `area_dtype`, outputs [n_outer][ny / f][nx / f] in the promoted type (F64 unless both are F32).  `delp` may be NULL: the
+ * weights are then `area` alone, shared by the fields (the area-weighted means of the surface data,
+ * coarsen_restarts.py:1163-1230, four fields per launch).  factor in
  * {2, 4, 8, 16} with 16-byte aligned rows; anything else returns FV3HIP_EUNSUPPORTED (callers then form the product with
  * fv3hip_ew and use fv3hip_weighted_block_average).
  */
@@ -190,6 +192,10 @@ int fv3hip_halo_pick(const void *rows, int elem_size, int n_local, int64_t n_mid
 /* out[i] = (out_dtype) in[i]: F32 / F64 / I32 / I64 -> F32 / F64 (the surface-data arithmetic of
  * coarsen_restarts.py:1140-1470 runs in one dtype; restart files mix them). */
 int fv3hip_cast(const void *in, int in_dtype, void *out, int out_dtype, int64_t n, void *stream);
+/* The same for `count` arrays in one launch (the 35 surface fields of a restart set): HOST arrays of device pointers,
+ * input dtypes and lengths. */
+int fv3hip_cast_many(const void *const *in, const int *in_dtype, void *const *out, int out_dtype, const int64_t *n, int count,
+                     void *stream);
 
 /*
  * Cell centres -> cell edges across the faces of the cube: the device half of what
