@@ -406,7 +406,7 @@ def secondary_benchmarks(dev, steps):
     del qs
     # (the secondary workloads never cost the headline line: a failure is recorded in place of the numbers)
     for fn, fn_args in ((dense_local_benchmark, (dev, steps)), (streaming_benchmark, (dev,)), (restart_pipeline_benchmark, (dev,)),
-                        (io_pipeline_benchmark, (dev,))):
+                        (io_pipeline_benchmark, (dev,)), (split_bf16_benchmark, (dev,))):
         try:
             out.extend(fn(*fn_args))
         except Exception as err:  # noqa: BLE001
@@ -512,6 +512,36 @@ def io_pipeline_benchmark(dev, n=384, f=8):
         }]
     finally:
         shutil.rmtree(root, ignore_errors=True)
+
+
+def split_bf16_benchmark(dev):
+    """EXPLORATORY (the headline stays fp32): one 256 x 256 layer contracted on the bf16 matrix cores with the fp32 operands
+    split into 2 or 3 bf16 pieces (benchmarks/bf16split) -- fp32-equivalent TFLOP/s and the error against the float64 product
+    next to the float32 evaluation's."""
+    import importlib.util
+
+    here = os.path.join(ROOT, "benchmarks", "bf16split")
+    if not os.path.exists(os.path.join(here, "libbf16split.so")):
+        return [{"kernel": "split-bf16 layer (exploratory)", "error": "benchmarks/bf16split/libbf16split.so is not built"}]
+    spec = importlib.util.spec_from_file_location("bf16split_run", os.path.join(here, "run.py"))
+    mod = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(mod)
+    import contextlib
+    import io
+
+    with contextlib.redirect_stdout(io.StringIO()):
+        res = mod.main()
+    out = []
+    for v in res["variants"]:
+        tf = v["fp32_equivalent_tflops"]
+        out.append({"kernel": f"gemm_split_kernel, {v['split']} (EXPLORATORY, standalone layer, not the product path)",
+                    "workload": res["workload"] + "; 8 passes per launch, activations re-read from HBM and split in registers every pass",
+                    "ms": v["ms_for_8_passes"], "max_rel_err_vs_f64": v["max_rel_err_vs_f64"],
+                    "fp32_numpy_max_rel_err": res["fp32_numpy_max_rel_err"],
+                    "roofline": {"bound": "mfma", "achieved": tf, "peak": PEAK_FP32_MFMA_TFLOPS, "unit": "TFLOP/s (fp32-equivalent)",
+                                 "frac": tf / PEAK_FP32_MFMA_TFLOPS, "traffic": None,
+                                 "note": "fraction of the FP32 matrix peak: above 1 means faster than any fp32-MFMA kernel can be"}})
+    return out
 
 
 def streaming_benchmark(dev, n_snapshots=24):
