@@ -167,6 +167,10 @@ SIGNATURES = {
     ),
     "fv3hip_mlp_flops_per_sample": (c_int64, [c_void_p]),
     "fv3hip_mlp_last_variant": (c_char_p, [c_void_p]),
+    "fv3hip_mlp3_create": (c_int, [POINTER(MlpDesc), POINTER(c_void_p)]),
+    "fv3hip_mlp3_destroy": (c_int, [c_void_p]),
+    "fv3hip_mlp3_flops_per_sample": (c_int64, [c_void_p]),
+    "fv3hip_mlp3_predict": (c_int, [c_void_p, POINTER(c_void_p), POINTER(c_int64), c_int64, POINTER(c_void_p), POINTER(c_int64), c_void_p]),
     "fv3hip_timer_create": (c_int, [POINTER(c_void_p)]),
     "fv3hip_timer_start": (c_int, [c_void_p, c_void_p]),
     "fv3hip_timer_stop": (c_int, [c_void_p, c_void_p]),

@@ -214,7 +214,7 @@ class MlpModel:
         self.flops_per_sample = int(_lib.load().fv3hip_mlp_flops_per_sample(self._handle))
 
     @staticmethod
-    def _create(spec: MlpSpec):
+    def _create(spec: MlpSpec, entry_point: str = "fv3hip_mlp_create"):
         sources = spec.sources
         keep = []  # keep numpy buffers alive during the call
 
@@ -295,7 +295,7 @@ class MlpModel:
             desc.res_output = _iptr(arr_i([out_names.index(r.output) for r in spec.residuals]))
         assert F == sum(o.nfeat for o in spec.outputs)
         handle = ctypes.c_void_p()
-        _lib.call("fv3hip_mlp_create", ctypes.byref(desc), ctypes.byref(handle))
+        _lib.call(entry_point, ctypes.byref(desc), ctypes.byref(handle))
         return handle
 
     def predict(
@@ -387,5 +387,52 @@ class MlpModel:
         if h:
             try:
                 _lib.load().fv3hip_mlp_destroy(h)
+            except Exception:
+                pass
+
+
+class MlpModelSplitBf16:
+    """EXPERIMENTAL: the same network through ``fv3hip_mlp3_*`` -- the contraction on the bf16 matrix cores with every fp32
+    operand split into three bf16 pieces (csrc/mlp_bf16x3.hip).  float32 ``[feature, sample]`` sources
+    with unit sample stride only; ``MlpModel`` (fp32 MFMA) is the product path."""
+
+    def __init__(self, spec: MlpSpec, device="cuda"):
+        spec.validate()
+        self.spec = spec
+        self.device = torch.device(device)
+        if self.device.type != "cuda":
+            raise RuntimeError("MlpModelSplitBf16 needs a 'cuda' (ROCm) device; there is no CPU fallback")
+        with torch.cuda.device(self.device):
+            _require_device(torch.empty(1, device=self.device))
+            self._handle = MlpModel._create(spec, "fv3hip_mlp3_create")
+        self.flops_per_sample = int(_lib.load().fv3hip_mlp3_flops_per_sample(self._handle))
+
+    def predict(self, sources: Mapping[str, torch.Tensor]) -> Dict[str, torch.Tensor]:
+        spec = self.spec
+        tensors = []
+        for name in spec.sources:
+            t = sources[name]
+            t = t.unsqueeze(0) if t.dim() == 1 else t
+            if t.dtype != torch.float32 or t.stride(1) != 1:
+                raise TypeError("the split-bf16 kernel takes float32 [feature, sample] sources with unit sample stride")
+            tensors.append(t)
+        dev = _require_device(*tensors)
+        n = int(tensors[0].shape[1])
+        nfeat = {o.name: o.nfeat for o in spec.outputs}
+        for r in spec.residuals:
+            nfeat[r.name] = nfeat[r.output]
+        outs = {name: torch.empty((nfeat[name], n), dtype=torch.float32, device=dev) for name in spec.output_names}
+        ol = [outs[name] for name in spec.output_names]
+        ns, no = len(tensors), len(ol)
+        _lib.call_on(dev, "fv3hip_mlp3_predict", self._handle, (ctypes.c_void_p * ns)(*[t.data_ptr() for t in tensors]),
+                     (ctypes.c_int64 * ns)(*[t.stride(0) for t in tensors]), n, (ctypes.c_void_p * no)(*[t.data_ptr() for t in ol]),
+                     (ctypes.c_int64 * no)(*[t.stride(0) for t in ol]), _stream(dev))
+        return outs
+
+    def __del__(self):
+        h = getattr(self, "_handle", None)
+        if h:
+            try:
+                _lib.load().fv3hip_mlp3_destroy(h)
             except Exception:
                 pass

@@ -375,6 +375,20 @@ int64_t fv3hip_mlp_flops_per_sample(fv3hip_mlp_t model);
  * The string lives in the model handle. */
 const char *fv3hip_mlp_last_variant(fv3hip_mlp_t model);
 
+/*
+ * EXPERIMENTAL: the same predict graph with the contraction on the bf16 matrix cores, every fp32 operand split into three
+ * bf16 pieces and six cross products accumulated in fp32 (fv3net_amd/csrc/mlp_bf16x3.hip).  Same
+ * descriptor as fv3hip_mlp_create; restrictions: hidden width 256, ReLU, no hidden output, no limits / masks, log epsilons
+ * >= FLT_MIN, 3 / 5 / 13 output tiles of 32.  Sources and outputs are float32 [feature][sample] with unit sample stride
+ * (element (f, n) at f * feat_stride + n).  Not a replacement of fv3hip_mlp_predict: the fp32 kernel is the product path.
+ */
+typedef struct fv3hip_mlp3 *fv3hip_mlp3_t;
+int fv3hip_mlp3_create(const fv3hip_mlp_desc_t *desc, fv3hip_mlp3_t *out);
+int fv3hip_mlp3_destroy(fv3hip_mlp3_t model);
+int64_t fv3hip_mlp3_flops_per_sample(fv3hip_mlp3_t model);
+int fv3hip_mlp3_predict(fv3hip_mlp3_t model, const void *const *sources, const int64_t *src_feat_stride, int64_t n_samples,
+                        void *const *outputs, const int64_t *out_feat_stride, void *stream);
+
 /* ------------------------------------------------------------------------------------------
  * Timing helper: HIP events on the caller's stream (bench.py measures kernels with these
  * because torch.cuda.Event only sees torch's current stream).

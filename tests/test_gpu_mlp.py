@@ -265,6 +265,43 @@ def test_timed_kernel_float64_sources_take_general_epilogue(device):
         assert np.max(np.abs(out[name].cpu().numpy().T - t)) <= 1e-5 * np.max(np.abs(t)), name
 
 
+@pytest.mark.parametrize("n", [4096, 147456 + 32])
+@pytest.mark.parametrize("residuals", [True, False])
+def test_split_bf16_kernel_against_oracle(device, n, residuals):
+    """EXPERIMENTAL path (csrc/mlp_bf16x3.hip): the Zhao-Carr network with every fp32 operand split into three bf16 pieces
+    and the contraction on the bf16 matrix cores, against the same float64 oracle and the same bar as the fp32 kernel --
+    and no less accurate than the float32 CPU evaluation by more than a small factor."""
+    import bench
+    from fv3net_amd.mlp import MlpModelSplitBf16
+
+    spec = bench.zc_spec(0, residuals=residuals)
+    src = bench.zc_inputs_numpy(np.random.default_rng(13), n)
+    model = MlpModelSplitBf16(spec, device=device)
+    out = model.predict({k: torch.from_numpy(np.ascontiguousarray(v.T)).to(device) for k, v in src.items()})
+    truth = mlp_np.forward(spec, src, dtype=np.float64)
+    cpu32 = mlp_np.forward(spec, src, dtype=np.float32)
+    assert set(out) == set(truth)
+    for name, t in truth.items():
+        got = out[name].cpu().numpy().T
+        scale = np.max(np.abs(t))
+        err = np.max(np.abs(got - t))
+        assert err <= 1e-5 * scale, (name, err, scale)
+        assert err <= 4 * np.max(np.abs(cpu32[name] - t)) + 2e-7 * scale, (name, err, np.max(np.abs(cpu32[name] - t)))
+
+
+def test_split_bf16_kernel_refuses_what_it_does_not_implement(device):
+    from fv3net_amd._lib import Fv3HipError
+    from fv3net_amd.mlp import MlpModelSplitBf16
+
+    rng = np.random.default_rng(1)
+    spec = _random_spec(rng, {"a": ("a", 79, 0)}, 64, 2, {"y": 79})
+    with pytest.raises(Fv3HipError, match="width 256"):
+        MlpModelSplitBf16(spec, device=device)
+    spec = _random_spec(rng, {"a": ("a", 79, 0)}, 256, 2, {"y": 79}, limits={"y": (0.0, None)})
+    with pytest.raises(Fv3HipError, match="limits"):
+        MlpModelSplitBf16(spec, device=device)
+
+
 @pytest.mark.parametrize("in_dtype,n_buffers", [(np.float32, 3), (np.float64, 2)])
 def test_snapshot_stream_matches_direct_predict(device, in_dtype, n_buffers):
     """Streaming snapshots through pinned host buffers on three HIP streams gives, for every snapshot and
