@@ -541,6 +541,47 @@ def split_bf16_benchmark(dev):
                     "roofline": {"bound": "mfma", "achieved": tf, "peak": PEAK_FP32_MFMA_TFLOPS, "unit": "TFLOP/s (fp32-equivalent)",
                                  "frac": tf / PEAK_FP32_MFMA_TFLOPS, "traffic": None,
                                  "note": "fraction of the FP32 matrix peak: above 1 means faster than any fp32-MFMA kernel can be"}})
+    out.extend(split_bf16_network_benchmark(dev))
+    return out
+
+
+PEAK_BF16_MFMA_TFLOPS = 2516.6  # dense v_mfma_f32_32x32x16_bf16 peak (MI355X_MICROARCH.md)
+
+
+def split_bf16_network_benchmark(dev, steps=10):
+    """EXPLORATORY: the whole headline network (same graph, same inputs, same launch shape) through the fused split-bf16 kernel
+    (``fv3hip_mlp3_*``, csrc/mlp_bf16x3.hip) -- time, fp32-equivalent TFLOP/s and the error against the float64 oracle next to
+    the fp32 kernel's on the same 4096 columns."""
+    from fv3net_amd.mlp import MlpModel, MlpModelSplitBf16
+
+    out = []
+    ncol = 6 * 384 * 384
+    src = zc_inputs_device(dev, ncol, seed=1000)
+    for residuals in (False, True):
+        spec = zc_spec(0, residuals=residuals)
+        try:
+            row = {}
+            for label, cls in (("fp32", MlpModel), ("split", MlpModelSplitBf16)):
+                model = cls(spec, device=dev)
+                sliced = parity_slice_predict(model, src)
+                ms = time_kernel(lambda: model.predict(src), steps, dev, warm=6)
+                row[label] = (ms, model.flops_per_sample, sliced)
+                del model
+            ms, flops, sliced = row["split"]
+            tf = flops * ncol / (ms * 1e-3) / 1e12
+            out.append({
+                "kernel": "mlp3_kernel<13> (EXPLORATORY split-bf16 arithmetic, 6 bf16 MFMAs per product; not the product path)",
+                "workload": "the headline network, 884736 columns, " + ("791 output rows (with the Difference residuals)" if residuals
+                                                                         else "396 direct outputs only"),
+                "ms": ms, "columns_per_s": ncol / ms * 1e3, "fp32_kernel_ms_same_run": row["fp32"][0],
+                "max_rel_err_vs_f64": parity_max_rel(spec, sliced), "fp32_kernel_max_rel_err_vs_f64": parity_max_rel(spec, row["fp32"][2]),
+                "roofline": {"bound": "mfma", "achieved": tf, "peak": PEAK_FP32_MFMA_TFLOPS, "unit": "TFLOP/s (fp32-equivalent)",
+                             "frac": tf / PEAK_FP32_MFMA_TFLOPS, "traffic": None,
+                             "bf16_mfma_frac": 6 * tf / PEAK_BF16_MFMA_TFLOPS,
+                             "note": "frac = fraction of the FP32 matrix peak (above 1: faster than any fp32-MFMA kernel can be); "
+                                     "bf16_mfma_frac = the 6x bf16 work actually issued over the dense bf16 peak"}})
+        except Exception as err:  # noqa: BLE001
+            out.append({"kernel": "mlp3_kernel (exploratory)", "error": f"{type(err).__name__}: {err}"})
     return out
 
 

@@ -33,251 +33,393 @@ namespace {
 typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
 typedef float f32x16 __attribute__((ext_vector_type(16)));
 typedef float f32x4 __attribute__((ext_vector_type(4)));
+typedef float f32x2 __attribute__((ext_vector_type(2)));
+typedef __attribute__((address_space(3))) char lds_char;
 
 constexpr int kHT = 8;          // hidden feature tiles (width 256)
 constexpr int kMaxSrc = 16;
 constexpr int kMaxOut = 32;
+constexpr int kMaxKs1 = 64;     // layer-1 k-steps (<= 1024 input features after padding every input to a multiple of 16)
 
 __host__ __device__ constexpr int rho3(int r) { return (r & 3) + 8 * (r >> 2); }
 
+// one layer-1 k-step: its 16 contraction indices are 16 consecutive features of ONE input (inputs are padded to whole
+// k-steps), so its rows are `base + (8 half + j) fs4`, fetched by bounds-checked buffer loads (a padding row reads 0)
+struct XStep {
+    uint64_t base;   // address of (first feature of the k-step, sample 0)
+    uint32_t nrec;   // bytes from there to the end of the input's last feature row
+    uint32_t fs4;    // bytes per feature row
+};
+
 struct Mlp3Launch {
     const f32x4 *w;        // packed stream: per k-step chunk [piece 3][tile][lane 64] float4 (= 8 bf16)
-    const float *bias;     // [layer][tile][reg 16][half 2]
-    const float *center;   // [n_ks1 * 16] layer-1 centre per k-slot ([ks][half][j])
-    const float *eps;      // [n_ks1 * 16] log epsilon per k-slot (log k-steps)
-    const int *xsrc;       // [n_ks1 * 16] source index per k-slot, -1 = padding
-    const int *xfeat;      // [n_ks1 * 16] feature inside the source
+    uint32_t w_bytes;
+    const float *bias;     // [(n_hidden 8 + n_ot) tiles][half 2][reg 16]
+    const float *center;   // [n_ks1][half][8] layer-1 centre per k-slot
+    const float *eps;      // [n_ks1][half][8] log epsilon per k-slot (log k-steps)
     const int *ofeat;      // [n_ot * 32] (output slot << 20 | feature), -1 = padding
     const int *ores;       // [n_ot * 32] (residual slot << 8 | residual source), -1 = none
     int n_ks1, n_log_ks, n_hidden, n_ot, n_residual;
     int64_t n_samples, n_tiles;
+    XStep xk[kMaxKs1];
     const float *src[kMaxSrc];
     int64_t src_fs[kMaxSrc];
     float *out[kMaxOut];
     int64_t out_fs[kMaxOut];
 };
 
-// three bf16x8 pieces of 8 fp32 values
-__device__ __forceinline__ void split3(const float (&x)[8], bf16x8 &hi, bf16x8 &mid, bf16x8 &lo)
+template <typename F, int... I>
+__device__ __forceinline__ void static_for_impl(F &&f, std::integer_sequence<int, I...>)
 {
+    (f(std::integral_constant<int, I>{}), ...);
+}
+template <int N, typename F>
+__device__ __forceinline__ void static_for(F &&f)
+{
+    static_for_impl(f, std::make_integer_sequence<int, N>{});
+}
+
+// LDS reads the compiler does not see: the weight chunks arrive by `buffer_load ... lds`, and the compiler orders every LDS
+// read it knows of behind ALL such loads in flight (s_waitcnt vmcnt(0)) -- which would serialise the two-chunk-deep prefetch.
+// So the LDS reads between the first and the last k-step of a tile are inline assembly.  A read and its s_waitcnt always sit
+// in ONE asm statement: the compiler takes an asm output as valid when the statement ends (it may copy the register at once).
+__device__ __forceinline__ void lds_read64_sync(uint32_t addr, f32x4 &a, f32x4 &b, f32x4 &c, f32x4 &d)
+{
+    asm volatile("ds_read_b128 %0, %4\n\tds_read_b128 %1, %4 offset:16\n\tds_read_b128 %2, %4 offset:32\n\tds_read_b128 %3, %4 offset:48\n\t"
+                 "s_waitcnt lgkmcnt(0)"
+                 : "=&v"(a), "=&v"(b), "=&v"(c), "=&v"(d)
+                 : "v"(addr)
+                 : "memory");
+}
+// 4 rows of 64 bytes, 128 bytes apart (the bias rows of four feature tiles)
+__device__ __forceinline__ void lds_read4x64_sync(uint32_t addr, f32x4 (&r)[4][4])
+{
+    asm volatile("ds_read_b128 %0, %16\n\tds_read_b128 %1, %16 offset:16\n\tds_read_b128 %2, %16 offset:32\n\tds_read_b128 %3, %16 offset:48\n\t"
+                 "ds_read_b128 %4, %16 offset:128\n\tds_read_b128 %5, %16 offset:144\n\tds_read_b128 %6, %16 offset:160\n\tds_read_b128 %7, %16 offset:176\n\t"
+                 "ds_read_b128 %8, %16 offset:256\n\tds_read_b128 %9, %16 offset:272\n\tds_read_b128 %10, %16 offset:288\n\tds_read_b128 %11, %16 offset:304\n\t"
+                 "ds_read_b128 %12, %16 offset:384\n\tds_read_b128 %13, %16 offset:400\n\tds_read_b128 %14, %16 offset:416\n\tds_read_b128 %15, %16 offset:432\n\t"
+                 "s_waitcnt lgkmcnt(0)"
+                 : "=&v"(r[0][0]), "=&v"(r[0][1]), "=&v"(r[0][2]), "=&v"(r[0][3]), "=&v"(r[1][0]), "=&v"(r[1][1]), "=&v"(r[1][2]), "=&v"(r[1][3]),
+                   "=&v"(r[2][0]), "=&v"(r[2][1]), "=&v"(r[2][2]), "=&v"(r[2][3]), "=&v"(r[3][0]), "=&v"(r[3][1]), "=&v"(r[3][2]), "=&v"(r[3][3])
+                 : "v"(addr)
+                 : "memory");
+}
+
+// three bf16x8 pieces of 8 fp32 values
+struct B3 {
+    bf16x8 hi, mid, lo;
+};
+__device__ __forceinline__ B3 split3(const float (&x)[8])
+{
+    B3 b;
 #pragma unroll
     for (int j = 0; j < 8; ++j) {
         const __bf16 a = (__bf16)x[j];
         const float r1 = x[j] - (float)a;
-        const __bf16 b = (__bf16)r1;
-        const float r2 = r1 - (float)b;
-        hi[j] = a;
-        mid[j] = b;
-        lo[j] = (__bf16)r2;
+        const __bf16 m = (__bf16)r1;
+        const float r2 = r1 - (float)m;
+        b.hi[j] = a;
+        b.mid[j] = m;
+        b.lo[j] = (__bf16)r2;
     }
+    return b;
 }
 
-__device__ __forceinline__ void mfma6(f32x16 &acc, const bf16x8 (&a)[3], const bf16x8 &bh, const bf16x8 &bm, const bf16x8 &bl)
+// The MFMAs of one k-step over NT output tiles, two tiles at a time, each shape one asm block (generated: gen/mlp3_kstep.py).
+// FIRST: the layer's first k-step (the accumulators start at 0, whatever they held).
+#include "mlp3_kstep.inc"
+
+template <int NT, bool FIRST>
+__device__ __forceinline__ void kstep_mfma(f32x16 (&acc)[NT], uint32_t abase, const B3 &b)
 {
-    acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[1], bm, acc, 0, 0, 0);
-    acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[0], bl, acc, 0, 0, 0);
-    acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[2], bh, acc, 0, 0, 0);
-    acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[0], bm, acc, 0, 0, 0);
-    acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[1], bh, acc, 0, 0, 0);
-    acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[0], bh, acc, 0, 0, 0);
+    static_assert(NT == 8 || NT == 13 || NT == 5 || NT == 3, "k-step shapes generated: 8, 13, 5, 3 tiles");
+    if constexpr (NT == 8) kstep_asm_8<FIRST>(acc, abase, b);
+    if constexpr (NT == 13) kstep_asm_13<FIRST>(acc, abase, b);
+    if constexpr (NT == 5) kstep_asm_5<FIRST>(acc, abase, b);
+    if constexpr (NT == 3) kstep_asm_3<FIRST>(acc, abase, b);
 }
 
-template <int OT>  // output tiles held in registers at once (13 for the Zhao-Carr emulator)
+template <int OT, bool RES>  // output tiles held in registers at once (13 for the Zhao-Carr emulator); residual outputs
 __global__ __launch_bounds__(256, 1) void mlp3_kernel(const Mlp3Launch p)
 {
-    constexpr int CH_H = 3 * kHT * 64;                 // float4 per hidden-type chunk (24 KB)
-    constexpr int CH_O = ((3 * OT * 64 + 255) / 256) * 256;  // per output-type chunk, padded to whole rounds of 256 threads
+    constexpr int CH_H = 3 * kHT * 64;                        // float4 per hidden-type chunk (24 KB)
+    constexpr int CH_O = ((3 * OT * 64 + 255) / 256) * 256;   // per output-type chunk, padded to whole rounds of 256 lanes
     constexpr int CH_MAX = (CH_H > CH_O) ? CH_H : CH_O;
-    constexpr int PER_H = CH_H / 256, PER_O = CH_O / 256, PER_MAX = (PER_H > PER_O) ? PER_H : PER_O;
+    constexpr int PER_H = CH_H / 256, PER_O = CH_O / 256;     // buffer_load ... lds instructions per wave and chunk
+    constexpr uint32_t CHB = CH_MAX * 16;
+    constexpr int NPRE = OT < 8 ? OT : 8;                     // output tiles whose `before` rows are prefetched in the output phase
     extern __shared__ __attribute__((aligned(16))) char smem[];
-    f32x4 *wbuf = reinterpret_cast<f32x4 *>(smem);                 // [2][CH_MAX]
-    float *cen = reinterpret_cast<float *>(wbuf + 2 * CH_MAX);     // [n_ks1 * 16]
-    float *epsl = cen + p.n_ks1 * 16;                              // [n_ks1 * 16]
-    int64_t *xrow = reinterpret_cast<int64_t *>(epsl + p.n_ks1 * 16);   // [n_ks1 * 16] byte address of (feature row, sample 0); 0 = padding
-    int64_t *orow = xrow + p.n_ks1 * 16;                           // [n_ot * 32] output row address, 0 = none
-    int64_t *rsrc = orow + p.n_ot * 32;                            // [n_ot * 32] residual `before` row, 0 = none
-    int64_t *rout = rsrc + p.n_ot * 32;                            // [n_ot * 32] residual `after` row
+    // LDS: [3 chunk buffers][bias table][centre][eps][row tables of the epilogue]
+    float *bias_t = reinterpret_cast<float *>(smem + 3 * (size_t)CHB);     // [(n_hidden 8 + OT)][2][16]
+    float *ce = bias_t + (p.n_hidden * kHT + OT) * 32;                     // [n_ks1][2 halves]{centre[8], epsilon[8]}
+    int64_t *orow = reinterpret_cast<int64_t *>(ce + p.n_ks1 * 32);        // [OT][2 register blocks][2 halves][8]: output row, 0 = none
+    int64_t *rsrc = orow + OT * 32;                                        // residual `before` row (a readable dummy where none)
+    int64_t *rout = rsrc + OT * 32;                                        // residual `after` row, 0 = none
+    const uint32_t lds0 = (uint32_t)(uintptr_t)(lds_char *)smem;
 
-    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, half = lane >> 5, col = lane & 31;
-    for (int i = tid; i < p.n_ks1 * 16; i += 256) {
-        cen[i] = p.center[i];
-        epsl[i] = p.eps[i];
-        const int s = p.xsrc[i];
-        xrow[i] = s < 0 ? 0 : reinterpret_cast<int64_t>(p.src[s]) + (int64_t)p.xfeat[i] * p.src_fs[s] * 4;
+    const int tid = threadIdx.x, lane = tid & 63, half = lane >> 5, col = lane & 31;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    for (int i = tid; i < (p.n_hidden * kHT + OT) * 32; i += 256) bias_t[i] = p.bias[i];
+    for (int i = tid; i < p.n_ks1 * 16; i += 256) {   // i = (k-step, half, j)
+        ce[(i >> 3) * 16 + (i & 7)] = p.center[i];
+        ce[(i >> 3) * 16 + 8 + (i & 7)] = p.eps[i];
     }
-    for (int i = tid; i < p.n_ot * 32; i += 256) {
-        const int of = p.ofeat[i], rs = p.ores[i];
+    for (int i = tid; i < OT * 32; i += 256) {
+        // table slot (t, rb, hf, jj) holds feature 32 t + rho3(8 rb + jj) + 4 hf
+        const int t = i >> 5, rb = (i >> 4) & 1, hf = (i >> 3) & 1, jj = i & 7;
+        const int f = 32 * t + rho3(8 * rb + jj) + 4 * hf;
+        const int of = p.ofeat[f], rs = p.ores[f];
         orow[i] = of < 0 ? 0 : reinterpret_cast<int64_t>(p.out[of >> 20]) + (int64_t)(of & 0xFFFFF) * p.out_fs[of >> 20] * 4;
         if (of >= 0 && rs >= 0) {
             const int feat = of & 0xFFFFF;
             rsrc[i] = reinterpret_cast<int64_t>(p.src[rs & 0xFF]) + (int64_t)feat * p.src_fs[rs & 0xFF] * 4;
             rout[i] = reinterpret_cast<int64_t>(p.out[rs >> 8]) + (int64_t)feat * p.out_fs[rs >> 8] * 4;
         } else {
-            rsrc[i] = 0;
+            rsrc[i] = reinterpret_cast<int64_t>(p.src[0]);
             rout[i] = 0;
         }
     }
     __syncthreads();
 
-    // ---- the weight stream: chunk g of a tile's G = n_ks1 + 16 (n_hidden - 1) + 16 chunks ----
+    // ---- the weight stream: chunk g of a tile's G = n_ks1 + 16 (n_hidden - 1) + 16 chunks; three LDS buffers, the chunk of
+    // k-step g + 2 is requested at the start of k-step g and awaited (this wave's share, then the barrier) at the end of g + 1
     const int n_hid_chunks = p.n_ks1 + 16 * (p.n_hidden - 1);
     const int G = n_hid_chunks + 16;
-    f32x4 stage[PER_MAX];
-    auto chunk_off = [&](int g) -> size_t { return g < n_hid_chunks ? (size_t)g * CH_H : (size_t)n_hid_chunks * CH_H + (size_t)(g - n_hid_chunks) * CH_O; };
-    auto issue_w = [&](int g) {
-        const f32x4 *src = p.w + chunk_off(g) + tid;
-        if (g < n_hid_chunks) {
-#pragma unroll
-            for (int i = 0; i < PER_H; ++i) stage[i] = src[i * 256];
-        } else {
-#pragma unroll
-            for (int i = 0; i < PER_O; ++i) stage[i] = src[i * 256];
-        }
+    const __amdgpu_buffer_rsrc_t w_rsrc = __builtin_amdgcn_make_buffer_rsrc(const_cast<f32x4 *>(p.w), 0, p.w_bytes, 0x00020000);
+    uint32_t b0 = 0, b1 = CHB, b2 = 2 * CHB;   // LDS byte offsets of the buffers holding chunks g, g + 1, g + 2
+    auto chunk_bytes = [&](int g) -> uint32_t {
+        return g < n_hid_chunks ? (uint32_t)g * (CH_H * 16) : (uint32_t)n_hid_chunks * (CH_H * 16) + (uint32_t)(g - n_hid_chunks) * (CH_O * 16);
     };
-    auto commit_w = [&](int g, int buf) {
-        f32x4 *dst = wbuf + (size_t)buf * CH_MAX + tid;
-        if (g < n_hid_chunks) {
+    auto dma = [&](auto per_c, int g, uint32_t buf) {
+        constexpr int PER = decltype(per_c)::value;
+        const uint32_t goff = chunk_bytes(g) + wave * 1024;
+        lds_char *dst = (lds_char *)smem + buf + wave * 1024;
 #pragma unroll
-            for (int i = 0; i < PER_H; ++i) dst[i * 256] = stage[i];
-        } else {
-#pragma unroll
-            for (int i = 0; i < PER_O; ++i) dst[i * 256] = stage[i];
-        }
+        for (int i = 0; i < PER; ++i)
+            __builtin_amdgcn_raw_ptr_buffer_load_lds(w_rsrc, (__attribute__((address_space(3))) void *)(dst + i * 4096), 16, lane * 16,
+                                                     goff + i * 4096, 0, 0);
     };
-    int par = 0;
-    issue_w(0);
-    commit_w(0, 0);
-    __syncthreads();
-    // one k-step of NT output tiles: 6 MFMAs per tile on the chunk in wbuf[par]; the next chunk is requested before and
-    // committed after them; one barrier per k-step
-    auto kstep = [&](auto &acc, auto nt_c, int g, const bf16x8 &bh, const bf16x8 &bm, const bf16x8 &bl) __attribute__((always_inline)) {
-        constexpr int NT = decltype(nt_c)::value;
-        const int gn = (g + 1 < G) ? g + 1 : 0;
-        issue_w(gn);
-        const f32x4 *lw = wbuf + (size_t)par * CH_MAX + lane;
-#pragma unroll
-        for (int t = 0; t < NT; ++t) {
-            bf16x8 a[3];
-#pragma unroll
-            for (int q = 0; q < 3; ++q) a[q] = __builtin_bit_cast(bf16x8, lw[(q * NT + t) * 64]);
-            mfma6(acc[t], a, bh, bm, bl);
-        }
-        commit_w(gn, par ^ 1);
-        __syncthreads();
-        par ^= 1;
+    // request the chunk two k-steps ahead of k-step g; returns whether it is a hidden-type chunk (its load count)
+    auto request_ahead = [&](int g) -> bool {
+        int g2 = g + 2;
+        if (g2 >= G) g2 -= G;
+        const bool is_h = g2 < n_hid_chunks;
+        if (is_h)
+            dma(std::integral_constant<int, PER_H>{}, g2, b2);
+        else
+            dma(std::integral_constant<int, PER_O>{}, g2, b2);
+        return is_h;
     };
+    // end of a k-step: this wave's share of chunk g + 1 has landed when at most the loads issued after it are in flight
+    // (EXTRA other loads + the chunk requested in this k-step); then the barrier, and the buffers rotate
+    auto fence = [&](auto extra_c, bool ahead_is_h) {
+        constexpr int EXTRA = decltype(extra_c)::value;
+        if (ahead_is_h)
+            asm volatile("s_waitcnt vmcnt(%0)\n\ts_barrier" ::"n"(EXTRA + PER_H) : "memory");
+        else
+            asm volatile("s_waitcnt vmcnt(%0)\n\ts_barrier" ::"n"(EXTRA + PER_O) : "memory");
+        const uint32_t t_ = b0;
+        b0 = b1;
+        b1 = b2;
+        b2 = t_;
+    };
+    const uint32_t a_lane = lds0 + lane * 16;
+    const uint32_t bias_lane = lds0 + 3 * CHB + half * 64;                         // + tile * 128
+    const uint32_t ce_lane = bias_lane + (p.n_hidden * kHT + OT) * 128;            // + ks * 128: {centre[8], epsilon[8]} of this half
+    const uint32_t row_addr = ce_lane + p.n_ks1 * 128;                             // orow: + (t * 2 + rb) * 128
+
+    // the first two chunks of the first tile
+    dma(std::integral_constant<int, PER_H>{}, 0, b0);   // (n_hid_chunks >= 1: chunk 0 is always hidden-type)
+    if (1 < n_hid_chunks)
+        dma(std::integral_constant<int, PER_H>{}, 1, b1);
+    else
+        dma(std::integral_constant<int, PER_O>{}, 1, b1);
+    asm volatile("s_waitcnt vmcnt(0)\n\ts_barrier" ::: "memory");
 
     for (int64_t tile = blockIdx.x; tile < p.n_tiles; tile += gridDim.x) {
         const int64_t n = tile * 128 + wave * 32 + col;
         const bool valid = n < p.n_samples;
-        const int64_t nb = (valid ? n : p.n_samples - 1) * 4;  // byte offset of this lane's sample inside a row
+        const uint32_t nb = (uint32_t)((valid ? n : p.n_samples - 1) * 4);  // byte offset of this lane's sample inside a row
         int g = 0;
         // ================= layer 1 =================
-        f32x16 h[kHT];
-#pragma unroll
-        for (int t = 0; t < kHT; ++t)
-#pragma unroll
-            for (int r = 0; r < 16; ++r) h[t][r] = p.bias[(t * 16 + r) * 2 + half];
-        float xn[8];
-        auto load_x = [&](int ks) {
+        // x of k-step ks: 8 buffer loads (rows 8 half + j of the k-step's 16), requested two k-steps ahead
+        auto load_x = [&](int ks, float (&x)[8]) {
+            const XStep s = p.xk[ks];
+            const uint32_t fs4 = __builtin_amdgcn_readfirstlane(s.fs4), nrec = __builtin_amdgcn_readfirstlane(s.nrec);
+            const uint32_t voff = nb + (half ? 8u * fs4 : 0u);
 #pragma unroll
             for (int j = 0; j < 8; ++j) {
-                const int64_t row = xrow[ks * 16 + half * 8 + j];
-                xn[j] = row ? *reinterpret_cast<const float *>(row + nb) : 0.f;
+                // (the scalar offset of a buffer load is not bounds-checked: row j gets its own resource, all scalar arithmetic)
+                const uint32_t skip = j * fs4;
+                const uint64_t row = s.base + skip;
+                const uint64_t row_u = ((uint64_t)(uint32_t)__builtin_amdgcn_readfirstlane((uint32_t)(row >> 32)) << 32) |
+                                       (uint32_t)__builtin_amdgcn_readfirstlane((uint32_t)row);
+                const uint32_t left = __builtin_amdgcn_readfirstlane(nrec > skip ? nrec - skip : 0u);
+                const __amdgpu_buffer_rsrc_t r = __builtin_amdgcn_make_buffer_rsrc(reinterpret_cast<void *>(row_u), 0, left, 0x00020000);
+                x[j] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(r, voff, 0, 0));
             }
         };
-        load_x(0);
-        for (int ks = 0; ks < p.n_ks1; ++ks) {
+        // normalise (log / centre) and split; `t` = the k-step's table row {centre[8], epsilon[8]} of this half
+        auto transform = [&](int ks, const float (&xr)[8], const f32x4 (&t)[4]) -> B3 {
             float x[8];
-            const float *c = cen + ks * 16 + half * 8;
             if (ks < p.n_log_ks) {
-                const float *e = epsl + ks * 16 + half * 8;
 #pragma unroll
                 for (int j = 0; j < 8; ++j) {
-                    const float v = xn[j] < e[j] ? e[j] : xn[j];
-                    x[j] = __builtin_amdgcn_logf(v) * 0.693147180559945f - c[j];
+                    const float e = t[2 + (j >> 2)][j & 3], c = t[j >> 2][j & 3];
+                    const float v = xr[j] < e ? e : xr[j];
+                    x[j] = __builtin_amdgcn_logf(v) * 0.693147180559945f - c;
                 }
             } else {
 #pragma unroll
-                for (int j = 0; j < 8; ++j) x[j] = xn[j] - c[j];
+                for (int j = 0; j < 8; ++j) x[j] = xr[j] - t[j >> 2][j & 3];
             }
-            if (ks + 1 < p.n_ks1) load_x(ks + 1);
-            bf16x8 bh, bm, bl;
-            split3(x, bh, bm, bl);
-            kstep(h, std::integral_constant<int, kHT>{}, g, bh, bm, bl);
+            return split3(x);
+        };
+        f32x16 h[kHT];
+        float xa[8], xb[8];
+        f32x4 tn[4], tnn[4];
+        load_x(0, xa);
+        load_x(p.n_ks1 > 1 ? 1 : 0, xb);
+        lds_read64_sync(ce_lane, tn[0], tn[1], tn[2], tn[3]);
+        B3 b = transform(0, xa, tn);
+        lds_read64_sync(ce_lane + (p.n_ks1 > 1 ? 128 : 0), tn[0], tn[1], tn[2], tn[3]);
+#pragma unroll
+        for (int j = 0; j < 8; ++j) xa[j] = xb[j];
+        // k-step ks: request x of ks + 2 and the chunk of g + 2, normalise / split x of ks + 1 (table row read during ks - 1),
+        // the MFMAs (their block also reads the table row of ks + 2)
+        auto layer1_step = [&](auto first_c, int ks) __attribute__((always_inline)) {
+            const int ks2 = ks + 2 < p.n_ks1 ? ks + 2 : p.n_ks1 - 1;   // (the last two k-steps reload the last rows: the load count stays static)
+            load_x(ks2, xb);
+            const bool ah = request_ahead(g);
+            B3 bn;
+            if (ks + 1 < p.n_ks1) bn = transform(ks + 1, xa, tn);
+            kstep_asm_8_tab<decltype(first_c)::value>(h, a_lane + b0, b, ce_lane + ks2 * 128, tnn[0], tnn[1], tnn[2], tnn[3]);
+            fence(std::integral_constant<int, 8>{}, ah);
+            b = bn;
+#pragma unroll
+            for (int j = 0; j < 8; ++j) xa[j] = xb[j];
+#pragma unroll
+            for (int q = 0; q < 4; ++q) tn[q] = tnn[q];
             ++g;
-        }
+        };
+        layer1_step(std::true_type{}, 0);
+        for (int ks = 1; ks < p.n_ks1; ++ks) layer1_step(std::false_type{}, ks);
+        asm volatile("s_nop 15\n\ts_nop 7");   // (the last MFMAs' results, before anything the compiler schedules reads them)
+        // bias + ReLU (bias rows: four tiles per LDS round trip)
+        auto bias_relu = [&](f32x16 (&dst)[kHT], const f32x16 (&raw)[kHT], int layer) {
+            const uint32_t ba = bias_lane + layer * (kHT * 128);
+            static_for<kHT / 4>([&](auto gc) {
+                constexpr int T4 = decltype(gc)::value * 4;
+                f32x4 bq[4][4];
+                lds_read4x64_sync(ba + T4 * 128, bq);
 #pragma unroll
-        for (int t = 0; t < kHT; ++t)
+                for (int tt = 0; tt < 4; ++tt)
 #pragma unroll
-            for (int r = 0; r < 16; ++r) h[t][r] = h[t][r] < 0.f ? 0.f : h[t][r];
+                    for (int r = 0; r < 16; ++r) {
+                        const float v = raw[T4 + tt][r] + bq[tt][r >> 2][r & 3];
+                        dst[T4 + tt][r] = v < 0.f ? 0.f : v;
+                    }
+            });
+        };
+        bias_relu(h, h, 0);
+        auto b_of = [&](const f32x16 (&hh)[kHT], auto ks_c) -> B3 {
+            constexpr int KS = decltype(ks_c)::value;
+            float x[8];
+#pragma unroll
+            for (int j = 0; j < 8; ++j) x[j] = hh[KS / 2][(KS % 2) * 8 + j];
+            return split3(x);
+        };
         // ================= hidden -> hidden =================
         for (int l = 1; l < p.n_hidden; ++l) {
             f32x16 h2[kHT];
-            const float *bl_ = p.bias + l * kHT * 32;
-#pragma unroll
-            for (int t = 0; t < kHT; ++t)
-#pragma unroll
-                for (int r = 0; r < 16; ++r) h2[t][r] = bl_[(t * 16 + r) * 2 + half];
-#pragma unroll
-            for (int ks = 0; ks < 16; ++ks) {
-                float x[8];
-#pragma unroll
-                for (int j = 0; j < 8; ++j) x[j] = h[ks / 2][(ks % 2) * 8 + j];
-                bf16x8 bh, bm, blo;
-                split3(x, bh, bm, blo);
-                kstep(h2, std::integral_constant<int, kHT>{}, g, bh, bm, blo);
+            b = b_of(h, std::integral_constant<int, 0>{});
+            static_for<16>([&](auto ks_c) {
+                constexpr int KS = decltype(ks_c)::value;
+                const bool ah = request_ahead(g);
+                B3 bn;
+                if constexpr (KS + 1 < 16) bn = b_of(h, std::integral_constant<int, (KS + 1 < 16 ? KS + 1 : 0)>{});
+                kstep_mfma<kHT, KS == 0>(h2, a_lane + b0, b);
+                fence(std::integral_constant<int, 0>{}, ah);
+                if constexpr (KS + 1 < 16) b = bn;
                 ++g;
-            }
-#pragma unroll
-            for (int t = 0; t < kHT; ++t)
-#pragma unroll
-                for (int r = 0; r < 16; ++r) h[t][r] = h2[t][r] < 0.f ? 0.f : h2[t][r];
+            });
+            asm volatile("s_nop 15\n\ts_nop 7");
+            bias_relu(h, h2, l);
         }
         // ================= hidden -> outputs =================
         f32x16 y[OT];
-        {
-            const float *bo = p.bias + p.n_hidden * kHT * 32;
+        float before[NPRE][16];
+        b = b_of(h, std::integral_constant<int, 0>{});
+        const int64_t nb64 = nb;
+        // the `before` rows of output tile T, register block RB (8 values): row table by hand-placed LDS reads
+        auto load_before = [&](auto t_c, auto rb_c, float *dst) {
+            constexpr int T = decltype(t_c)::value, RB = decltype(rb_c)::value;
+            const uint32_t ra = row_addr + OT * 256 + (T * 2 + RB) * 128;   // rsrc table
+            f32x4 rr[4];
+            lds_read64_sync(ra, rr[0], rr[1], rr[2], rr[3]);
 #pragma unroll
-            for (int t = 0; t < OT; ++t)
-#pragma unroll
-                for (int r = 0; r < 16; ++r) y[t][r] = bo[(t * 16 + r) * 2 + half];
-        }
-#pragma unroll
-        for (int ks = 0; ks < 16; ++ks) {
-            float x[8];
-#pragma unroll
-            for (int j = 0; j < 8; ++j) x[j] = h[ks / 2][(ks % 2) * 8 + j];
-            bf16x8 bh, bm, blo;
-            split3(x, bh, bm, blo);
-            kstep(y, std::integral_constant<int, OT>{}, g, bh, bm, blo);
+            for (int jj = 0; jj < 8; ++jj) {
+                const f32x2 pr = {rr[jj >> 1][(jj & 1) * 2], rr[jj >> 1][(jj & 1) * 2 + 1]};
+                const int64_t row = __builtin_bit_cast(int64_t, pr);
+                dst[jj] = *reinterpret_cast<const float *>(row + nb64);
+            }
+        };
+        static_for<16>([&](auto ks_c) {
+            constexpr int KS = decltype(ks_c)::value;
+            if constexpr (RES && KS / 2 < NPRE)   // (the h registers of k-step KS are free: KS + 1's operand was split a k-step ago)
+                load_before(std::integral_constant<int, KS / 2>{}, std::integral_constant<int, KS % 2>{}, &before[KS / 2 < NPRE ? KS / 2 : 0][(KS % 2) * 8]);
+            const bool ah = request_ahead(g);
+            B3 bn;
+            if constexpr (KS + 1 < 16) bn = b_of(h, std::integral_constant<int, (KS + 1 < 16 ? KS + 1 : 0)>{});
+            kstep_mfma<OT, KS == 0>(y, a_lane + b0, b);
+            fence(std::integral_constant<int, (RES && KS / 2 < NPRE) ? 8 : 0>{}, ah);
+            if constexpr (KS + 1 < 16) b = bn;
             ++g;
-        }
-        // ================= epilogue: direct stores (a row of a wave = 32 samples = 128 bytes) =================
-        if (valid) {
+        });
+        asm volatile("s_nop 15\n\ts_nop 7");
+        // ================= epilogue: bias, direct stores (a row of a wave = 32 samples = 128 bytes) =================
+        auto rows_of = [&](const int64_t *table, int t, int rb, int64_t (&rows)[8]) {
+            const int64_t *q = table + ((t * 2 + rb) * 2 + half) * 8;
 #pragma unroll
-            for (int t = 0; t < OT; ++t) {
-                float before[16];
-                if (p.n_residual) {
+            for (int jj = 0; jj < 8; ++jj) rows[jj] = q[jj];
+        };
+        auto finish_tile = [&](auto t_c, const float *bef) {
+            constexpr int T = decltype(t_c)::value;
+            const float *bo = bias_t + ((p.n_hidden * kHT + T) * 2 + half) * 16;
 #pragma unroll
-                    for (int r = 0; r < 16; ++r) {
-                        const int64_t rs = rsrc[t * 32 + rho3(r) + 4 * half];
-                        before[r] = rs ? *reinterpret_cast<const float *>(rs + nb) : 0.f;
-                    }
-                }
+            for (int rb = 0; rb < 2; ++rb) {
+                int64_t ro[8], ra[8];
+                rows_of(orow, T, rb, ro);
+                if (RES) rows_of(rout, T, rb, ra);
 #pragma unroll
-                for (int r = 0; r < 16; ++r) {
-                    const int idx = t * 32 + rho3(r) + 4 * half;
-                    const int64_t o = orow[idx];
-                    if (o) *reinterpret_cast<float *>(o + nb) = y[t][r];
-                    if (p.n_residual) {
-                        const int64_t ro = rout[idx];
-                        if (ro) *reinterpret_cast<float *>(ro + nb) = before[r] + y[t][r];
-                    }
+                for (int jj = 0; jj < 8; ++jj) {
+                    const float v = y[T][rb * 8 + jj] + bo[rb * 8 + jj];
+                    if (valid && ro[jj]) *reinterpret_cast<float *>(ro[jj] + nb64) = v;
+                    if (RES)
+                        if (valid && ra[jj]) *reinterpret_cast<float *>(ra[jj] + nb64) = bef[rb * 8 + jj] + v;
                 }
             }
+        };
+        if constexpr (RES) {
+            float later[(OT > NPRE ? OT - NPRE : 1)][16];
+            static_for<NPRE>([&](auto t_c) {
+                constexpr int T = decltype(t_c)::value;
+                finish_tile(t_c, before[T]);
+                if constexpr (T + NPRE < OT) {
+                    load_before(std::integral_constant<int, (T + NPRE < OT ? T + NPRE : 0)>{}, std::integral_constant<int, 0>{}, &later[T + NPRE < OT ? T : 0][0]);
+                    load_before(std::integral_constant<int, (T + NPRE < OT ? T + NPRE : 0)>{}, std::integral_constant<int, 1>{}, &later[T + NPRE < OT ? T : 0][8]);
+                }
+            });
+            static_for<(OT > NPRE ? OT - NPRE : 0)>([&](auto t_c) {
+                constexpr int T = decltype(t_c)::value;
+                finish_tile(std::integral_constant<int, T + NPRE>{}, later[T]);
+            });
+        } else {
+            static_for<OT>([&](auto t_c) { finish_tile(t_c, nullptr); });
         }
     }
+    // (chunks requested for a tile this workgroup does not have are still in flight towards its LDS)
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
 }
 
 inline unsigned short bf16_rne(float x)
@@ -305,9 +447,10 @@ struct fv3hip_mlp3 {
     int device = 0, n_cu = 256;
     int n_sources = 0, n_outputs = 0, n_residual = 0, n_hidden = 0, n_ks1 = 0, n_log_ks = 0, n_ot = 0;
     int64_t flops = 0;
-    void *d_w = nullptr, *d_bias = nullptr, *d_center = nullptr, *d_eps = nullptr, *d_xsrc = nullptr, *d_xfeat = nullptr,
-         *d_ofeat = nullptr, *d_ores = nullptr;
-    size_t lds_bytes = 0;
+    void *d_w = nullptr, *d_bias = nullptr, *d_center = nullptr, *d_eps = nullptr, *d_ofeat = nullptr, *d_ores = nullptr;
+    size_t lds_bytes = 0, w_bytes = 0;
+    // per layer-1 k-step: the source it reads, its first feature row there and how many real rows follow (<= 16)
+    std::vector<int> ks_src, ks_feat0, ks_rows;
 };
 
 namespace {
@@ -325,7 +468,7 @@ int upload3(const std::vector<T> &v, void **dptr)
 extern "C" int fv3hip_mlp3_destroy(fv3hip_mlp3_t m)
 {
     if (!m) return FV3HIP_OK;
-    for (void *q : {m->d_w, m->d_bias, m->d_center, m->d_eps, m->d_xsrc, m->d_xfeat, m->d_ofeat, m->d_ores})
+    for (void *q : {m->d_w, m->d_bias, m->d_center, m->d_eps, m->d_ofeat, m->d_ores})
         if (q) hipFree(q);
     delete m;
     return FV3HIP_OK;
@@ -350,26 +493,38 @@ extern "C" int fv3hip_mlp3_create(const fv3hip_mlp_desc_t *d, fv3hip_mlp3_t *out
     const int n_ot = (F + 31) / 32;
     if (n_ot != 13 && n_ot != 3 && n_ot != 5)
         return fail(FV3HIP_EUNSUPPORTED, "the split-bf16 kernel is compiled for 3, 5 or 13 output tiles of 32 (got %d outputs)", F);
-    // k-slots of layer 1: log-transformed features first, padded to whole k-steps of 16, then the others
+    // k-slots of layer 1: every input padded to whole k-steps of 16 (a k-step reads 16 consecutive rows of one source), the
+    // log-transformed inputs first
     struct Slot { int src, feat; float center, rscale, eps; int orig; };
     std::vector<Slot> slots;
-    {
+    std::vector<int> ks_src, ks_feat0, ks_rows;
+    int n_log_slots = 0;
+    for (int pass = 0; pass < 2; ++pass) {
         int k = 0;
-        std::vector<Slot> logs, plain;
-        for (int i = 0; i < d->n_inputs; ++i)
-            for (int f = 0; f < d->in_nfeat[i]; ++f, ++k) {
-                Slot s{d->in_source[i], d->in_feat_start[i] + f, d->in_center ? d->in_center[k] : 0.f,
-                       d->in_scale ? (float)(1.0 / (double)d->in_scale[k]) : 1.f, d->in_eps ? d->in_eps[i] : 0.f, k};
-                const bool is_log = d->in_transform && d->in_transform[i] == FV3HIP_TRANSFORM_LOG;
-                if (is_log && !(s.eps >= FLT_MIN))
-                    return fail(FV3HIP_EUNSUPPORTED, "the split-bf16 kernel needs log epsilons >= FLT_MIN (the fast logarithm)");
-                (is_log ? logs : plain).push_back(s);
+        for (int i = 0; i < d->n_inputs; ++i) {
+            const bool is_log = d->in_transform && d->in_transform[i] == FV3HIP_TRANSFORM_LOG;
+            const float eps = d->in_eps ? d->in_eps[i] : 0.f;
+            if (is_log && !(eps >= FLT_MIN))
+                return fail(FV3HIP_EUNSUPPORTED, "the split-bf16 kernel needs log epsilons >= FLT_MIN (the fast logarithm)");
+            if (is_log == (pass == 0)) {
+                for (int f = 0; f < d->in_nfeat[i]; ++f)
+                    slots.push_back(Slot{d->in_source[i], d->in_feat_start[i] + f, d->in_center ? d->in_center[k + f] : 0.f,
+                                         d->in_scale ? (float)(1.0 / (double)d->in_scale[k + f]) : 1.f, eps, k + f});
+                while (slots.size() % 16) slots.push_back(Slot{-1, 0, 0.f, 0.f, 1.f, -1});
+                for (int f0 = 0; f0 < d->in_nfeat[i]; f0 += 16) {
+                    ks_src.push_back(d->in_source[i]);
+                    ks_feat0.push_back(d->in_feat_start[i] + f0);
+                    ks_rows.push_back(d->in_nfeat[i] - f0 < 16 ? d->in_nfeat[i] - f0 : 16);
+                }
             }
-        slots = logs;
-        while (slots.size() % 16) slots.push_back(Slot{-1, 0, 0.f, 0.f, 1.f, -1});
-        const int n_log_slots = (int)slots.size();
-        slots.insert(slots.end(), plain.begin(), plain.end());
-        while (slots.size() % 16) slots.push_back(Slot{-1, 0, 0.f, 0.f, 1.f, -1});
+            k += d->in_nfeat[i];
+        }
+        if (pass == 0) n_log_slots = (int)slots.size();
+    }
+    if (slots.size() / 16 > (size_t)kMaxKs1)
+        return fail(FV3HIP_EUNSUPPORTED, "the split-bf16 kernel takes at most %d layer-1 k-steps of 16 input features (got %zu)", kMaxKs1,
+                    slots.size() / 16);
+    {
         fv3hip_mlp3 *m = new fv3hip_mlp3();
         hipGetDevice(&m->device);
         hipDeviceProp_t prop;
@@ -382,6 +537,9 @@ extern "C" int fv3hip_mlp3_create(const fv3hip_mlp_desc_t *d, fv3hip_mlp3_t *out
         m->n_log_ks = n_log_slots / 16;
         m->n_ot = n_ot;
         m->flops = 2 * ((int64_t)K * W + (int64_t)(d->n_hidden - 1) * W * W + (int64_t)W * F);
+        m->ks_src = ks_src;
+        m->ks_feat0 = ks_feat0;
+        m->ks_rows = ks_rows;
         *out = m;
     }
     fv3hip_mlp3 *m = *out;
@@ -428,24 +586,22 @@ extern "C" int fv3hip_mlp3_create(const fv3hip_mlp_desc_t *d, fv3hip_mlp3_t *out
     for (int l = 0; l < d->n_hidden; ++l)
         for (int t = 0; t < kHT; ++t)
             for (int r = 0; r < 16; ++r)
-                for (int hf = 0; hf < 2; ++hf) bias[(size_t)l * kHT * 32 + (t * 16 + r) * 2 + hf] = d->hidden_biases[l][32 * t + rho3(r) + 4 * hf];
+                for (int hf = 0; hf < 2; ++hf) bias[(((size_t)l * kHT + t) * 2 + hf) * 16 + r] = d->hidden_biases[l][32 * t + rho3(r) + 4 * hf];
     for (int t = 0; t < n_ot; ++t)
         for (int r = 0; r < 16; ++r)
             for (int hf = 0; hf < 2; ++hf) {
                 const int f = 32 * t + rho3(r) + 4 * hf;
                 if (f < F)
-                    bias[(size_t)d->n_hidden * kHT * 32 + (t * 16 + r) * 2 + hf] =
+                    bias[(((size_t)d->n_hidden * kHT + t) * 2 + hf) * 16 + r] =
                         (float)((double)d->out_bias[f] * (d->out_scale ? d->out_scale[f] : 1.f) + (d->out_center ? d->out_center[f] : 0.f));
             }
     std::vector<float> center(slots.size()), eps(slots.size());
-    std::vector<int> xsrc(slots.size()), xfeat(slots.size());
     for (size_t i = 0; i < slots.size(); ++i) {
         center[i] = slots[i].orig < 0 ? 0.f : slots[i].center;
         eps[i] = slots[i].eps;
-        xsrc[i] = slots[i].orig < 0 ? -1 : slots[i].src;
-        xfeat[i] = slots[i].feat;
     }
-    // (a padding slot of a log k-step: x = 0 -> max(0, eps = 1) = 1 -> log 1 = 0, centre 0: exactly 0 times a zero weight)
+    // (a padding slot reads 0 (out of the bounds of its buffer resource); in a log k-step: max(0, eps = 1) = 1 -> log 1 = 0,
+    // centre 0: exactly 0 times a zero weight)
     std::vector<int> ofeat((size_t)n_ot * 32, -1), ores((size_t)n_ot * 32, -1);
     {
         int f = 0;
@@ -461,14 +617,14 @@ extern "C" int fv3hip_mlp3_create(const fv3hip_mlp_desc_t *d, fv3hip_mlp3_t *out
     }
     int rc;
     if ((rc = upload3(w, &m->d_w)) || (rc = upload3(bias, &m->d_bias)) || (rc = upload3(center, &m->d_center)) ||
-        (rc = upload3(eps, &m->d_eps)) || (rc = upload3(xsrc, &m->d_xsrc)) || (rc = upload3(xfeat, &m->d_xfeat)) ||
-        (rc = upload3(ofeat, &m->d_ofeat)) || (rc = upload3(ores, &m->d_ores))) {
+        (rc = upload3(eps, &m->d_eps)) || (rc = upload3(ofeat, &m->d_ofeat)) || (rc = upload3(ores, &m->d_ores))) {
         fv3hip_mlp3_destroy(m);
         *out = nullptr;
         return rc;
     }
     const size_t ch_max = (size_t)((CH_H > CH_O) ? CH_H : CH_O);
-    m->lds_bytes = 2 * ch_max * 16 + (size_t)slots.size() * (4 + 4 + 8) + (size_t)n_ot * 32 * 24;
+    m->w_bytes = w.size() * sizeof(unsigned short);
+    m->lds_bytes = 3 * ch_max * 16 + (size_t)(d->n_hidden * kHT + n_ot) * 128 + (size_t)slots.size() * 8 + (size_t)n_ot * 32 * 24;
     if (m->lds_bytes > 160 * 1024) {
         fv3hip_mlp3_destroy(m);
         *out = nullptr;
@@ -505,8 +661,18 @@ extern "C" int fv3hip_mlp3_predict(fv3hip_mlp3_t m, const void *const *sources, 
     lp.bias = static_cast<const float *>(m->d_bias);
     lp.center = static_cast<const float *>(m->d_center);
     lp.eps = static_cast<const float *>(m->d_eps);
-    lp.xsrc = static_cast<const int *>(m->d_xsrc);
-    lp.xfeat = static_cast<const int *>(m->d_xfeat);
+    lp.w_bytes = (uint32_t)m->w_bytes;
+    for (int ks = 0; ks < m->n_ks1; ++ks) {
+        const int sidx = m->ks_src[ks];
+        const int64_t fs4 = src_feat_stride[sidx] * 4;
+        FV3HIP_REQUIRE(fs4 >= n_samples * 4, "source %d: feature stride %lld < n_samples", sidx, (long long)src_feat_stride[sidx]);
+        if (fs4 * 16 >= ((int64_t)1 << 32))
+            return fail(FV3HIP_EUNSUPPORTED, "the split-bf16 kernel addresses 16 feature rows with 32-bit offsets (feature stride %lld too large)",
+                        (long long)src_feat_stride[sidx]);
+        lp.xk[ks].base = reinterpret_cast<uint64_t>(sources[sidx]) + (uint64_t)m->ks_feat0[ks] * (uint64_t)fs4;
+        lp.xk[ks].nrec = (uint32_t)(m->ks_rows[ks] * fs4);
+        lp.xk[ks].fs4 = (uint32_t)fs4;
+    }
     lp.ofeat = static_cast<const int *>(m->d_ofeat);
     lp.ores = static_cast<const int *>(m->d_ores);
     lp.n_ks1 = m->n_ks1;
@@ -519,12 +685,15 @@ extern "C" int fv3hip_mlp3_predict(fv3hip_mlp3_t m, const void *const *sources, 
     const int grid = (int)(lp.n_tiles < m->n_cu ? lp.n_tiles : m->n_cu);
     hipStream_t st = as_stream(stream);
 #define LAUNCH3_(OT)                                                                                                     \
+    if (m->n_residual) LAUNCH3R_(OT, true) else LAUNCH3R_(OT, false)
+#define LAUNCH3R_(OT, RES)                                                                                               \
     {                                                                                                                    \
-        auto kern = mlp3_kernel<OT>;                                                                                     \
+        auto kern = mlp3_kernel<OT, RES>;                                                                                \
         FV3HIP_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)m->lds_bytes)); \
         hipLaunchKernelGGL(kern, dim3(grid), dim3(256), m->lds_bytes, st, lp);                                           \
     }
     if (m->n_ot == 13) LAUNCH3_(13) else if (m->n_ot == 5) LAUNCH3_(5) else LAUNCH3_(3)
 #undef LAUNCH3_
+#undef LAUNCH3R_
     return check_launch("mlp3_kernel");
 }

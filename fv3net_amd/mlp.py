@@ -406,6 +406,7 @@ class MlpModelSplitBf16:
             _require_device(torch.empty(1, device=self.device))
             self._handle = MlpModel._create(spec, "fv3hip_mlp3_create")
         self.flops_per_sample = int(_lib.load().fv3hip_mlp3_flops_per_sample(self._handle))
+        self.last_variant = "mlp3_kernel"
 
     def predict(self, sources: Mapping[str, torch.Tensor]) -> Dict[str, torch.Tensor]:
         spec = self.spec
