@@ -4,7 +4,8 @@ shape, so that its schedule is exactly the one written here: the A operands (thr
 tile, from the LDS chunk at `ab`) of tile pair P + 1 are requested before the 12 MFMAs of pair P issue, and each wait is a
 hand-placed `s_waitcnt lgkmcnt` (LDS returns in order).  The compiler cannot see LDS reads that overlap the `buffer_load ...
 lds` stream without ordering them behind it, and asynchronous reads in separate asm statements are unsafe (it may copy a
-destination register before the wait), hence one block.
+destination register before the wait), hence one block.  The `_split` shapes also split the NEXT k-step's 8 activations into their bf16 pieces inside the block
+(behind the first LDS requests).
 
 Per tile the six significant products of (w_hi + w_mid + w_lo)(x_hi + x_mid + x_lo) are accumulated smallest first:
     mid*mid, hi*lo, lo*hi, hi*mid, mid*hi, hi*hi.
@@ -14,7 +15,26 @@ import os
 PRODUCTS = [(1, "bm"), (0, "bl"), (2, "bh"), (0, "bm"), (1, "bh"), (0, "bh")]  # (weight piece, activation piece)
 
 
-def block(nt, first, tab):
+def split_text(emit):
+    """x = hi + mid + lo in bf16 (round to nearest; the residuals are exact in fp32) for the 8 values of the NEXT k-step:
+    11 VALU instructions per pair.  They sit behind the first LDS requests of the block, whose latency (the four waves ask
+    at once, right after the barrier) they cover."""
+    for i in range(4):
+        a, b = f"%[xn{2 * i}]", f"%[xn{2 * i + 1}]"
+        emit(f"v_cvt_pk_bf16_f32 %[nh{i}], {a}, {b}")
+        emit(f"v_lshlrev_b32 %[u0], 16, %[nh{i}]")
+        emit(f"v_and_b32 %[u1], 0xffff0000, %[nh{i}]")
+        emit(f"v_sub_f32 %[r0], {a}, %[u0]")
+        emit(f"v_sub_f32 %[r1], {b}, %[u1]")
+        emit(f"v_cvt_pk_bf16_f32 %[nm{i}], %[r0], %[r1]")
+        emit(f"v_lshlrev_b32 %[u0], 16, %[nm{i}]")
+        emit(f"v_and_b32 %[u1], 0xffff0000, %[nm{i}]")
+        emit("v_sub_f32 %[r0], %[r0], %[u0]")
+        emit("v_sub_f32 %[r1], %[r1], %[u1]")
+        emit(f"v_cvt_pk_bf16_f32 %[nl{i}], %[r0], %[r1]")
+
+
+def block(nt, first, tab, split):
     lines = []
     emit = lines.append
     pairs = [(2 * p, 2 * p + 1 if 2 * p + 1 < nt else None) for p in range((nt + 1) // 2)]
@@ -35,9 +55,15 @@ def block(nt, first, tab):
         for i in range(4):
             emit(f"ds_read_b128 %[x{i}], %[tb] offset:{16 * i}")
     request(0)
+    pending1 = request(1) if len(pairs) > 1 else 0
+    if split:
+        split_text(emit)
     for p, (t0, t1) in enumerate(pairs):
         s = p & 1
-        pending = request(p + 1) if p + 1 < len(pairs) else 0
+        if p == 0:
+            pending = pending1
+        else:
+            pending = request(p + 1) if p + 1 < len(pairs) else 0
         emit(f"s_waitcnt lgkmcnt({pending})")
         emit("s_nop 0")
         for i, (q, b) in enumerate(PRODUCTS):
@@ -49,12 +75,19 @@ def block(nt, first, tab):
     return "\\n\\t".join(lines)
 
 
-def function(nt, tab):
-    name = f"kstep_asm_{nt}" + ("_tab" if tab else "")
-    args = f"f32x16 (&c)[{nt}], uint32_t ab, const B3 &b" + (", uint32_t tb, f32x4 &x0, f32x4 &x1, f32x4 &x2, f32x4 &x3" if tab else "")
+def function(nt, tab, split):
+    name = f"kstep_asm_{nt}" + ("_tab" if tab else "") + ("_split" if split else "")
+    args = f"f32x16 (&c)[{nt}], uint32_t ab, const B3 &b"
+    if tab:
+        args += ", uint32_t tb, f32x4 &x0, f32x4 &x1, f32x4 &x2, f32x4 &x3"
+    if split:
+        args += ", const float (&xn)[8], B3 &bn"
     temps = [f"t{s}{tt}{q}" for s in range(2) for tt in range(2) for q in range(3)]
     out = [f"template <bool FIRST>\n__device__ __forceinline__ void {name}({args})\n{{"]
     out.append("    f32x4 " + ", ".join(temps) + ";")
+    if split:
+        out.append("    uint32_t " + ", ".join(f"n{w}{i}" for w in "hml" for i in range(4)) + ";")
+        out.append("    float u0, u1, r0, r1;")
     for first in (True, False):
         out.append("    if constexpr (%sFIRST) {" % ("" if first else "!"))
         cons = "=&a" if first else "+a"
@@ -62,11 +95,18 @@ def function(nt, tab):
         if tab:
             outs += [f'[x{i}] "=&v"(x{i})' for i in range(4)]
         ins = ['[ab] "v"(ab)', '[bh] "v"(b.hi)', '[bm] "v"(b.mid)', '[bl] "v"(b.lo)'] + (['[tb] "v"(tb)'] if tab else [])
-        out.append(f'        asm volatile("{block(nt, first, tab)}"')
+        if split:
+            outs += [f'[n{w}{i}] "=&v"(n{w}{i})' for w in "hml" for i in range(4)]
+            outs += [f'[{t}] "=&v"({t})' for t in ("u0", "u1", "r0", "r1")]
+            ins += [f'[xn{i}] "v"(xn[{i}])' for i in range(8)]
+        out.append(f'        asm volatile("{block(nt, first, tab, split)}"')
         out.append("                     : " + ", ".join(outs))
         out.append("                     : " + ", ".join(ins))
         out.append('                     : "memory");')
         out.append("    }")
+    if split:
+        for w, field in (("h", "hi"), ("m", "mid"), ("l", "lo")):
+            out.append(f"    bn.{field} = __builtin_bit_cast(bf16x8, u32x4{{n{w}0, n{w}1, n{w}2, n{w}3}});")
     out.append("}\n")
     return "\n".join(out)
 
@@ -75,7 +115,8 @@ def main():
     here = os.path.dirname(os.path.abspath(__file__))
     parts = ["// GENERATED by gen/mlp3_kstep.py -- do not edit; see the generator for the schedule.\n"]
     for nt, tab in ((8, False), (8, True), (13, False), (5, False), (3, False)):
-        parts.append(function(nt, tab))
+        for split in (False, True):
+            parts.append(function(nt, tab, split))
     with open(os.path.join(here, "..", "mlp3_kstep.inc"), "w") as f:
         f.write("\n".join(parts))
 

@@ -34,6 +34,7 @@ typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
 typedef float f32x16 __attribute__((ext_vector_type(16)));
 typedef float f32x4 __attribute__((ext_vector_type(4)));
 typedef float f32x2 __attribute__((ext_vector_type(2)));
+typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
 typedef __attribute__((address_space(3))) char lds_char;
 
 constexpr int kHT = 8;          // hidden feature tiles (width 256)
@@ -47,7 +48,7 @@ __host__ __device__ constexpr int rho3(int r) { return (r & 3) + 8 * (r >> 2); }
 // k-steps), so its rows are `base + (8 half + j) fs4`, fetched by bounds-checked buffer loads (a padding row reads 0)
 struct XStep {
     uint64_t base;   // address of (first feature of the k-step, sample 0)
-    uint32_t nrec;   // bytes from there to the end of the input's last feature row
+    uint32_t rows;   // real feature rows of the k-step (1..16; the others read 0)
     uint32_t fs4;    // bytes per feature row
 };
 
@@ -59,6 +60,8 @@ struct Mlp3Launch {
     const float *eps;      // [n_ks1][half][8] log epsilon per k-slot (log k-steps)
     const int *ofeat;      // [n_ot * 32] (output slot << 20 | feature), -1 = padding
     const int *ores;       // [n_ot * 32] (residual slot << 8 | residual source), -1 = none
+    float *sink;           // a row of n_samples floats nobody reads: where padding features / absent residuals are stored
+    unsigned long long *stamps;  // diagnostic builds only (-DMLP3_STAMPS): [workgroup][wave][8] cycle sums per phase
     int n_ks1, n_log_ks, n_hidden, n_ot, n_residual;
     int64_t n_samples, n_tiles;
     XStep xk[kMaxKs1];
@@ -138,6 +141,15 @@ __device__ __forceinline__ void kstep_mfma(f32x16 (&acc)[NT], uint32_t abase, co
     if constexpr (NT == 5) kstep_asm_5<FIRST>(acc, abase, b);
     if constexpr (NT == 3) kstep_asm_3<FIRST>(acc, abase, b);
 }
+// ... and the split of the next k-step's activations `xn` into `bn` inside the block
+template <int NT, bool FIRST>
+__device__ __forceinline__ void kstep_mfma_split(f32x16 (&acc)[NT], uint32_t abase, const B3 &b, const float (&xn)[8], B3 &bn)
+{
+    if constexpr (NT == 8) kstep_asm_8_split<FIRST>(acc, abase, b, xn, bn);
+    if constexpr (NT == 13) kstep_asm_13_split<FIRST>(acc, abase, b, xn, bn);
+    if constexpr (NT == 5) kstep_asm_5_split<FIRST>(acc, abase, b, xn, bn);
+    if constexpr (NT == 3) kstep_asm_3_split<FIRST>(acc, abase, b, xn, bn);
+}
 
 template <int OT, bool RES>  // output tiles held in registers at once (13 for the Zhao-Carr emulator); residual outputs
 __global__ __launch_bounds__(256, 1) void mlp3_kernel(const Mlp3Launch p)
@@ -152,9 +164,9 @@ __global__ __launch_bounds__(256, 1) void mlp3_kernel(const Mlp3Launch p)
     // LDS: [3 chunk buffers][bias table][centre][eps][row tables of the epilogue]
     float *bias_t = reinterpret_cast<float *>(smem + 3 * (size_t)CHB);     // [(n_hidden 8 + OT)][2][16]
     float *ce = bias_t + (p.n_hidden * kHT + OT) * 32;                     // [n_ks1][2 halves]{centre[8], epsilon[8]}
-    int64_t *orow = reinterpret_cast<int64_t *>(ce + p.n_ks1 * 32);        // [OT][2 register blocks][2 halves][8]: output row, 0 = none
+    int64_t *orow = reinterpret_cast<int64_t *>(ce + p.n_ks1 * 32);        // [OT][2 register blocks][2 halves][8]: output row (the sink where none)
     int64_t *rsrc = orow + OT * 32;                                        // residual `before` row (a readable dummy where none)
-    int64_t *rout = rsrc + OT * 32;                                        // residual `after` row, 0 = none
+    int64_t *rout = rsrc + OT * 32;                                        // residual `after` row (the sink where none)
     const uint32_t lds0 = (uint32_t)(uintptr_t)(lds_char *)smem;
 
     const int tid = threadIdx.x, lane = tid & 63, half = lane >> 5, col = lane & 31;
@@ -169,14 +181,15 @@ __global__ __launch_bounds__(256, 1) void mlp3_kernel(const Mlp3Launch p)
         const int t = i >> 5, rb = (i >> 4) & 1, hf = (i >> 3) & 1, jj = i & 7;
         const int f = 32 * t + rho3(8 * rb + jj) + 4 * hf;
         const int of = p.ofeat[f], rs = p.ores[f];
-        orow[i] = of < 0 ? 0 : reinterpret_cast<int64_t>(p.out[of >> 20]) + (int64_t)(of & 0xFFFFF) * p.out_fs[of >> 20] * 4;
+        const int64_t sink = reinterpret_cast<int64_t>(p.sink);
+        orow[i] = of < 0 ? sink : reinterpret_cast<int64_t>(p.out[of >> 20]) + (int64_t)(of & 0xFFFFF) * p.out_fs[of >> 20] * 4;
         if (of >= 0 && rs >= 0) {
             const int feat = of & 0xFFFFF;
             rsrc[i] = reinterpret_cast<int64_t>(p.src[rs & 0xFF]) + (int64_t)feat * p.src_fs[rs & 0xFF] * 4;
             rout[i] = reinterpret_cast<int64_t>(p.out[rs >> 8]) + (int64_t)feat * p.out_fs[rs >> 8] * 4;
         } else {
             rsrc[i] = reinterpret_cast<int64_t>(p.src[0]);
-            rout[i] = 0;
+            rout[i] = sink;
         }
     }
     __syncthreads();
@@ -200,24 +213,43 @@ __global__ __launch_bounds__(256, 1) void mlp3_kernel(const Mlp3Launch p)
                                                      goff + i * 4096, 0, 0);
     };
     // request the chunk two k-steps ahead of k-step g; returns whether it is a hidden-type chunk (its load count)
-    auto request_ahead = [&](int g) -> bool {
-        int g2 = g + 2;
-        if (g2 >= G) g2 -= G;
-        const bool is_h = g2 < n_hid_chunks;
-        if (is_h)
-            dma(std::integral_constant<int, PER_H>{}, g2, b2);
-        else
-            dma(std::integral_constant<int, PER_O>{}, g2, b2);
-        return is_h;
+    // KIND 0 / 1: the caller knows it is a hidden-type / an output-type chunk of this tile; 2: decided here.  (Where the
+    // compiler has loads of its own in flight -- layer 1, the residual rows -- the chunk loads must not sit in a branch: its
+    // wait counts drop them at the join, and every wait it then places also waits for the loads just issued.)
+    auto request_ahead = [&](int g, auto kind_c) -> bool {
+        constexpr int KIND = decltype(kind_c)::value;
+        if constexpr (KIND == 0) {
+            dma(std::integral_constant<int, PER_H>{}, g + 2, b2);
+            return true;
+        } else if constexpr (KIND == 1) {
+            dma(std::integral_constant<int, PER_O>{}, g + 2, b2);
+            return false;
+        } else {
+            int g2 = g + 2;
+            if (g2 >= G) g2 -= G;
+            const bool is_h = g2 < n_hid_chunks;
+            if (is_h)
+                dma(std::integral_constant<int, PER_H>{}, g2, b2);
+            else
+                dma(std::integral_constant<int, PER_O>{}, g2, b2);
+            return is_h;
+        }
     };
     // end of a k-step: this wave's share of chunk g + 1 has landed when at most the loads issued after it are in flight
     // (EXTRA other loads + the chunk requested in this k-step); then the barrier, and the buffers rotate
     auto fence = [&](auto extra_c, bool ahead_is_h) {
         constexpr int EXTRA = decltype(extra_c)::value;
+#ifdef MLP3_EXP_NOBARRIER
+        if (ahead_is_h)
+            asm volatile("s_waitcnt vmcnt(%0)" ::"n"(EXTRA + PER_H) : "memory");
+        else
+            asm volatile("s_waitcnt vmcnt(%0)" ::"n"(EXTRA + PER_O) : "memory");
+#else
         if (ahead_is_h)
             asm volatile("s_waitcnt vmcnt(%0)\n\ts_barrier" ::"n"(EXTRA + PER_H) : "memory");
         else
             asm volatile("s_waitcnt vmcnt(%0)\n\ts_barrier" ::"n"(EXTRA + PER_O) : "memory");
+#endif
         const uint32_t t_ = b0;
         b0 = b1;
         b1 = b2;
@@ -236,32 +268,41 @@ __global__ __launch_bounds__(256, 1) void mlp3_kernel(const Mlp3Launch p)
         dma(std::integral_constant<int, PER_O>{}, 1, b1);
     asm volatile("s_waitcnt vmcnt(0)\n\ts_barrier" ::: "memory");
 
+#ifdef MLP3_STAMPS
+    unsigned long long st_acc[8] = {0, 0, 0, 0, 0, 0, 0, 0}, st_t0 = 0;
+#define STAMP3_BEGIN() st_t0 = __builtin_readcyclecounter()
+#define STAMP3_END(i)                                               \
+    {                                                               \
+        const unsigned long long t_ = __builtin_readcyclecounter(); \
+        st_acc[i] += t_ - st_t0;                                    \
+        st_t0 = t_;                                                 \
+    }
+#else
+#define STAMP3_BEGIN() ((void)0)
+#define STAMP3_END(i) ((void)0)
+#endif
     for (int64_t tile = blockIdx.x; tile < p.n_tiles; tile += gridDim.x) {
+        STAMP3_BEGIN();
         const int64_t n = tile * 128 + wave * 32 + col;
         const bool valid = n < p.n_samples;
         const uint32_t nb = (uint32_t)((valid ? n : p.n_samples - 1) * 4);  // byte offset of this lane's sample inside a row
         int g = 0;
         // ================= layer 1 =================
         // x of k-step ks: 8 buffer loads (rows 8 half + j of the k-step's 16), requested two k-steps ahead
-        auto load_x = [&](int ks, float (&x)[8]) {
-            const XStep s = p.xk[ks];
-            const uint32_t fs4 = __builtin_amdgcn_readfirstlane(s.fs4), nrec = __builtin_amdgcn_readfirstlane(s.nrec);
-            const uint32_t voff = nb + (half ? 8u * fs4 : 0u);
+        auto load_x = [&](const XStep &s, float (&x)[8]) {
+            const uint32_t voff = nb + (half ? 8u * s.fs4 : 0u);
 #pragma unroll
             for (int j = 0; j < 8; ++j) {
                 // (the scalar offset of a buffer load is not bounds-checked: row j gets its own resource, all scalar arithmetic)
-                const uint32_t skip = j * fs4;
-                const uint64_t row = s.base + skip;
-                const uint64_t row_u = ((uint64_t)(uint32_t)__builtin_amdgcn_readfirstlane((uint32_t)(row >> 32)) << 32) |
-                                       (uint32_t)__builtin_amdgcn_readfirstlane((uint32_t)row);
-                const uint32_t left = __builtin_amdgcn_readfirstlane(nrec > skip ? nrec - skip : 0u);
-                const __amdgpu_buffer_rsrc_t r = __builtin_amdgcn_make_buffer_rsrc(reinterpret_cast<void *>(row_u), 0, left, 0x00020000);
+                const int left = (int)s.rows - j;
+                const __amdgpu_buffer_rsrc_t r = __builtin_amdgcn_make_buffer_rsrc(reinterpret_cast<void *>(s.base + (uint64_t)(j * s.fs4)), 0,
+                                                                                   (left > 0 ? left : 0) * s.fs4, 0x00020000);
                 x[j] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(r, voff, 0, 0));
             }
         };
-        // normalise (log / centre) and split; `t` = the k-step's table row {centre[8], epsilon[8]} of this half
-        auto transform = [&](int ks, const float (&xr)[8], const f32x4 (&t)[4]) -> B3 {
-            float x[8];
+        auto xstep = [&](int ks) { return p.xk[ks < p.n_ks1 ? ks : p.n_ks1 - 1]; };   // (past the end: the last k-step's rows again)
+        // normalise (log / centre); `t` = the k-step's table row {centre[8], epsilon[8]} of this half
+        auto normalise = [&](int ks, const float (&xr)[8], const f32x4 (&t)[4], float (&x)[8]) {
             if (ks < p.n_log_ks) {
 #pragma unroll
                 for (int j = 0; j < 8; ++j) {
@@ -273,37 +314,50 @@ __global__ __launch_bounds__(256, 1) void mlp3_kernel(const Mlp3Launch p)
 #pragma unroll
                 for (int j = 0; j < 8; ++j) x[j] = xr[j] - t[j >> 2][j & 3];
             }
-            return split3(x);
         };
         f32x16 h[kHT];
-        float xa[8], xb[8];
-        f32x4 tn[4], tnn[4];
-        load_x(0, xa);
-        load_x(p.n_ks1 > 1 ? 1 : 0, xb);
-        lds_read64_sync(ce_lane, tn[0], tn[1], tn[2], tn[3]);
-        B3 b = transform(0, xa, tn);
-        lds_read64_sync(ce_lane + (p.n_ks1 > 1 ? 128 : 0), tn[0], tn[1], tn[2], tn[3]);
-#pragma unroll
-        for (int j = 0; j < 8; ++j) xa[j] = xb[j];
-        // k-step ks: request x of ks + 2 and the chunk of g + 2, normalise / split x of ks + 1 (table row read during ks - 1),
-        // the MFMAs (their block also reads the table row of ks + 2)
-        auto layer1_step = [&](auto first_c, int ks) __attribute__((always_inline)) {
-            const int ks2 = ks + 2 < p.n_ks1 ? ks + 2 : p.n_ks1 - 1;   // (the last two k-steps reload the last rows: the load count stays static)
-            load_x(ks2, xb);
-            const bool ah = request_ahead(g);
+        float xA[8], xB[8], xn[8];
+        f32x4 tA[4], tB[4];
+        load_x(xstep(0), xA);
+        load_x(xstep(1), xB);
+        XStep xs = xstep(2);   // (fetched one k-step before its loads are issued)
+        lds_read64_sync(ce_lane, tA[0], tA[1], tA[2], tA[3]);
+        normalise(0, xA, tA, xn);
+        B3 b = split3(xn);
+        lds_read64_sync(ce_lane + (p.n_ks1 > 1 ? 128 : 0), tB[0], tB[1], tB[2], tB[3]);
+        // k-step ks.  On entry: `b` = its operand; x_in / t_in = the loaded rows and table row of ks + 1; x_out / t_out are
+        // free.  It normalises x of ks + 1 (loaded a k-step ago) -- the split into pieces happens inside the MFMA block --, then
+        // requests x of ks + 2 into x_out and the chunk of g + 2; the block also reads the table row of ks + 2 into t_out.
+        // (The arithmetic comes first: the compiler's waits for the x loads do not count the chunk loads, so anything it waits
+        // for after this k-step's requests would wait for these requests too.)
+        auto layer1_step = [&](auto first_c, auto kind_c, int ks, float (&x_in)[8], f32x4 (&t_in)[4], float (&x_out)[8], f32x4 (&t_out)[4])
+                               __attribute__((always_inline)) {
+            const int ks2 = ks + 2 < p.n_ks1 ? ks + 2 : p.n_ks1 - 1;   // (the last two k-steps re-read the last rows: the load count stays static)
+            normalise(ks + 1 < p.n_ks1 ? ks + 1 : ks, x_in, t_in, xn);
+            load_x(xs, x_out);
+            xs = xstep(ks + 3);
+            const bool ah = request_ahead(g, kind_c);
             B3 bn;
-            if (ks + 1 < p.n_ks1) bn = transform(ks + 1, xa, tn);
-            kstep_asm_8_tab<decltype(first_c)::value>(h, a_lane + b0, b, ce_lane + ks2 * 128, tnn[0], tnn[1], tnn[2], tnn[3]);
+            kstep_asm_8_tab_split<decltype(first_c)::value>(h, a_lane + b0, b, ce_lane + ks2 * 128, t_out[0], t_out[1], t_out[2], t_out[3], xn, bn);
             fence(std::integral_constant<int, 8>{}, ah);
             b = bn;
-#pragma unroll
-            for (int j = 0; j < 8; ++j) xa[j] = xb[j];
-#pragma unroll
-            for (int q = 0; q < 4; ++q) tn[q] = tnn[q];
             ++g;
         };
-        layer1_step(std::true_type{}, 0);
-        for (int ks = 1; ks < p.n_ks1; ++ks) layer1_step(std::false_type{}, ks);
+        STAMP3_END(0);
+        auto layer1 = [&](auto kind_c) __attribute__((always_inline)) {
+            layer1_step(std::true_type{}, kind_c, 0, xB, tB, xA, tA);
+            int ks = 1;
+            for (; ks + 1 < p.n_ks1; ks += 2) {
+                layer1_step(std::false_type{}, kind_c, ks, xA, tA, xB, tB);
+                layer1_step(std::false_type{}, kind_c, ks + 1, xB, tB, xA, tA);
+            }
+            if (ks < p.n_ks1) layer1_step(std::false_type{}, kind_c, ks, xA, tA, xB, tB);
+        };
+        if (p.n_hidden >= 2)
+            layer1(std::integral_constant<int, 0>{});   // (every chunk two k-steps ahead of layer 1 is hidden-type)
+        else
+            layer1(std::integral_constant<int, 2>{});
+        STAMP3_END(1);
         asm volatile("s_nop 15\n\ts_nop 7");   // (the last MFMAs' results, before anything the compiler schedules reads them)
         // bias + ReLU (bias rows: four tiles per LDS round trip)
         auto bias_relu = [&](f32x16 (&dst)[kHT], const f32x16 (&raw)[kHT], int layer) {
@@ -322,11 +376,15 @@ __global__ __launch_bounds__(256, 1) void mlp3_kernel(const Mlp3Launch p)
             });
         };
         bias_relu(h, h, 0);
-        auto b_of = [&](const f32x16 (&hh)[kHT], auto ks_c) -> B3 {
+        STAMP3_END(2);
+        auto x_of = [&](const f32x16 (&hh)[kHT], auto ks_c, float (&x)[8]) {
             constexpr int KS = decltype(ks_c)::value;
-            float x[8];
 #pragma unroll
             for (int j = 0; j < 8; ++j) x[j] = hh[KS / 2][(KS % 2) * 8 + j];
+        };
+        auto b_of = [&](const f32x16 (&hh)[kHT], auto ks_c) -> B3 {
+            float x[8];
+            x_of(hh, ks_c, x);
             return split3(x);
         };
         // ================= hidden -> hidden =================
@@ -335,16 +393,23 @@ __global__ __launch_bounds__(256, 1) void mlp3_kernel(const Mlp3Launch p)
             b = b_of(h, std::integral_constant<int, 0>{});
             static_for<16>([&](auto ks_c) {
                 constexpr int KS = decltype(ks_c)::value;
-                const bool ah = request_ahead(g);
-                B3 bn;
-                if constexpr (KS + 1 < 16) bn = b_of(h, std::integral_constant<int, (KS + 1 < 16 ? KS + 1 : 0)>{});
-                kstep_mfma<kHT, KS == 0>(h2, a_lane + b0, b);
-                fence(std::integral_constant<int, 0>{}, ah);
-                if constexpr (KS + 1 < 16) b = bn;
+                const bool ah = request_ahead(g, std::integral_constant<int, (KS < 14 ? 0 : 2)>{});
+                if constexpr (KS + 1 < 16) {
+                    B3 bn;
+                    x_of(h, std::integral_constant<int, (KS + 1 < 16 ? KS + 1 : 0)>{}, xn);
+                    kstep_mfma_split<kHT, KS == 0>(h2, a_lane + b0, b, xn, bn);
+                    fence(std::integral_constant<int, 0>{}, ah);
+                    b = bn;
+                } else {
+                    kstep_mfma<kHT, KS == 0>(h2, a_lane + b0, b);
+                    fence(std::integral_constant<int, 0>{}, ah);
+                }
                 ++g;
             });
             asm volatile("s_nop 15\n\ts_nop 7");
+            STAMP3_END(3);
             bias_relu(h, h2, l);
+            STAMP3_END(2);
         }
         // ================= hidden -> outputs =================
         f32x16 y[OT];
@@ -368,15 +433,21 @@ __global__ __launch_bounds__(256, 1) void mlp3_kernel(const Mlp3Launch p)
             constexpr int KS = decltype(ks_c)::value;
             if constexpr (RES && KS / 2 < NPRE)   // (the h registers of k-step KS are free: KS + 1's operand was split a k-step ago)
                 load_before(std::integral_constant<int, KS / 2>{}, std::integral_constant<int, KS % 2>{}, &before[KS / 2 < NPRE ? KS / 2 : 0][(KS % 2) * 8]);
-            const bool ah = request_ahead(g);
-            B3 bn;
-            if constexpr (KS + 1 < 16) bn = b_of(h, std::integral_constant<int, (KS + 1 < 16 ? KS + 1 : 0)>{});
-            kstep_mfma<OT, KS == 0>(y, a_lane + b0, b);
-            fence(std::integral_constant<int, (RES && KS / 2 < NPRE) ? 8 : 0>{}, ah);
-            if constexpr (KS + 1 < 16) b = bn;
+            const bool ah = request_ahead(g, std::integral_constant<int, (KS < 14 ? 1 : 2)>{});
+            if constexpr (KS + 1 < 16) {
+                B3 bn;
+                x_of(h, std::integral_constant<int, (KS + 1 < 16 ? KS + 1 : 0)>{}, xn);
+                kstep_mfma_split<OT, KS == 0>(y, a_lane + b0, b, xn, bn);
+                fence(std::integral_constant<int, (RES && KS / 2 < NPRE) ? 8 : 0>{}, ah);
+                b = bn;
+            } else {
+                kstep_mfma<OT, KS == 0>(y, a_lane + b0, b);
+                fence(std::integral_constant<int, (RES && KS / 2 < NPRE) ? 8 : 0>{}, ah);
+            }
             ++g;
         });
         asm volatile("s_nop 15\n\ts_nop 7");
+        STAMP3_END(4);
         // ================= epilogue: bias, direct stores (a row of a wave = 32 samples = 128 bytes) =================
         auto rows_of = [&](const int64_t *table, int t, int rb, int64_t (&rows)[8]) {
             const int64_t *q = table + ((t * 2 + rb) * 2 + half) * 8;
@@ -394,13 +465,14 @@ __global__ __launch_bounds__(256, 1) void mlp3_kernel(const Mlp3Launch p)
 #pragma unroll
                 for (int jj = 0; jj < 8; ++jj) {
                     const float v = y[T][rb * 8 + jj] + bo[rb * 8 + jj];
-                    if (valid && ro[jj]) *reinterpret_cast<float *>(ro[jj] + nb64) = v;
-                    if (RES)
-                        if (valid && ra[jj]) *reinterpret_cast<float *>(ra[jj] + nb64) = bef[rb * 8 + jj] + v;
+                    *reinterpret_cast<float *>(ro[jj] + nb64) = v;
+                    if (RES) *reinterpret_cast<float *>(ra[jj] + nb64) = bef[rb * 8 + jj] + v;
                 }
             }
         };
-        if constexpr (RES) {
+        if (!valid) {
+            // (lanes past the last sample store nothing; they took part in everything above with the last sample's inputs)
+        } else if constexpr (RES) {
             float later[(OT > NPRE ? OT - NPRE : 1)][16];
             static_for<NPRE>([&](auto t_c) {
                 constexpr int T = decltype(t_c)::value;
@@ -417,9 +489,16 @@ __global__ __launch_bounds__(256, 1) void mlp3_kernel(const Mlp3Launch p)
         } else {
             static_for<OT>([&](auto t_c) { finish_tile(t_c, nullptr); });
         }
+        STAMP3_END(5);
     }
     // (chunks requested for a tile this workgroup does not have are still in flight towards its LDS)
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+#ifdef MLP3_STAMPS
+    if (p.stamps && lane == 0) {
+        unsigned long long *o = p.stamps + ((size_t)blockIdx.x * 4 + wave) * 8;
+        for (int i = 0; i < 8; ++i) o[i] = st_acc[i];
+    }
+#endif
 }
 
 inline unsigned short bf16_rne(float x)
@@ -449,6 +528,8 @@ struct fv3hip_mlp3 {
     int64_t flops = 0;
     void *d_w = nullptr, *d_bias = nullptr, *d_center = nullptr, *d_eps = nullptr, *d_ofeat = nullptr, *d_ores = nullptr;
     size_t lds_bytes = 0, w_bytes = 0;
+    void *d_sink = nullptr;
+    int64_t sink_samples = 0;
     // per layer-1 k-step: the source it reads, its first feature row there and how many real rows follow (<= 16)
     std::vector<int> ks_src, ks_feat0, ks_rows;
 };
@@ -465,11 +546,17 @@ int upload3(const std::vector<T> &v, void **dptr)
 }
 }  // namespace
 
+#ifdef MLP3_STAMPS
+static unsigned long long *g_mlp3_stamps = nullptr;
+extern "C" void fv3hip_diag_set_mlp3_stamps(void *p) { g_mlp3_stamps = static_cast<unsigned long long *>(p); }
+#endif
+
 extern "C" int fv3hip_mlp3_destroy(fv3hip_mlp3_t m)
 {
     if (!m) return FV3HIP_OK;
     for (void *q : {m->d_w, m->d_bias, m->d_center, m->d_eps, m->d_ofeat, m->d_ores})
         if (q) hipFree(q);
+    if (m->d_sink) hipFree(m->d_sink);
     delete m;
     return FV3HIP_OK;
 }
@@ -661,7 +748,18 @@ extern "C" int fv3hip_mlp3_predict(fv3hip_mlp3_t m, const void *const *sources, 
     lp.bias = static_cast<const float *>(m->d_bias);
     lp.center = static_cast<const float *>(m->d_center);
     lp.eps = static_cast<const float *>(m->d_eps);
+    if (n_samples > m->sink_samples) {   // (grow-only; a first call or a larger batch than any before)
+        if (m->d_sink) FV3HIP_CHECK_HIP(hipFree(m->d_sink));
+        m->d_sink = nullptr;
+        m->sink_samples = 0;
+        FV3HIP_CHECK_HIP(hipMalloc(&m->d_sink, (size_t)n_samples * 4));
+        m->sink_samples = n_samples;
+    }
+    lp.sink = static_cast<float *>(m->d_sink);
     lp.w_bytes = (uint32_t)m->w_bytes;
+#ifdef MLP3_STAMPS
+    lp.stamps = g_mlp3_stamps;
+#endif
     for (int ks = 0; ks < m->n_ks1; ++ks) {
         const int sidx = m->ks_src[ks];
         const int64_t fs4 = src_feat_stride[sidx] * 4;
@@ -670,7 +768,7 @@ extern "C" int fv3hip_mlp3_predict(fv3hip_mlp3_t m, const void *const *sources, 
             return fail(FV3HIP_EUNSUPPORTED, "the split-bf16 kernel addresses 16 feature rows with 32-bit offsets (feature stride %lld too large)",
                         (long long)src_feat_stride[sidx]);
         lp.xk[ks].base = reinterpret_cast<uint64_t>(sources[sidx]) + (uint64_t)m->ks_feat0[ks] * (uint64_t)fs4;
-        lp.xk[ks].nrec = (uint32_t)(m->ks_rows[ks] * fs4);
+        lp.xk[ks].rows = (uint32_t)m->ks_rows[ks];
         lp.xk[ks].fs4 = (uint32_t)fs4;
     }
     lp.ofeat = static_cast<const int *>(m->d_ofeat);
