@@ -15,26 +15,44 @@ import os
 PRODUCTS = [(1, "bm"), (0, "bl"), (2, "bh"), (0, "bm"), (1, "bh"), (0, "bh")]  # (weight piece, activation piece)
 
 
-def split_text(emit):
+def split_lines():
     """x = hi + mid + lo in bf16 (round to nearest; the residuals are exact in fp32) for the 8 values of the NEXT k-step:
-    11 VALU instructions per pair.  They sit behind the first LDS requests of the block, whose latency (the four waves ask
-    at once, right after the barrier) they cover."""
+    11 VALU instructions per pair of values."""
+    out = []
     for i in range(4):
         a, b = f"%[xn{2 * i}]", f"%[xn{2 * i + 1}]"
-        emit(f"v_cvt_pk_bf16_f32 %[nh{i}], {a}, {b}")
-        emit(f"v_lshlrev_b32 %[u0], 16, %[nh{i}]")
-        emit(f"v_and_b32 %[u1], 0xffff0000, %[nh{i}]")
-        emit(f"v_sub_f32 %[r0], {a}, %[u0]")
-        emit(f"v_sub_f32 %[r1], {b}, %[u1]")
-        emit(f"v_cvt_pk_bf16_f32 %[nm{i}], %[r0], %[r1]")
-        emit(f"v_lshlrev_b32 %[u0], 16, %[nm{i}]")
-        emit(f"v_and_b32 %[u1], 0xffff0000, %[nm{i}]")
-        emit("v_sub_f32 %[r0], %[r0], %[u0]")
-        emit("v_sub_f32 %[r1], %[r1], %[u1]")
-        emit(f"v_cvt_pk_bf16_f32 %[nl{i}], %[r0], %[r1]")
+        out += [
+            f"v_cvt_pk_bf16_f32 %[nh{i}], {a}, {b}",
+            f"v_lshlrev_b32 %[u0], 16, %[nh{i}]",
+            f"v_and_b32 %[u1], 0xffff0000, %[nh{i}]",
+            f"v_sub_f32 %[r0], {a}, %[u0]",
+            f"v_sub_f32 %[r1], {b}, %[u1]",
+            f"v_cvt_pk_bf16_f32 %[nm{i}], %[r0], %[r1]",
+            f"v_lshlrev_b32 %[u0], 16, %[nm{i}]",
+            f"v_and_b32 %[u1], 0xffff0000, %[nm{i}]",
+            "v_sub_f32 %[r0], %[r0], %[u0]",
+            "v_sub_f32 %[r1], %[r1], %[u1]",
+            f"v_cvt_pk_bf16_f32 %[nl{i}], %[r0], %[r1]",
+        ]
+    return out
 
 
-def block(nt, first, tab, split):
+def dma_lines(per):
+    """`per` buffer_load_dwordx4 ... lds of this wave (1 KB each, 4 KB apart in the chunk and in LDS); M0 = LDS address.
+    (An instruction sits between every M0 write and the load that uses it.)"""
+    out = ["s_mov_b32 m0, %[dl]"]
+    for i in range(per):
+        out.append("s_nop 0" if i == 0 else "s_add_u32 %[dg], %[dg], 0x1000")
+        out.append("buffer_load_dwordx4 %[dv], %[dr], %[dg] offen lds")
+        if i + 1 < per:
+            out.append("s_add_u32 m0, m0, 0x1000")
+    return out
+
+
+def block(nt, first, tab, split, per):
+    """The instruction list of one k-step.  Measured on gfx950 (scratch/mfma): beside a pair of 32x32x16 bf16 MFMAs (64
+    cycles of matrix pipe) about four VALU instructions issue for free, so the side work -- the chunk request (`per` loads
+    when > 0) and the activation split -- is spread over the MFMA stream, at most two instructions behind each MFMA."""
     lines = []
     emit = lines.append
     pairs = [(2 * p, 2 * p + 1 if 2 * p + 1 < nt else None) for p in range((nt + 1) // 2)]
@@ -51,13 +69,12 @@ def block(nt, first, tab, split):
                 n += 1
         return n
 
+    side = (dma_lines(per) if per else []) + (split_lines() if split else [])
     if tab:  # the centre / epsilon rows of a later layer-1 k-step ride along (they land before the first A operands)
         for i in range(4):
             emit(f"ds_read_b128 %[x{i}], %[tb] offset:{16 * i}")
     request(0)
     pending1 = request(1) if len(pairs) > 1 else 0
-    if split:
-        split_text(emit)
     for p, (t0, t1) in enumerate(pairs):
         s = p & 1
         if p == 0:
@@ -72,16 +89,23 @@ def block(nt, first, tab, split):
                     continue
                 c = "0" if (first and i == 0) else f"%[c{t}]"
                 emit(f"v_mfma_f32_32x32x16_bf16 %[c{t}], %[t{s}{tt}{q}], %[{b}], {c}")
+                for _ in range(2):
+                    if side:
+                        emit(side.pop(0))
+    for x in side:
+        emit(x)
     return "\\n\\t".join(lines)
 
 
-def function(nt, tab, split):
-    name = f"kstep_asm_{nt}" + ("_tab" if tab else "") + ("_split" if split else "")
+def function(nt, tab, split, per):
+    name = f"kstep_asm_{nt}" + ("_tab" if tab else "") + ("_split" if split else "") + (f"_dma{per}" if per else "")
     args = f"f32x16 (&c)[{nt}], uint32_t ab, const B3 &b"
     if tab:
         args += ", uint32_t tb, f32x4 &x0, f32x4 &x1, f32x4 &x2, f32x4 &x3"
     if split:
         args += ", const float (&xn)[8], B3 &bn"
+    if per:
+        args += ", i32x4 dr, uint32_t dg, uint32_t dl, uint32_t dv"
     temps = [f"t{s}{tt}{q}" for s in range(2) for tt in range(2) for q in range(3)]
     out = [f"template <bool FIRST>\n__device__ __forceinline__ void {name}({args})\n{{"]
     out.append("    f32x4 " + ", ".join(temps) + ";")
@@ -99,10 +123,15 @@ def function(nt, tab, split):
             outs += [f'[n{w}{i}] "=&v"(n{w}{i})' for w in "hml" for i in range(4)]
             outs += [f'[{t}] "=&v"({t})' for t in ("u0", "u1", "r0", "r1")]
             ins += [f'[xn{i}] "v"(xn[{i}])' for i in range(8)]
-        out.append(f'        asm volatile("{block(nt, first, tab, split)}"')
+        clob = '"memory"'
+        if per:
+            outs += ['[dg] "+s"(dg)']
+            ins += ['[dr] "s"(dr)', '[dl] "s"(dl)', '[dv] "v"(dv)']
+            clob += ', "m0", "scc"'
+        out.append(f'        asm volatile("{block(nt, first, tab, split, per)}"')
         out.append("                     : " + ", ".join(outs))
         out.append("                     : " + ", ".join(ins))
-        out.append('                     : "memory");')
+        out.append(f"                     : {clob});")
         out.append("    }")
     if split:
         for w, field in (("h", "hi"), ("m", "mid"), ("l", "lo")):
@@ -114,9 +143,15 @@ def function(nt, tab, split):
 def main():
     here = os.path.dirname(os.path.abspath(__file__))
     parts = ["// GENERATED by gen/mlp3_kstep.py -- do not edit; see the generator for the schedule.\n"]
-    for nt, tab in ((8, False), (8, True), (13, False), (5, False), (3, False)):
+    # (tiles, with the layer-1 table row, chunk loads inside: 6 = a hidden-type chunk, 10 / 4 / 3 = the output-type chunk of
+    # 13 / 5 / 3 tiles, 0 = requested by the caller)
+    per_o = {13: 10, 5: 4, 3: 3}
+    shapes = [(8, False, 0), (8, False, 6), (8, True, 0), (8, True, 6)]
+    for nt in (13, 5, 3):
+        shapes += [(nt, False, 0), (nt, False, per_o[nt])]
+    for nt, tab, per in shapes:
         for split in (False, True):
-            parts.append(function(nt, tab, split))
+            parts.append(function(nt, tab, split, per))
     with open(os.path.join(here, "..", "mlp3_kstep.inc"), "w") as f:
         f.write("\n".join(parts))
 

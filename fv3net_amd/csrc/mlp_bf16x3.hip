@@ -35,7 +35,10 @@ typedef float f32x16 __attribute__((ext_vector_type(16)));
 typedef float f32x4 __attribute__((ext_vector_type(4)));
 typedef float f32x2 __attribute__((ext_vector_type(2)));
 typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
+typedef int i32x4 __attribute__((ext_vector_type(4)));
 typedef __attribute__((address_space(3))) char lds_char;
+typedef __attribute__((address_space(1))) float global_float;   // (row addresses come out of tables: say that they are global, or
+                                                                // the accesses become FLAT ones, which also count as LDS traffic)
 
 constexpr int kHT = 8;          // hidden feature tiles (width 256)
 constexpr int kMaxSrc = 16;
@@ -94,6 +97,28 @@ __device__ __forceinline__ void lds_read64_sync(uint32_t addr, f32x4 &a, f32x4 &
                  : "v"(addr)
                  : "memory");
 }
+// two rows of 64 bytes, 128 bytes apart (the two register blocks of a tile in a row table)
+__device__ __forceinline__ void lds_read2x64_sync(uint32_t addr, f32x4 (&r)[8])
+{
+    asm volatile("ds_read_b128 %0, %8\n\tds_read_b128 %1, %8 offset:16\n\tds_read_b128 %2, %8 offset:32\n\tds_read_b128 %3, %8 offset:48\n\t"
+                 "ds_read_b128 %4, %8 offset:128\n\tds_read_b128 %5, %8 offset:144\n\tds_read_b128 %6, %8 offset:160\n\tds_read_b128 %7, %8 offset:176\n\t"
+                 "s_waitcnt lgkmcnt(0)"
+                 : "=&v"(r[0]), "=&v"(r[1]), "=&v"(r[2]), "=&v"(r[3]), "=&v"(r[4]), "=&v"(r[5]), "=&v"(r[6]), "=&v"(r[7])
+                 : "v"(addr)
+                 : "memory");
+}
+// a tile's bias row (64 bytes) and its two rows of one / two row tables, one LDS round trip
+__device__ __forceinline__ void lds_tile_tables_sync(uint32_t bias, uint32_t rows0, f32x4 (&bq)[4], f32x4 (&r0)[8])
+{
+    asm volatile("ds_read_b128 %0, %12\n\tds_read_b128 %1, %12 offset:16\n\tds_read_b128 %2, %12 offset:32\n\tds_read_b128 %3, %12 offset:48\n\t"
+                 "ds_read_b128 %4, %13\n\tds_read_b128 %5, %13 offset:16\n\tds_read_b128 %6, %13 offset:32\n\tds_read_b128 %7, %13 offset:48\n\t"
+                 "ds_read_b128 %8, %13 offset:128\n\tds_read_b128 %9, %13 offset:144\n\tds_read_b128 %10, %13 offset:160\n\tds_read_b128 %11, %13 offset:176\n\t"
+                 "s_waitcnt lgkmcnt(0)"
+                 : "=&v"(bq[0]), "=&v"(bq[1]), "=&v"(bq[2]), "=&v"(bq[3]), "=&v"(r0[0]), "=&v"(r0[1]), "=&v"(r0[2]), "=&v"(r0[3]), "=&v"(r0[4]),
+                   "=&v"(r0[5]), "=&v"(r0[6]), "=&v"(r0[7])
+                 : "v"(bias), "v"(rows0)
+                 : "memory");
+}
 // 4 rows of 64 bytes, 128 bytes apart (the bias rows of four feature tiles)
 __device__ __forceinline__ void lds_read4x64_sync(uint32_t addr, f32x4 (&r)[4][4])
 {
@@ -132,23 +157,31 @@ __device__ __forceinline__ B3 split3(const float (&x)[8])
 // FIRST: the layer's first k-step (the accumulators start at 0, whatever they held).
 #include "mlp3_kstep.inc"
 
-template <int NT, bool FIRST>
-__device__ __forceinline__ void kstep_mfma(f32x16 (&acc)[NT], uint32_t abase, const B3 &b)
+// The chunk request of a k-step when it is made inside the block (`kstep_asm_*_dma*`): buffer resource of the weight
+// stream, this wave's byte offset in it, this wave's LDS byte address, this lane's 16 bytes.
+struct Dma {
+    i32x4 rsrc;
+    uint32_t goff, lds, voff;
+};
+
+// One k-step on NT tiles.  FIRST: the layer's first (accumulators start at 0).  SPLIT: also split `xn`, the next k-step's
+// activations, into `bn`.  INSIDE: the chunk two k-steps ahead is requested inside the block (`d`), else the caller did.
+template <int NT, bool FIRST, bool SPLIT, bool INSIDE>
+__device__ __forceinline__ void kstep_mfma(f32x16 (&acc)[NT], uint32_t ab, const B3 &b, const float (&xn)[8], B3 &bn, const Dma &d)
 {
     static_assert(NT == 8 || NT == 13 || NT == 5 || NT == 3, "k-step shapes generated: 8, 13, 5, 3 tiles");
-    if constexpr (NT == 8) kstep_asm_8<FIRST>(acc, abase, b);
-    if constexpr (NT == 13) kstep_asm_13<FIRST>(acc, abase, b);
-    if constexpr (NT == 5) kstep_asm_5<FIRST>(acc, abase, b);
-    if constexpr (NT == 3) kstep_asm_3<FIRST>(acc, abase, b);
-}
-// ... and the split of the next k-step's activations `xn` into `bn` inside the block
-template <int NT, bool FIRST>
-__device__ __forceinline__ void kstep_mfma_split(f32x16 (&acc)[NT], uint32_t abase, const B3 &b, const float (&xn)[8], B3 &bn)
-{
-    if constexpr (NT == 8) kstep_asm_8_split<FIRST>(acc, abase, b, xn, bn);
-    if constexpr (NT == 13) kstep_asm_13_split<FIRST>(acc, abase, b, xn, bn);
-    if constexpr (NT == 5) kstep_asm_5_split<FIRST>(acc, abase, b, xn, bn);
-    if constexpr (NT == 3) kstep_asm_3_split<FIRST>(acc, abase, b, xn, bn);
+#define KSTEP3_(NTV, PERV)                                                                                                  \
+    if constexpr (NT == NTV) {                                                                                              \
+        if constexpr (SPLIT && INSIDE) kstep_asm_##NTV##_split_dma##PERV<FIRST>(acc, ab, b, xn, bn, d.rsrc, d.goff, d.lds, d.voff); \
+        if constexpr (SPLIT && !INSIDE) kstep_asm_##NTV##_split<FIRST>(acc, ab, b, xn, bn);                                 \
+        if constexpr (!SPLIT && INSIDE) kstep_asm_##NTV##_dma##PERV<FIRST>(acc, ab, b, d.rsrc, d.goff, d.lds, d.voff);      \
+        if constexpr (!SPLIT && !INSIDE) kstep_asm_##NTV<FIRST>(acc, ab, b);                                                \
+    }
+    KSTEP3_(8, 6)
+    KSTEP3_(13, 10)
+    KSTEP3_(5, 4)
+    KSTEP3_(3, 3)
+#undef KSTEP3_
 }
 
 template <int OT, bool RES>  // output tiles held in registers at once (13 for the Zhao-Carr emulator); residual outputs
@@ -159,7 +192,6 @@ __global__ __launch_bounds__(256, 1) void mlp3_kernel(const Mlp3Launch p)
     constexpr int CH_MAX = (CH_H > CH_O) ? CH_H : CH_O;
     constexpr int PER_H = CH_H / 256, PER_O = CH_O / 256;     // buffer_load ... lds instructions per wave and chunk
     constexpr uint32_t CHB = CH_MAX * 16;
-    constexpr int NPRE = OT < 8 ? OT : 8;                     // output tiles whose `before` rows are prefetched in the output phase
     extern __shared__ __attribute__((aligned(16))) char smem[];
     // LDS: [3 chunk buffers][bias table][centre][eps][row tables of the epilogue]
     float *bias_t = reinterpret_cast<float *>(smem + 3 * (size_t)CHB);     // [(n_hidden 8 + OT)][2][16]
@@ -216,14 +248,18 @@ __global__ __launch_bounds__(256, 1) void mlp3_kernel(const Mlp3Launch p)
     // KIND 0 / 1: the caller knows it is a hidden-type / an output-type chunk of this tile; 2: decided here.  (Where the
     // compiler has loads of its own in flight -- layer 1, the residual rows -- the chunk loads must not sit in a branch: its
     // wait counts drop them at the join, and every wait it then places also waits for the loads just issued.)
+    const uint32_t w_lo = __builtin_amdgcn_readfirstlane((uint32_t)reinterpret_cast<uintptr_t>(p.w)),
+                   w_hi = __builtin_amdgcn_readfirstlane((uint32_t)(reinterpret_cast<uintptr_t>(p.w) >> 32));
+    Dma dsc;
+    dsc.rsrc = i32x4{(int)w_lo, (int)(w_hi & 0xFFFFu), (int)p.w_bytes, 0x00020000};
+    dsc.voff = lane * 16;
+    dsc.goff = dsc.lds = 0;
     auto request_ahead = [&](int g, auto kind_c) -> bool {
         constexpr int KIND = decltype(kind_c)::value;
-        if constexpr (KIND == 0) {
-            dma(std::integral_constant<int, PER_H>{}, g + 2, b2);
-            return true;
-        } else if constexpr (KIND == 1) {
-            dma(std::integral_constant<int, PER_O>{}, g + 2, b2);
-            return false;
+        if constexpr (KIND == 0 || KIND == 1) {   // (made inside the k-step's block: only say where from and where to)
+            dsc.goff = __builtin_amdgcn_readfirstlane(chunk_bytes(g + 2) + wave * 1024);
+            dsc.lds = __builtin_amdgcn_readfirstlane(lds0 + b2 + wave * 1024);
+            return KIND == 0;
         } else {
             int g2 = g + 2;
             if (g2 >= G) g2 -= G;
@@ -338,7 +374,11 @@ __global__ __launch_bounds__(256, 1) void mlp3_kernel(const Mlp3Launch p)
             xs = xstep(ks + 3);
             const bool ah = request_ahead(g, kind_c);
             B3 bn;
-            kstep_asm_8_tab_split<decltype(first_c)::value>(h, a_lane + b0, b, ce_lane + ks2 * 128, t_out[0], t_out[1], t_out[2], t_out[3], xn, bn);
+            if constexpr (decltype(kind_c)::value == 0)
+                kstep_asm_8_tab_split_dma6<decltype(first_c)::value>(h, a_lane + b0, b, ce_lane + ks2 * 128, t_out[0], t_out[1], t_out[2], t_out[3], xn,
+                                                                     bn, dsc.rsrc, dsc.goff, dsc.lds, dsc.voff);
+            else
+                kstep_asm_8_tab_split<decltype(first_c)::value>(h, a_lane + b0, b, ce_lane + ks2 * 128, t_out[0], t_out[1], t_out[2], t_out[3], xn, bn);
             fence(std::integral_constant<int, 8>{}, ah);
             b = bn;
             ++g;
@@ -394,16 +434,11 @@ __global__ __launch_bounds__(256, 1) void mlp3_kernel(const Mlp3Launch p)
             static_for<16>([&](auto ks_c) {
                 constexpr int KS = decltype(ks_c)::value;
                 const bool ah = request_ahead(g, std::integral_constant<int, (KS < 14 ? 0 : 2)>{});
-                if constexpr (KS + 1 < 16) {
-                    B3 bn;
-                    x_of(h, std::integral_constant<int, (KS + 1 < 16 ? KS + 1 : 0)>{}, xn);
-                    kstep_mfma_split<kHT, KS == 0>(h2, a_lane + b0, b, xn, bn);
-                    fence(std::integral_constant<int, 0>{}, ah);
-                    b = bn;
-                } else {
-                    kstep_mfma<kHT, KS == 0>(h2, a_lane + b0, b);
-                    fence(std::integral_constant<int, 0>{}, ah);
-                }
+                B3 bn;
+                if constexpr (KS + 1 < 16) x_of(h, std::integral_constant<int, (KS + 1 < 16 ? KS + 1 : 0)>{}, xn);
+                kstep_mfma<kHT, KS == 0, (KS + 1 < 16), (KS < 14)>(h2, a_lane + b0, b, xn, bn, dsc);
+                fence(std::integral_constant<int, 0>{}, ah);
+                if constexpr (KS + 1 < 16) b = bn;
                 ++g;
             });
             asm volatile("s_nop 15\n\ts_nop 7");
@@ -413,81 +448,61 @@ __global__ __launch_bounds__(256, 1) void mlp3_kernel(const Mlp3Launch p)
         }
         // ================= hidden -> outputs =================
         f32x16 y[OT];
-        float before[NPRE][16];
         b = b_of(h, std::integral_constant<int, 0>{});
         const int64_t nb64 = nb;
-        // the `before` rows of output tile T, register block RB (8 values): row table by hand-placed LDS reads
-        auto load_before = [&](auto t_c, auto rb_c, float *dst) {
-            constexpr int T = decltype(t_c)::value, RB = decltype(rb_c)::value;
-            const uint32_t ra = row_addr + OT * 256 + (T * 2 + RB) * 128;   // rsrc table
-            f32x4 rr[4];
-            lds_read64_sync(ra, rr[0], rr[1], rr[2], rr[3]);
-#pragma unroll
-            for (int jj = 0; jj < 8; ++jj) {
-                const f32x2 pr = {rr[jj >> 1][(jj & 1) * 2], rr[jj >> 1][(jj & 1) * 2 + 1]};
-                const int64_t row = __builtin_bit_cast(int64_t, pr);
-                dst[jj] = *reinterpret_cast<const float *>(row + nb64);
-            }
+        auto row_of = [](const f32x4 (&rr)[8], int r) -> int64_t {   // row r (0..15) of a tile out of its two table rows
+            const f32x2 pr = {rr[r >> 1][(r & 1) * 2], rr[r >> 1][(r & 1) * 2 + 1]};
+            return __builtin_bit_cast(int64_t, pr);
         };
+        // the row tables: 0 / 1 / 2 = output rows, `before` rows, `after` rows; a tile's two register blocks are 128 bytes apart
+        auto table_addr = [&](int table, int t) -> uint32_t { return row_addr + table * (OT * 256) + t * 256; };
+        auto load_before = [&](int t, float (&dst)[16]) {
+            f32x4 rr[8];
+            lds_read2x64_sync(table_addr(1, t), rr);
+#pragma unroll
+            for (int r = 0; r < 16; ++r) dst[r] = *reinterpret_cast<const global_float *>(row_of(rr, r) + nb64);
+        };
+        // `before` rows of the residual outputs: a rolling window of WIN tiles; the first WIN are requested during the last
+        // WIN k-steps of this layer (most hidden activations are dead by then), the others as the epilogue frees the window
+        constexpr int WIN = RES ? (OT < 5 ? OT : 5) : 1;
+        float before[WIN][16];
         static_for<16>([&](auto ks_c) {
             constexpr int KS = decltype(ks_c)::value;
-            if constexpr (RES && KS / 2 < NPRE)   // (the h registers of k-step KS are free: KS + 1's operand was split a k-step ago)
-                load_before(std::integral_constant<int, KS / 2>{}, std::integral_constant<int, KS % 2>{}, &before[KS / 2 < NPRE ? KS / 2 : 0][(KS % 2) * 8]);
+            constexpr bool PRE = RES && KS >= 16 - WIN;
+            if constexpr (PRE) load_before(KS - (16 - WIN), before[PRE ? KS - (16 - WIN) : 0]);
             const bool ah = request_ahead(g, std::integral_constant<int, (KS < 14 ? 1 : 2)>{});
-            if constexpr (KS + 1 < 16) {
-                B3 bn;
-                x_of(h, std::integral_constant<int, (KS + 1 < 16 ? KS + 1 : 0)>{}, xn);
-                kstep_mfma_split<OT, KS == 0>(y, a_lane + b0, b, xn, bn);
-                fence(std::integral_constant<int, (RES && KS / 2 < NPRE) ? 8 : 0>{}, ah);
-                b = bn;
-            } else {
-                kstep_mfma<OT, KS == 0>(y, a_lane + b0, b);
-                fence(std::integral_constant<int, (RES && KS / 2 < NPRE) ? 8 : 0>{}, ah);
-            }
+            B3 bn;
+            if constexpr (KS + 1 < 16) x_of(h, std::integral_constant<int, (KS + 1 < 16 ? KS + 1 : 0)>{}, xn);
+            kstep_mfma<OT, KS == 0, (KS + 1 < 16), (KS < 14)>(y, a_lane + b0, b, xn, bn, dsc);
+            fence(std::integral_constant<int, PRE ? 16 : 0>{}, ah);
+            if constexpr (KS + 1 < 16) b = bn;
             ++g;
         });
         asm volatile("s_nop 15\n\ts_nop 7");
         STAMP3_END(4);
         // ================= epilogue: bias, direct stores (a row of a wave = 32 samples = 128 bytes) =================
-        auto rows_of = [&](const int64_t *table, int t, int rb, int64_t (&rows)[8]) {
-            const int64_t *q = table + ((t * 2 + rb) * 2 + half) * 8;
-#pragma unroll
-            for (int jj = 0; jj < 8; ++jj) rows[jj] = q[jj];
-        };
-        auto finish_tile = [&](auto t_c, const float *bef) {
-            constexpr int T = decltype(t_c)::value;
-            const float *bo = bias_t + ((p.n_hidden * kHT + T) * 2 + half) * 16;
-#pragma unroll
-            for (int rb = 0; rb < 2; ++rb) {
-                int64_t ro[8], ra[8];
-                rows_of(orow, T, rb, ro);
-                if (RES) rows_of(rout, T, rb, ra);
-#pragma unroll
-                for (int jj = 0; jj < 8; ++jj) {
-                    const float v = y[T][rb * 8 + jj] + bo[rb * 8 + jj];
-                    *reinterpret_cast<float *>(ro[jj] + nb64) = v;
-                    if (RES) *reinterpret_cast<float *>(ra[jj] + nb64) = bef[rb * 8 + jj] + v;
-                }
-            }
-        };
-        if (!valid) {
-            // (lanes past the last sample store nothing; they took part in everything above with the last sample's inputs)
-        } else if constexpr (RES) {
-            float later[(OT > NPRE ? OT - NPRE : 1)][16];
-            static_for<NPRE>([&](auto t_c) {
+        // (the next tile's first chunks are in flight: row tables and biases by hand-placed LDS reads here too)
+        if (valid) {   // (lanes past the last sample store nothing; they took part in everything above with the last sample's inputs)
+            // the direct outputs: y + bias (kept in y for the residual outputs)
+            static_for<OT>([&](auto t_c) {
                 constexpr int T = decltype(t_c)::value;
-                finish_tile(t_c, before[T]);
-                if constexpr (T + NPRE < OT) {
-                    load_before(std::integral_constant<int, (T + NPRE < OT ? T + NPRE : 0)>{}, std::integral_constant<int, 0>{}, &later[T + NPRE < OT ? T : 0][0]);
-                    load_before(std::integral_constant<int, (T + NPRE < OT ? T + NPRE : 0)>{}, std::integral_constant<int, 1>{}, &later[T + NPRE < OT ? T : 0][8]);
+                f32x4 bq[4], rr[8];
+                lds_tile_tables_sync(bias_lane + (p.n_hidden * kHT + T) * 128, table_addr(0, T), bq, rr);
+#pragma unroll
+                for (int r = 0; r < 16; ++r) {
+                    y[T][r] += bq[r >> 2][r & 3];
+                    *reinterpret_cast<global_float *>(row_of(rr, r) + nb64) = y[T][r];
                 }
             });
-            static_for<(OT > NPRE ? OT - NPRE : 0)>([&](auto t_c) {
-                constexpr int T = decltype(t_c)::value;
-                finish_tile(std::integral_constant<int, T + NPRE>{}, later[T]);
-            });
-        } else {
-            static_for<OT>([&](auto t_c) { finish_tile(t_c, nullptr); });
+            if constexpr (RES)
+                static_for<OT>([&](auto t_c) {
+                    constexpr int T = decltype(t_c)::value;
+                    f32x4 rr[8];
+                    lds_read2x64_sync(table_addr(2, T), rr);
+#pragma unroll
+                    for (int r = 0; r < 16; ++r) *reinterpret_cast<global_float *>(row_of(rr, r) + nb64) = before[T % WIN][r] + y[T][r];
+                    if constexpr (T + WIN < OT) load_before(T + WIN, before[T % WIN]);
+                });
         }
         STAMP3_END(5);
     }
