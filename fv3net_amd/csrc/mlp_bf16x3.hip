@@ -9,16 +9,27 @@
 //
 // Same graph as mlp.hip (reference lines there): log / centre inputs (1/std folded into the layer-1 weights), Dense + ReLU
 // stack, output heads with scale / centre folded in, optional residual outputs `after = before + difference`.
-// Restrictions of this first version: hidden width 256, float32 sources and outputs that are sample-contiguous, every
-// log epsilon >= FLT_MIN (the fast log), no output limits / masks.  Anything else: FV3HIP_EUNSUPPORTED.
+// Restrictions: hidden width 256, float32 sources and outputs that are sample-contiguous, every log epsilon >= FLT_MIN (the
+// fast log), no output limits / masks, 3 / 5 / 13 output tiles of 32 features.  Anything else: FV3HIP_EUNSUPPORTED.
 //
 // Structure: a workgroup is 4 waves x 32 samples and walks 128-sample tiles persistently.  A layer is a sequence of k-steps
-// of 16 contraction indices; per k-step the wave holds its B operand (8 values per lane -> three bf16x8 vectors, split in
-// registers) and runs 6 MFMAs per 32-feature output tile; the A operands (the three pre-split weight pieces of the k-step,
-// [piece][tile][lane][8 bf16]) come from an LDS buffer the four waves share, double-buffered through registers from one
-// packed stream (L2-resident).  The accumulator layout of a layer (lane = sample, registers = features) is, by choice of
-// the k-slot -> feature map the host packs the weights with, exactly the B operand layout of the next layer's k-steps:
-// activations never leave registers.
+// of 16 contraction indices; per k-step the wave holds its B operand (8 activations per lane as three bf16x8 pieces) and runs
+// 6 MFMAs per 32-feature output tile; the A operands (the three pre-split weight pieces of the k-step, [piece][tile][lane]
+// [8 bf16], 24 KB for 8 tiles) are shared by the four waves through LDS.  The accumulator layout of a layer (lane = sample,
+// registers = features) is, by choice of the k-slot -> feature map the host packs the weights with, exactly the B operand
+// layout of the next layer's k-steps: activations never leave registers.
+//   * weight stream: one packed stream per tile (L2-resident, 2.1 MB for the Zhao-Carr network), chunk = one k-step, brought
+//     in by `buffer_load_dwordx4 ... lds` (no registers, no ds_write) into three LDS buffers, two k-steps ahead; one barrier
+//     per k-step.  The wait is an exact `s_waitcnt vmcnt(N)`: N = the loads issued after the chunk that must have landed.
+//   * a k-step is ONE inline-assembly block (generated: gen/mlp3_kstep.py -> mlp3_kstep.inc): LDS reads of the A operands one
+//     tile pair ahead of the MFMAs, and -- in the shadow of the MFMAs, measured free up to ~4 instructions per MFMA pair --
+//     the chunk request and the split of the NEXT k-step's activations into their pieces.
+//   * layer 1: a k-step = 16 consecutive feature rows of one input (inputs padded to 16), 8 bounds-checked buffer loads per
+//     lane two k-steps ahead; centre / epsilon rows ride along in the block's LDS reads.
+//   * epilogue: through a per-wave LDS patch to 16 bytes per lane where alignment allows (at most 63 memory operations of a
+//     wave can be in flight); the residual outputs' `before` rows in a rolling window of 5 tiles, the first 5 requested
+//     during the last k-steps of the output layer.
+// Diagnostics: -DMLP3_STAMPS accumulates cycle counts per phase (scratch/mlp3_stamps.py prints them).
 #include <cfloat>
 #include <cmath>
 #include <cstring>
@@ -119,6 +130,63 @@ __device__ __forceinline__ void lds_tile_tables_sync(uint32_t bias, uint32_t row
                  : "v"(bias), "v"(rows0)
                  : "memory");
 }
+// The 16-byte epilogue: a wave's 32 x 32 output tile goes through its own LDS patch ([feature][sample], rows of 36 floats) so
+// that a lane ends up with four consecutive samples of one feature.  Write: the lane's 16 values (features rho3(r) + 4 half
+// of its sample).  Read: features l / 8 + 8 i (i = 0..3), samples 4 (l % 8)..+3 -- together with the row addresses of those
+// features from a feature-ordered table (8 bytes per feature).
+constexpr int kPatchRow = 36 * 4;   // bytes
+#define PATCH_WRITES_                                                                                                          \
+    "ds_write_b32 %[pw], %[v0]\n\tds_write_b32 %[pw], %[v1] offset:144\n\tds_write_b32 %[pw], %[v2] offset:288\n\t"                \
+    "ds_write_b32 %[pw], %[v3] offset:432\n\tds_write_b32 %[pw], %[v4] offset:1152\n\tds_write_b32 %[pw], %[v5] offset:1296\n\t"   \
+    "ds_write_b32 %[pw], %[v6] offset:1440\n\tds_write_b32 %[pw], %[v7] offset:1584\n\tds_write_b32 %[pw], %[v8] offset:2304\n\t"  \
+    "ds_write_b32 %[pw], %[v9] offset:2448\n\tds_write_b32 %[pw], %[v10] offset:2592\n\tds_write_b32 %[pw], %[v11] offset:2736\n\t" \
+    "ds_write_b32 %[pw], %[v12] offset:3456\n\tds_write_b32 %[pw], %[v13] offset:3600\n\tds_write_b32 %[pw], %[v14] offset:3744\n\t" \
+    "ds_write_b32 %[pw], %[v15] offset:3888\n\t"                                                                                   \
+    "ds_read_b128 %[t0], %[pr]\n\tds_read_b128 %[t1], %[pr] offset:1152\n\tds_read_b128 %[t2], %[pr] offset:2304\n\t"              \
+    "ds_read_b128 %[t3], %[pr] offset:3456\n\t"                                                                                    \
+    "ds_read_b64 %[r0], %[ro]\n\tds_read_b64 %[r1], %[ro] offset:64\n\tds_read_b64 %[r2], %[ro] offset:128\n\tds_read_b64 %[r3], %[ro] offset:192\n\t" \
+    "ds_read_b32 %[b0], %[bo]\n\tds_read_b32 %[b1], %[bo] offset:32\n\tds_read_b32 %[b2], %[bo] offset:64\n\tds_read_b32 %[b3], %[bo] offset:96\n\t"
+#define PATCH_V_(v) "v"(v[0]), "v"(v[1]), "v"(v[2]), "v"(v[3]), "v"(v[4]), "v"(v[5]), "v"(v[6]), "v"(v[7]), "v"(v[8]), "v"(v[9]), "v"(v[10]), \
+                    "v"(v[11]), "v"(v[12]), "v"(v[13]), "v"(v[14]), "v"(v[15])
+// one LDS round trip per tile: write the lane's 16 values, read back the transposed tile (t), the output rows (r) and biases (b)
+// of its four features ...
+__device__ __forceinline__ void patch_exchange(uint32_t pw, uint32_t pr, uint32_t ro, uint32_t bo, const float (&v)[16], f32x4 (&t)[4], f32x2 (&r)[4],
+                                               float (&b)[4])
+{
+    asm volatile(PATCH_WRITES_ "s_waitcnt lgkmcnt(0)"
+                 : [t0] "=&v"(t[0]), [t1] "=&v"(t[1]), [t2] "=&v"(t[2]), [t3] "=&v"(t[3]), [r0] "=&v"(r[0]), [r1] "=&v"(r[1]), [r2] "=&v"(r[2]),
+                   [r3] "=&v"(r[3]), [b0] "=&v"(b[0]), [b1] "=&v"(b[1]), [b2] "=&v"(b[2]), [b3] "=&v"(b[3])
+                 : [pw] "v"(pw), [pr] "v"(pr), [ro] "v"(ro), [bo] "v"(bo), [v0] "v"(v[0]), [v1] "v"(v[1]), [v2] "v"(v[2]), [v3] "v"(v[3]),
+                   [v4] "v"(v[4]), [v5] "v"(v[5]), [v6] "v"(v[6]), [v7] "v"(v[7]), [v8] "v"(v[8]), [v9] "v"(v[9]), [v10] "v"(v[10]),
+                   [v11] "v"(v[11]), [v12] "v"(v[12]), [v13] "v"(v[13]), [v14] "v"(v[14]), [v15] "v"(v[15])
+                 : "memory");
+}
+// ... and, with residual outputs, the `after` rows of this tile (a) and the `before` rows of a later tile (n)
+__device__ __forceinline__ void patch_exchange_res(uint32_t pw, uint32_t pr, uint32_t ro, uint32_t bo, uint32_t ao, uint32_t no, const float (&v)[16],
+                                                   f32x4 (&t)[4], f32x2 (&r)[4], float (&b)[4], f32x2 (&a)[4], f32x2 (&n)[4])
+{
+    asm volatile(PATCH_WRITES_
+                 "ds_read_b64 %[a0], %[ao]\n\tds_read_b64 %[a1], %[ao] offset:64\n\tds_read_b64 %[a2], %[ao] offset:128\n\tds_read_b64 %[a3], %[ao] offset:192\n\t"
+                 "ds_read_b64 %[n0], %[no]\n\tds_read_b64 %[n1], %[no] offset:64\n\tds_read_b64 %[n2], %[no] offset:128\n\tds_read_b64 %[n3], %[no] offset:192\n\t"
+                 "s_waitcnt lgkmcnt(0)"
+                 : [t0] "=&v"(t[0]), [t1] "=&v"(t[1]), [t2] "=&v"(t[2]), [t3] "=&v"(t[3]), [r0] "=&v"(r[0]), [r1] "=&v"(r[1]), [r2] "=&v"(r[2]),
+                   [r3] "=&v"(r[3]), [b0] "=&v"(b[0]), [b1] "=&v"(b[1]), [b2] "=&v"(b[2]), [b3] "=&v"(b[3]), [a0] "=&v"(a[0]), [a1] "=&v"(a[1]),
+                   [a2] "=&v"(a[2]), [a3] "=&v"(a[3]), [n0] "=&v"(n[0]), [n1] "=&v"(n[1]), [n2] "=&v"(n[2]), [n3] "=&v"(n[3])
+                 : [pw] "v"(pw), [pr] "v"(pr), [ro] "v"(ro), [bo] "v"(bo), [ao] "v"(ao), [no] "v"(no), [v0] "v"(v[0]), [v1] "v"(v[1]), [v2] "v"(v[2]),
+                   [v3] "v"(v[3]), [v4] "v"(v[4]), [v5] "v"(v[5]), [v6] "v"(v[6]), [v7] "v"(v[7]), [v8] "v"(v[8]), [v9] "v"(v[9]), [v10] "v"(v[10]),
+                   [v11] "v"(v[11]), [v12] "v"(v[12]), [v13] "v"(v[13]), [v14] "v"(v[14]), [v15] "v"(v[15])
+                 : "memory");
+}
+#undef PATCH_V_
+__device__ __forceinline__ void rows_read(uint32_t rows, f32x2 (&r)[4])
+{
+    asm volatile("ds_read_b64 %0, %4\n\tds_read_b64 %1, %4 offset:64\n\tds_read_b64 %2, %4 offset:128\n\tds_read_b64 %3, %4 offset:192\n\t"
+                 "s_waitcnt lgkmcnt(0)"
+                 : "=&v"(r[0]), "=&v"(r[1]), "=&v"(r[2]), "=&v"(r[3])
+                 : "v"(rows)
+                 : "memory");
+}
+typedef __attribute__((address_space(1))) f32x4 global_f32x4;
 // 4 rows of 64 bytes, 128 bytes apart (the bias rows of four feature tiles)
 __device__ __forceinline__ void lds_read4x64_sync(uint32_t addr, f32x4 (&r)[4][4])
 {
@@ -184,7 +252,9 @@ __device__ __forceinline__ void kstep_mfma(f32x16 (&acc)[NT], uint32_t ab, const
 #undef KSTEP3_
 }
 
-template <int OT, bool RES>  // output tiles held in registers at once (13 for the Zhao-Carr emulator); residual outputs
+// OT: output tiles held in registers at once (13 for the Zhao-Carr emulator); RES: residual outputs; FAST: every output and
+// residual row is 16-byte aligned with a stride that is a multiple of 4 and n_samples % 4 == 0 (the 16-byte epilogue)
+template <int OT, bool RES, bool FAST>
 __global__ __launch_bounds__(256, 1) void mlp3_kernel(const Mlp3Launch p)
 {
     constexpr int CH_H = 3 * kHT * 64;                        // float4 per hidden-type chunk (24 KB)
@@ -196,7 +266,8 @@ __global__ __launch_bounds__(256, 1) void mlp3_kernel(const Mlp3Launch p)
     // LDS: [3 chunk buffers][bias table][centre][eps][row tables of the epilogue]
     float *bias_t = reinterpret_cast<float *>(smem + 3 * (size_t)CHB);     // [(n_hidden 8 + OT)][2][16]
     float *ce = bias_t + (p.n_hidden * kHT + OT) * 32;                     // [n_ks1][2 halves]{centre[8], epsilon[8]}
-    int64_t *orow = reinterpret_cast<int64_t *>(ce + p.n_ks1 * 32);        // [OT][2 register blocks][2 halves][8]: output row (the sink where none)
+    // row tables: [OT][2 register blocks][2 halves][8] (the order a lane holds them in) or, FAST, [OT * 32] by feature
+    int64_t *orow = reinterpret_cast<int64_t *>(ce + p.n_ks1 * 32);        // output row (the sink where none)
     int64_t *rsrc = orow + OT * 32;                                        // residual `before` row (a readable dummy where none)
     int64_t *rout = rsrc + OT * 32;                                        // residual `after` row (the sink where none)
     const uint32_t lds0 = (uint32_t)(uintptr_t)(lds_char *)smem;
@@ -211,7 +282,7 @@ __global__ __launch_bounds__(256, 1) void mlp3_kernel(const Mlp3Launch p)
     for (int i = tid; i < OT * 32; i += 256) {
         // table slot (t, rb, hf, jj) holds feature 32 t + rho3(8 rb + jj) + 4 hf
         const int t = i >> 5, rb = (i >> 4) & 1, hf = (i >> 3) & 1, jj = i & 7;
-        const int f = 32 * t + rho3(8 * rb + jj) + 4 * hf;
+        const int f = FAST ? i : 32 * t + rho3(8 * rb + jj) + 4 * hf;
         const int of = p.ofeat[f], rs = p.ores[f];
         const int64_t sink = reinterpret_cast<int64_t>(p.sink);
         orow[i] = of < 0 ? sink : reinterpret_cast<int64_t>(p.out[of >> 20]) + (int64_t)(of & 0xFFFFF) * p.out_fs[of >> 20] * 4;
@@ -222,6 +293,14 @@ __global__ __launch_bounds__(256, 1) void mlp3_kernel(const Mlp3Launch p)
         } else {
             rsrc[i] = reinterpret_cast<int64_t>(p.src[0]);
             rout[i] = sink;
+        }
+    }
+    if constexpr (FAST) {   // the output layer's biases once more, by feature (the transposed tile adds them after the exchange)
+        float *bias_f = reinterpret_cast<float *>(smem + 3 * (size_t)CHB + (p.n_hidden * kHT + OT) * 128 + p.n_ks1 * 128 + 3 * OT * 256 +
+                                                  4 * (32 * kPatchRow));
+        for (int i = tid; i < OT * 32; i += 256) {
+            const int t = i >> 5, fl = i & 31, hf = (fl >> 2) & 1, r = (fl & 3) + 4 * (fl >> 3);   // fl = rho3(r) + 4 hf
+            bias_f[i] = p.bias[((p.n_hidden * kHT + t) * 2 + hf) * 16 + r];
         }
     }
     __syncthreads();
@@ -275,17 +354,10 @@ __global__ __launch_bounds__(256, 1) void mlp3_kernel(const Mlp3Launch p)
     // (EXTRA other loads + the chunk requested in this k-step); then the barrier, and the buffers rotate
     auto fence = [&](auto extra_c, bool ahead_is_h) {
         constexpr int EXTRA = decltype(extra_c)::value;
-#ifdef MLP3_EXP_NOBARRIER
-        if (ahead_is_h)
-            asm volatile("s_waitcnt vmcnt(%0)" ::"n"(EXTRA + PER_H) : "memory");
-        else
-            asm volatile("s_waitcnt vmcnt(%0)" ::"n"(EXTRA + PER_O) : "memory");
-#else
         if (ahead_is_h)
             asm volatile("s_waitcnt vmcnt(%0)\n\ts_barrier" ::"n"(EXTRA + PER_H) : "memory");
         else
             asm volatile("s_waitcnt vmcnt(%0)\n\ts_barrier" ::"n"(EXTRA + PER_O) : "memory");
-#endif
         const uint32_t t_ = b0;
         b0 = b1;
         b1 = b2;
@@ -295,6 +367,11 @@ __global__ __launch_bounds__(256, 1) void mlp3_kernel(const Mlp3Launch p)
     const uint32_t bias_lane = lds0 + 3 * CHB + half * 64;                         // + tile * 128
     const uint32_t ce_lane = bias_lane + (p.n_hidden * kHT + OT) * 128;            // + ks * 128: {centre[8], epsilon[8]} of this half
     const uint32_t row_addr = ce_lane + p.n_ks1 * 128;                             // orow: + (t * 2 + rb) * 128
+    // FAST: this wave's transposition patch behind the tables, this lane's write / read positions in it, its table position
+    const uint32_t patch0 = lds0 + 3 * CHB + (p.n_hidden * kHT + OT) * 128 + p.n_ks1 * 128 + 3 * OT * 256 + wave * (32 * kPatchRow);
+    const uint32_t patch_w = patch0 + (4 * half) * kPatchRow + col * 4, patch_r = patch0 + (lane >> 3) * kPatchRow + (lane & 7) * 16;
+    const uint32_t rowsF = lds0 + 3 * CHB + (p.n_hidden * kHT + OT) * 128 + p.n_ks1 * 128 + (lane >> 3) * 8;   // + table * OT * 256 + t * 256
+    const uint32_t biasF = patch0 - wave * (32 * kPatchRow) + 4 * (32 * kPatchRow) + (lane >> 3) * 4;           // + t * 128: output biases by feature
 
     // the first two chunks of the first tile
     dma(std::integral_constant<int, PER_H>{}, 0, b0);   // (n_hid_chunks >= 1: chunk 0 is always hidden-type)
@@ -326,15 +403,12 @@ __global__ __launch_bounds__(256, 1) void mlp3_kernel(const Mlp3Launch p)
         // ================= layer 1 =================
         // x of k-step ks: 8 buffer loads (rows 8 half + j of the k-step's 16), requested two k-steps ahead
         auto load_x = [&](const XStep &s, float (&x)[8]) {
+            // one bounds-checked resource over the k-step's real rows; the row goes into the VECTOR offset (a scalar offset
+            // would not be bounds-checked): row 8 half + j of a k-step with fewer rows is out of range and reads 0
+            const __amdgpu_buffer_rsrc_t r = __builtin_amdgcn_make_buffer_rsrc(reinterpret_cast<void *>(s.base), 0, s.rows * s.fs4, 0x00020000);
             const uint32_t voff = nb + (half ? 8u * s.fs4 : 0u);
 #pragma unroll
-            for (int j = 0; j < 8; ++j) {
-                // (the scalar offset of a buffer load is not bounds-checked: row j gets its own resource, all scalar arithmetic)
-                const int left = (int)s.rows - j;
-                const __amdgpu_buffer_rsrc_t r = __builtin_amdgcn_make_buffer_rsrc(reinterpret_cast<void *>(s.base + (uint64_t)(j * s.fs4)), 0,
-                                                                                   (left > 0 ? left : 0) * s.fs4, 0x00020000);
-                x[j] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(r, voff, 0, 0));
-            }
+            for (int j = 0; j < 8; ++j) x[j] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(r, voff + j * s.fs4, 0, 0));
         };
         auto xstep = [&](int ks) { return p.xk[ks < p.n_ks1 ? ks : p.n_ks1 - 1]; };   // (past the end: the last k-step's rows again)
         // normalise (log / centre); `t` = the k-step's table row {centre[8], epsilon[8]} of this half
@@ -356,22 +430,22 @@ __global__ __launch_bounds__(256, 1) void mlp3_kernel(const Mlp3Launch p)
         f32x4 tA[4], tB[4];
         load_x(xstep(0), xA);
         load_x(xstep(1), xB);
-        XStep xs = xstep(2);   // (fetched one k-step before its loads are issued)
         lds_read64_sync(ce_lane, tA[0], tA[1], tA[2], tA[3]);
         normalise(0, xA, tA, xn);
         B3 b = split3(xn);
+        load_x(xstep(2), xA);
+        XStep xs = xstep(3);   // (fetched one k-step before its loads are issued)
         lds_read64_sync(ce_lane + (p.n_ks1 > 1 ? 128 : 0), tB[0], tB[1], tB[2], tB[3]);
-        // k-step ks.  On entry: `b` = its operand; x_in / t_in = the loaded rows and table row of ks + 1; x_out / t_out are
-        // free.  It normalises x of ks + 1 (loaded a k-step ago) -- the split into pieces happens inside the MFMA block --, then
-        // requests x of ks + 2 into x_out and the chunk of g + 2; the block also reads the table row of ks + 2 into t_out.
-        // (The arithmetic comes first: the compiler's waits for the x loads do not count the chunk loads, so anything it waits
-        // for after this k-step's requests would wait for these requests too.)
-        auto layer1_step = [&](auto first_c, auto kind_c, int ks, float (&x_in)[8], f32x4 (&t_in)[4], float (&x_out)[8], f32x4 (&t_out)[4])
+        // k-step ks.  On entry: `b` = its operand; x_in / t_in = the loaded rows and the table row of ks + 1 (the other x
+        // buffer holds the rows of ks + 2); t_out is free.  It normalises x of ks + 1 (requested two k-steps ago) -- the split
+        // into pieces happens inside the MFMA block, which also requests the chunk of g + 2 and reads the table row of ks + 2
+        // into t_out --, then requests x of ks + 3 into x_in.  The order matters: the compiler does not see the chunk loads of
+        // the block, so where it waits for "all but the last 8" of its own loads, the chunk loads behind them wait too; with
+        // the x loads AFTER the block, what it forces at the next normalise is the chunk requested a whole k-step earlier.
+        auto layer1_step = [&](auto first_c, auto kind_c, int ks, float (&x_in)[8], f32x4 (&t_in)[4], f32x4 (&t_out)[4])
                                __attribute__((always_inline)) {
-            const int ks2 = ks + 2 < p.n_ks1 ? ks + 2 : p.n_ks1 - 1;   // (the last two k-steps re-read the last rows: the load count stays static)
+            const int ks2 = ks + 2 < p.n_ks1 ? ks + 2 : p.n_ks1 - 1;   // (past the end: the last row again, unused)
             normalise(ks + 1 < p.n_ks1 ? ks + 1 : ks, x_in, t_in, xn);
-            load_x(xs, x_out);
-            xs = xstep(ks + 3);
             const bool ah = request_ahead(g, kind_c);
             B3 bn;
             if constexpr (decltype(kind_c)::value == 0)
@@ -379,19 +453,21 @@ __global__ __launch_bounds__(256, 1) void mlp3_kernel(const Mlp3Launch p)
                                                                      bn, dsc.rsrc, dsc.goff, dsc.lds, dsc.voff);
             else
                 kstep_asm_8_tab_split<decltype(first_c)::value>(h, a_lane + b0, b, ce_lane + ks2 * 128, t_out[0], t_out[1], t_out[2], t_out[3], xn, bn);
-            fence(std::integral_constant<int, 8>{}, ah);
+            load_x(xs, x_in);   // (past the end: the last k-step's rows again -- the load count stays static)
+            xs = xstep(ks + 4);
+            fence(std::integral_constant<int, 16>{}, ah);   // (behind the chunk of g + 1: the x loads of the last k-step and of this one)
             b = bn;
             ++g;
         };
         STAMP3_END(0);
         auto layer1 = [&](auto kind_c) __attribute__((always_inline)) {
-            layer1_step(std::true_type{}, kind_c, 0, xB, tB, xA, tA);
+            layer1_step(std::true_type{}, kind_c, 0, xB, tB, tA);
             int ks = 1;
             for (; ks + 1 < p.n_ks1; ks += 2) {
-                layer1_step(std::false_type{}, kind_c, ks, xA, tA, xB, tB);
-                layer1_step(std::false_type{}, kind_c, ks + 1, xB, tB, xA, tA);
+                layer1_step(std::false_type{}, kind_c, ks, xA, tA, tB);
+                layer1_step(std::false_type{}, kind_c, ks + 1, xB, tB, tA);
             }
-            if (ks < p.n_ks1) layer1_step(std::false_type{}, kind_c, ks, xA, tA, xB, tB);
+            if (ks < p.n_ks1) layer1_step(std::false_type{}, kind_c, ks, xA, tA, tB);
         };
         if (p.n_hidden >= 2)
             layer1(std::integral_constant<int, 0>{});   // (every chunk two k-steps ahead of layer 1 is hidden-type)
@@ -456,11 +532,26 @@ __global__ __launch_bounds__(256, 1) void mlp3_kernel(const Mlp3Launch p)
         };
         // the row tables: 0 / 1 / 2 = output rows, `before` rows, `after` rows; a tile's two register blocks are 128 bytes apart
         auto table_addr = [&](int table, int t) -> uint32_t { return row_addr + table * (OT * 256) + t * 256; };
+        // FAST: this lane's quad of samples (4 consecutive, all inside or all outside the batch) of the wave's 32
+        const int64_t q0 = tile * 128 + wave * 32 + (lane & 7) * 4;
+        const bool qvalid = q0 < p.n_samples;
+        const int64_t qb64 = (qvalid ? q0 : 0) * 4;
         auto load_before = [&](int t, float (&dst)[16]) {
-            f32x4 rr[8];
-            lds_read2x64_sync(table_addr(1, t), rr);
+            if constexpr (FAST) {
+                f32x2 rq[4];
+                rows_read(rowsF + OT * 256 + t * 256, rq);   // (the prefetch of the first window; later tiles get their rows from the exchange)
 #pragma unroll
-            for (int r = 0; r < 16; ++r) dst[r] = *reinterpret_cast<const global_float *>(row_of(rr, r) + nb64);
+                for (int i = 0; i < 4; ++i) {
+                    const f32x4 v = *reinterpret_cast<const global_f32x4 *>(__builtin_bit_cast(int64_t, rq[i]) + qb64);
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) dst[i * 4 + e] = v[e];
+                }
+            } else {
+                f32x4 rr[8];
+                lds_read2x64_sync(table_addr(1, t), rr);
+#pragma unroll
+                for (int r = 0; r < 16; ++r) dst[r] = *reinterpret_cast<const global_float *>(row_of(rr, r) + nb64);
+            }
         };
         // `before` rows of the residual outputs: a rolling window of WIN tiles; the first WIN are requested during the last
         // WIN k-steps of this layer (most hidden activations are dead by then), the others as the epilogue frees the window
@@ -474,15 +565,57 @@ __global__ __launch_bounds__(256, 1) void mlp3_kernel(const Mlp3Launch p)
             B3 bn;
             if constexpr (KS + 1 < 16) x_of(h, std::integral_constant<int, (KS + 1 < 16 ? KS + 1 : 0)>{}, xn);
             kstep_mfma<OT, KS == 0, (KS + 1 < 16), (KS < 14)>(y, a_lane + b0, b, xn, bn, dsc);
-            fence(std::integral_constant<int, PRE ? 16 : 0>{}, ah);
+            fence(std::integral_constant<int, PRE ? (FAST ? 4 : 16) : 0>{}, ah);
             if constexpr (KS + 1 < 16) b = bn;
             ++g;
         });
         asm volatile("s_nop 15\n\ts_nop 7");
         STAMP3_END(4);
-        // ================= epilogue: bias, direct stores (a row of a wave = 32 samples = 128 bytes) =================
+        // ================= epilogue: bias, stores =================
         // (the next tile's first chunks are in flight: row tables and biases by hand-placed LDS reads here too)
-        if (valid) {   // (lanes past the last sample store nothing; they took part in everything above with the last sample's inputs)
+        if constexpr (FAST) {
+            // 16 bytes per lane: at most 63 memory operations of a wave are in flight, so the 4-byte epilogue below is bound by
+            // their latency; here a tile is 4 stores (+ 4 loads and 4 stores for a residual output) instead of 16 (+ 32)
+            static_for<OT>([&](auto t_c) {
+                constexpr int T = decltype(t_c)::value;
+                constexpr int TN = T + WIN < OT ? T + WIN : T;   // the tile whose `before` rows this step requests
+                float v[16], bf[4];
+#pragma unroll
+                for (int r = 0; r < 16; ++r) v[r] = y[T][r];
+                f32x4 tq[4];
+                f32x2 rq[4], ra[4], rn[4];
+                if constexpr (RES)
+                    patch_exchange_res(patch_w, patch_r, rowsF + T * 256, biasF + T * 128, rowsF + 2 * OT * 256 + T * 256, rowsF + OT * 256 + TN * 256, v, tq,
+                                       rq, bf, ra, rn);
+                else
+                    patch_exchange(patch_w, patch_r, rowsF + T * 256, biasF + T * 128, v, tq, rq, bf);
+#pragma unroll
+                for (int i = 0; i < 4; ++i)
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) tq[i][e] += bf[i];
+                if (qvalid) {
+#pragma unroll
+                    for (int i = 0; i < 4; ++i) *reinterpret_cast<global_f32x4 *>(__builtin_bit_cast(int64_t, rq[i]) + qb64) = tq[i];
+                    if constexpr (RES) {
+#pragma unroll
+                        for (int i = 0; i < 4; ++i) {
+                            f32x4 o;
+#pragma unroll
+                            for (int e = 0; e < 4; ++e) o[e] = before[T % WIN][i * 4 + e] + tq[i][e];
+                            *reinterpret_cast<global_f32x4 *>(__builtin_bit_cast(int64_t, ra[i]) + qb64) = o;
+                        }
+                    }
+                }
+                if constexpr (RES && T + WIN < OT) {
+#pragma unroll
+                    for (int i = 0; i < 4; ++i) {
+                        const f32x4 nv = *reinterpret_cast<const global_f32x4 *>(__builtin_bit_cast(int64_t, rn[i]) + qb64);
+#pragma unroll
+                        for (int e = 0; e < 4; ++e) before[T % WIN][i * 4 + e] = nv[e];
+                    }
+                }
+            });
+        } else if (valid) {   // (lanes past the last sample store nothing; they took part in everything above with the last sample's inputs)
             // the direct outputs: y + bias (kept in y for the residual outputs)
             static_for<OT>([&](auto t_c) {
                 constexpr int T = decltype(t_c)::value;
@@ -542,11 +675,11 @@ struct fv3hip_mlp3 {
     int n_sources = 0, n_outputs = 0, n_residual = 0, n_hidden = 0, n_ks1 = 0, n_log_ks = 0, n_ot = 0;
     int64_t flops = 0;
     void *d_w = nullptr, *d_bias = nullptr, *d_center = nullptr, *d_eps = nullptr, *d_ofeat = nullptr, *d_ores = nullptr;
-    size_t lds_bytes = 0, w_bytes = 0;
+    size_t lds_bytes = 0, lds_fast = 0, w_bytes = 0;
     void *d_sink = nullptr;
     int64_t sink_samples = 0;
     // per layer-1 k-step: the source it reads, its first feature row there and how many real rows follow (<= 16)
-    std::vector<int> ks_src, ks_feat0, ks_rows;
+    std::vector<int> ks_src, ks_feat0, ks_rows, res_source;
 };
 
 namespace {
@@ -642,6 +775,7 @@ extern "C" int fv3hip_mlp3_create(const fv3hip_mlp_desc_t *d, fv3hip_mlp3_t *out
         m->ks_src = ks_src;
         m->ks_feat0 = ks_feat0;
         m->ks_rows = ks_rows;
+        for (int r = 0; r < d->n_residual; ++r) m->res_source.push_back(d->res_source[r]);
         *out = m;
     }
     fv3hip_mlp3 *m = *out;
@@ -727,6 +861,7 @@ extern "C" int fv3hip_mlp3_create(const fv3hip_mlp_desc_t *d, fv3hip_mlp3_t *out
     const size_t ch_max = (size_t)((CH_H > CH_O) ? CH_H : CH_O);
     m->w_bytes = w.size() * sizeof(unsigned short);
     m->lds_bytes = 3 * ch_max * 16 + (size_t)(d->n_hidden * kHT + n_ot) * 128 + (size_t)slots.size() * 8 + (size_t)n_ot * 32 * 24;
+    m->lds_fast = m->lds_bytes + 4 * 32 * 36 * 4 + (size_t)n_ot * 128;   // + a transposition patch per wave and the output biases by feature
     if (m->lds_bytes > 160 * 1024) {
         fv3hip_mlp3_destroy(m);
         *out = nullptr;
@@ -797,13 +932,24 @@ extern "C" int fv3hip_mlp3_predict(fv3hip_mlp3_t m, const void *const *sources, 
     lp.n_tiles = ceil_div(n_samples, 128);
     const int grid = (int)(lp.n_tiles < m->n_cu ? lp.n_tiles : m->n_cu);
     hipStream_t st = as_stream(stream);
+    // the 16-byte epilogue: every output row and every residual `before` row 16-byte aligned at every feature, whole quads
+    bool fast = n_samples % 4 == 0 && m->lds_fast <= 160 * 1024;
+    for (int j = 0; j < m->n_outputs + m->n_residual && fast; ++j)
+        fast = reinterpret_cast<uintptr_t>(outputs[j]) % 16 == 0 && out_feat_stride[j] % 4 == 0;
+    for (int r = 0; r < m->n_residual && fast; ++r)
+        fast = reinterpret_cast<uintptr_t>(sources[m->res_source[r]]) % 16 == 0 && src_feat_stride[m->res_source[r]] % 4 == 0;
+    const size_t lds = fast ? m->lds_fast : m->lds_bytes;
 #define LAUNCH3_(OT)                                                                                                     \
-    if (m->n_residual) LAUNCH3R_(OT, true) else LAUNCH3R_(OT, false)
-#define LAUNCH3R_(OT, RES)                                                                                               \
+    if (m->n_residual) {                                                                                                 \
+        if (fast) LAUNCH3R_(OT, true, true) else LAUNCH3R_(OT, true, false)                                              \
+    } else {                                                                                                             \
+        if (fast) LAUNCH3R_(OT, false, true) else LAUNCH3R_(OT, false, false)                                            \
+    }
+#define LAUNCH3R_(OT, RES, FAST)                                                                                         \
     {                                                                                                                    \
-        auto kern = mlp3_kernel<OT, RES>;                                                                                \
-        FV3HIP_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)m->lds_bytes)); \
-        hipLaunchKernelGGL(kern, dim3(grid), dim3(256), m->lds_bytes, st, lp);                                           \
+        auto kern = mlp3_kernel<OT, RES, FAST>;                                                                          \
+        FV3HIP_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds)); \
+        hipLaunchKernelGGL(kern, dim3(grid), dim3(256), lds, st, lp);                                                    \
     }
     if (m->n_ot == 13) LAUNCH3_(13) else if (m->n_ot == 5) LAUNCH3_(5) else LAUNCH3_(3)
 #undef LAUNCH3_

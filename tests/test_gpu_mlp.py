@@ -289,11 +289,14 @@ def test_split_bf16_kernel_against_oracle(device, n, residuals):
         assert err <= 4 * np.max(np.abs(cpu32[name] - t)) + 2e-7 * scale, (name, err, np.max(np.abs(cpu32[name] - t)))
 
 
-@pytest.mark.parametrize("n_hidden,out_feats,n", [(1, {"y": 79, "z": 5}, 1000), (3, {"a": 1, "b": 79, "c": 79}, 257), (2, {"y": 70}, 128)])
-def test_split_bf16_kernel_other_architectures(device, n_hidden, out_feats, n):
+@pytest.mark.parametrize("n_hidden,out_feats,n,pad", [(1, {"y": 79, "z": 5}, 1000, 37), (3, {"a": 1, "b": 79, "c": 79}, 257, 37),
+                                                      (2, {"y": 70}, 128, 37), (1, {"y": 79, "z": 5}, 1000, 0),
+                                                      (3, {"a": 1, "b": 79, "c": 79}, 260, 0)])
+def test_split_bf16_kernel_other_architectures(device, n_hidden, out_feats, n, pad):
     """The split-bf16 kernel on other shapes: 1 and 3 hidden layers (the weight stream's chunk types change at different
     k-steps), 3 / 5 output tiles, inputs that are feature ranges of a shared source (start > 0), log inputs, a residual
-    output, sample counts that end inside a 128-sample tile and feature rows longer than the sample count (strided views)."""
+    output, sample counts that end inside a 128-sample tile and feature rows longer than the sample count (strided views:
+    the 4-byte epilogue; pad = 0: aligned rows, the 16-byte epilogue)."""
     from fv3net_amd.mlp import MlpModelSplitBf16
 
     rng = np.random.default_rng(5)
@@ -302,7 +305,7 @@ def test_split_bf16_kernel_other_architectures(device, n_hidden, out_feats, n):
     nres = out_feats[res_out]
     in_feats = {"T": ("state", nres, 0), "q": ("state", 30, nres), "logq": ("state", 30, nres), "ps": ("ps", 1, 0)}
     spec = _random_spec(rng, in_feats, 256, n_hidden, out_feats, log_inputs=("logq",), residual={"T_after": ("state", res_out)})
-    pad = 37  # (rows are views into wider arrays: feature stride > n)
+    # (pad > 0: rows are views into wider arrays, feature stride > n)
     state = np.concatenate([rng.normal(0, 1, (nres, n + pad)), 10 ** rng.uniform(-8, -2, (30, n + pad))]).astype(np.float32)
     ps = rng.normal(0, 1, (1, n + pad)).astype(np.float32)
     dev_src = {"state": torch.from_numpy(state).to(device)[:, :n], "ps": torch.from_numpy(ps).to(device)[:, :n]}
