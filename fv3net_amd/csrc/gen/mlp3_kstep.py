@@ -50,7 +50,7 @@ def dma_lines(per):
 
 
 def block(nt, first, tab, split, per):
-    """The instruction list of one k-step.  Measured on gfx950 (scratch/mfma): beside a pair of 32x32x16 bf16 MFMAs (64
+    """The instruction list of one k-step.  Measured on gfx950 (benchmarks/mfma_ubench): beside a pair of 32x32x16 bf16 MFMAs (64
     cycles of matrix pipe) about four VALU instructions issue for free, so the side work -- the chunk request (`per` loads
     when > 0) and the activation split -- is spread over the MFMA stream, at most two instructions behind each MFMA."""
     lines = []

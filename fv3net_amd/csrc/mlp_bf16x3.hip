@@ -29,7 +29,7 @@
 //   * epilogue: through a per-wave LDS patch to 16 bytes per lane where alignment allows (at most 63 memory operations of a
 //     wave can be in flight); the residual outputs' `before` rows in a rolling window of 5 tiles, the first 5 requested
 //     during the last k-steps of the output layer.
-// Diagnostics: -DMLP3_STAMPS accumulates cycle counts per phase (scratch/mlp3_stamps.py prints them).
+// Diagnostics: -DMLP3_STAMPS accumulates cycle counts per phase (benchmarks/mlp3_stamps prints them).
 #include <cfloat>
 #include <cmath>
 #include <cstring>
