@@ -518,10 +518,15 @@ def test_offline_training_produces_a_working_predictor():
 # ------------------------------------------------------------------------------------------------
 # emulation hook
 # ------------------------------------------------------------------------------------------------
-def test_microphysics_hook_with_hip_emulator(tmp_path):
+@pytest.mark.parametrize("arithmetic", ["fp32", "split-bf16"])
+def test_microphysics_hook_with_hip_emulator(tmp_path, arithmetic, monkeypatch):
+    """The hook call as the Fortran model makes it, on the product kernel and on the opt-in split-bf16 arithmetic (selected by
+    the environment, as a run would)."""
     import bench
     from fv3net_amd.emulation import HipEmulator, MicrophysicsHook
     from fv3net_amd.mlp import ResidualSpec
+
+    monkeypatch.setenv(HipEmulator.ARITHMETIC_ENV, arithmetic)
 
     spec = bench.zc_spec(0)
     spec.residuals = [
@@ -531,6 +536,7 @@ def test_microphysics_hook_with_hip_emulator(tmp_path):
     emulator = HipEmulator(spec)
     emulator.dump(str(tmp_path / "emu"))
     emulator = HipEmulator.load(str(tmp_path / "emu"))
+    assert emulator.arithmetic == arithmetic
     n = 2304  # one C384 rank with a 48 x 48 subdomain
     src_sf = bench.zc_inputs_numpy(np.random.default_rng(5), n)
     # the Fortran state: [feature, sample] float64 arrays plus scalars
@@ -548,6 +554,7 @@ def test_microphysics_hook_with_hip_emulator(tmp_path):
         assert got.shape == (want.shape[1], n) and got.flags.c_contiguous  # [feature, sample]
         assert np.max(np.abs(got.T - want)) <= 1e-5 * np.max(np.abs(want)), name
     assert state["rank"] == 3
+    assert type(emulator.model).__name__ == ("MlpModelSplitBf16" if arithmetic == "split-bf16" else "MlpModel")
 
 
 def test_microphysics_hook_keeps_masks_on_the_device(tmp_path):
