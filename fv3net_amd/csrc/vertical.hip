@@ -59,6 +59,34 @@ __global__ void mask_weights_kernel(const Tw *__restrict__ w, const Tp *__restri
     }
 }
 
+// The same on a (column chunk, batch x level) grid: no 64-bit division per element, 4 columns per thread (n_inner % 4 == 0).
+template <typename Tw, typename Tp>
+__global__ __launch_bounds__(256) void mask_weights_rows_kernel(const Tw *__restrict__ w, const Tp *__restrict__ pc, const Tp *__restrict__ pf,
+                                                                Tw *__restrict__ out, int nz, int64_t n_inner, int64_t w_repeat, int cmp_levels,
+                                                                int cmp_offset)
+{
+    const int64_t c = ((int64_t)blockIdx.x * 256 + threadIdx.x) * 4;
+    if (c >= n_inner) return;
+    const int64_t b = blockIdx.y / nz;
+    const int k = (int)(blockIdx.y - b * nz);
+    const Tp *lv = pc + (b * cmp_levels + (k + cmp_offset)) * n_inner + c;
+    const Tp *ps = pf + (b * (nz + 1) + nz) * n_inner + c;
+    const Tw *wr = w + (b / w_repeat) * n_inner + c;
+    Tw *o = out + (b * nz + k) * n_inner + c;
+    Tp l4[4], p4[4];
+    Tw w4[4], r4[4];
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        l4[i] = lv[i];
+        p4[i] = ps[i];
+        w4[i] = wr[i];
+    }
+#pragma unroll
+    for (int i = 0; i < 4; ++i) r4[i] = (l4[i] < p4[i]) ? w4[i] : (Tw)0;
+#pragma unroll
+    for (int i = 0; i < 4; ++i) o[i] = r4[i];
+}
+
 // pressure_at_midpoint_log: delp / diff(log(p_interface)), sequential down the column
 template <typename T>
 __global__ void pressure_at_midpoint_log_kernel(const T *__restrict__ delp, T *__restrict__ out,
@@ -1148,11 +1176,20 @@ extern "C" int fv3hip_mask_weights(const void *weights, int w_dtype, const void 
     int64_t blocks = ceil_div(total, 256);
     if (blocks > 256 * 64) blocks = 256 * 64;
     hipStream_t st = as_stream(stream);
+    // rows grid (no per-element division) when a row is whole quads of 16-byte aligned columns and the grid fits
+    const bool rows = n_inner % 4 == 0 && n_batch * nz <= 65535 && reinterpret_cast<uintptr_t>(weights) % 16 == 0 &&
+                      reinterpret_cast<uintptr_t>(p_cmp) % 16 == 0 && reinterpret_cast<uintptr_t>(p_fine) % 16 == 0 &&
+                      reinterpret_cast<uintptr_t>(out) % 16 == 0;
 #define LAUNCH_(TW, TP)                                                                              \
-    hipLaunchKernelGGL((mask_weights_kernel<TW, TP>), dim3((unsigned)blocks), dim3(256), 0, st,      \
-                       static_cast<const TW *>(weights), static_cast<const TP *>(p_cmp),             \
-                       static_cast<const TP *>(p_fine), static_cast<TW *>(out), n_batch, nz, n_inner, \
-                       w_repeat, cmp_levels, cmp_offset)
+    if (rows)                                                                                        \
+        hipLaunchKernelGGL((mask_weights_rows_kernel<TW, TP>), dim3((unsigned)ceil_div(n_inner, 1024), (unsigned)(n_batch * nz)), dim3(256), 0, st, \
+                           static_cast<const TW *>(weights), static_cast<const TP *>(p_cmp), static_cast<const TP *>(p_fine),                      \
+                           static_cast<TW *>(out), nz, n_inner, w_repeat, cmp_levels, cmp_offset);                                                 \
+    else                                                                                             \
+        hipLaunchKernelGGL((mask_weights_kernel<TW, TP>), dim3((unsigned)blocks), dim3(256), 0, st,  \
+                           static_cast<const TW *>(weights), static_cast<const TP *>(p_cmp),         \
+                           static_cast<const TP *>(p_fine), static_cast<TW *>(out), n_batch, nz, n_inner, \
+                           w_repeat, cmp_levels, cmp_offset)
     if (w_dtype == FV3HIP_F32 && p_dtype == FV3HIP_F32) LAUNCH_(float, float);
     else if (w_dtype == FV3HIP_F32) LAUNCH_(float, double);
     else if (p_dtype == FV3HIP_F32) LAUNCH_(double, float);

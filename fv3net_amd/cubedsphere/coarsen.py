@@ -150,10 +150,42 @@ def weighted_block_average(
     """Coarsen a DataArray or Dataset through weighted block averaging (coarsen.py:183-218):
     ``(obj * weights).coarsen(x, y).sum() / weights.coarsen(x, y).sum()`` with NaN-skipping sums."""
     o, w = to_compat(obj), to_compat(weights)
-    result = _map_dataset(
-        o, lambda da: _weighted_block_average_da(da, w, coarsening_factor, x_dim, y_dim, coord_func)
-    )
+    if isinstance(o, Dataset) and len(o) > 1:
+        result = _weighted_block_average_ds(o, w, coarsening_factor, x_dim, y_dim, coord_func)
+    else:
+        result = _map_dataset(
+            o, lambda da: _weighted_block_average_da(da, w, coarsening_factor, x_dim, y_dim, coord_func)
+        )
     return from_compat(_propagate_attrs(o, result), obj)
+
+
+def _weighted_block_average_ds(ds: Dataset, w: DataArray, factor: int, x_dim, y_dim, coord_func) -> Dataset:
+    """The variables of a Dataset that share dims, shape and the weights' dtype go four to a launch (the weights -- often a
+    whole 3-D masked area, regridz.py:200-220 -- are read once per four fields); the others one by one.  Same results."""
+    kinds = {"float32": torch.float32, "float64": torch.float64, "torch.float32": torch.float32, "torch.float64": torch.float64}
+    kind = lambda a: kinds.get(str(a.dtype))  # (numpy or torch data)
+    groups = {}
+    for name, da in ds.items():
+        ok = x_dim in da.dims and y_dim in da.dims and kind(da) is not None and kind(da) == kind(w)
+        groups.setdefault((da.dims, tuple(da.shape)) if ok else ("single", name), []).append(name)
+    done = {}
+    for key, names in groups.items():
+        if key[0] == "single" or len(names) == 1:
+            for n in names:
+                done[n] = _weighted_block_average_da(ds[n], w, factor, x_dim, y_dim, coord_func)
+            continue
+        first, outer = horizontal_last(ds[names[0]], y_dim, x_dim)
+        wt = _weights_tensor(w, outer, y_dim, x_dim, "weights")
+        tensors = [first] + [horizontal_last(ds[n], y_dim, x_dim)[0] for n in names[1:]]
+        for n, res in zip(names, ops.weighted_block_average_multi(tensors, wt, factor)):
+            da = ds[n]
+            r = DataArray(like_input(res, da.data), dims=tuple(outer) + (y_dim, x_dim), name=da.name, attrs=da.attrs,
+                          coords=_coarsened_coords(da, {x_dim: factor, y_dim: factor}, coord_func))
+            done[n] = r.transpose(*da.dims)
+    out = Dataset(attrs=ds.attrs)
+    for name in ds:
+        out[name] = done[name]
+    return out
 
 
 def mass_weighted_block_average(

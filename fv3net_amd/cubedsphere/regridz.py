@@ -116,10 +116,12 @@ def _mask_weights(weights, pfull_coarse_on_fine, phalf_coarse_on_fine, phalf_fin
 def _regrid_given_delp(ds, delp_fine, delp_coarse, weights, toa_pressure, x_dim: str = FV_CORE_X_CENTER,
                        y_dim: str = FV_CORE_Y_CENTER, z_dim: str = RESTART_Z_CENTER, extrapolate: bool = False):
     """regridz.py:149-197."""
-    delp_coarse_on_fine = block_upsample_like(delp_coarse, delp_fine, x_dim=x_dim, y_dim=y_dim)
-    phalf_coarse_on_fine = pressure_at_interface(delp_coarse_on_fine, dim_center=z_dim, dim_outer=RESTART_Z_OUTER,
-                                                 toa_pressure=toa_pressure)
+    # The reference upsamples the coarse thicknesses and integrates them on the fine grid; the column sums of a block are
+    # those of its coarse column, bit for bit, so the interfaces are integrated on the coarse grid (1/f^2 of the columns)
+    # and upsampled -- one fine-size pass instead of two.
     phalf_fine = pressure_at_interface(delp_fine, dim_center=z_dim, dim_outer=RESTART_Z_OUTER, toa_pressure=toa_pressure)
+    phalf_coarse = pressure_at_interface(delp_coarse, dim_center=z_dim, dim_outer=RESTART_Z_OUTER, toa_pressure=toa_pressure)
+    phalf_coarse_on_fine = block_upsample_like(phalf_coarse, phalf_fine, x_dim=x_dim, y_dim=y_dim)
     d = to_compat(ds)
     if isinstance(d, Dataset):
         regridded = Dataset(attrs=d.attrs)
@@ -129,9 +131,10 @@ def _regrid_given_delp(ds, delp_fine, delp_coarse, weights, toa_pressure, x_dim:
             regridded[var] = out
     else:
         regridded = regrid_vertical(phalf_fine, d, phalf_coarse_on_fine, z_dim_center=z_dim)
-    pfull_coarse_on_fine = (
-        pressure_at_midpoint_log(delp_coarse_on_fine, dim=z_dim, toa_pressure=toa_pressure) if extrapolate else None
-    )
+    pfull_coarse_on_fine = None
+    if extrapolate:
+        pfull_coarse_on_fine = block_upsample_like(pressure_at_midpoint_log(delp_coarse, dim=z_dim, toa_pressure=toa_pressure),
+                                                   delp_fine, x_dim=x_dim, y_dim=y_dim)
     masked_weights = _mask_weights(weights, pfull_coarse_on_fine, phalf_coarse_on_fine, phalf_fine, dim_center=z_dim,
                                    extrapolate=extrapolate)
     return from_compat(regridded, ds), masked_weights
