@@ -122,6 +122,10 @@ SIGNATURES = {
                                            c_double, c_void_p, c_void_p, c_void_p]),
     "fv3hip_mappm_multi": (c_int, [c_void_p, c_void_p, c_void_p, c_int, c_void_p, c_int, c_int64, c_int64, c_int, c_int, c_int, c_int,
                                    c_int, c_int, c_void_p, c_size_t, c_void_p]),
+    "fv3hip_mappm_multi_coarse_target": (c_int, [c_void_p, c_void_p, c_void_p, c_int, c_void_p, c_int, c_int64, c_int, c_int, c_int, c_int, c_int,
+                                                 c_int, c_int, c_int, c_void_p, c_size_t, c_void_p]),
+    "fv3hip_mask_weights_coarse": (c_int, [c_void_p, c_int, c_void_p, c_int, c_int, c_void_p, c_int, c_int64, c_int, c_int, c_int, c_int,
+                                           c_int64, c_void_p, c_void_p]),
     "fv3hip_level_scale": (c_int, [c_void_p, c_int, c_void_p, c_int64, c_int, c_int64, c_void_p, c_void_p]),
     "fv3hip_member_reduce": (c_int, [c_void_p, c_int, c_int, c_int, c_int64, c_void_p, c_void_p]),
     "fv3hip_local_pack": (c_int, [c_void_p, c_int, c_int, c_int, c_double, c_void_p, c_void_p, c_int, c_int64, c_void_p, c_void_p]),

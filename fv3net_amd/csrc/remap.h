@@ -16,6 +16,12 @@ struct SweepArgs {
     int64_t n_inner;  // columns per batch plane (a multiple of 64)
     int km, kn, iv;
     unsigned int *n_bad, *bad_cols;
+    // target interfaces on a horizontally coarser grid (regridz.py:119-121 upsamples them; here the upsampled copy is never
+    // made): pe2 is [batch][kn + 1][pe2_plane = pe2_ny * pe2_nx] and column (y, x) of rows of nx columns reads coarse column
+    // (y / pe2_f, x / pe2_f) -- also right for a staggered dim, whose last point maps to the last coarse point.  pe2_f 0 / 1:
+    // same grid.
+    int pe2_f, nx, pe2_nx;
+    int64_t pe2_plane;
 };
 
 // LEVEL_COL layout, kord <= 3, km >= 8, n_inner % 64 == 0, every row offset of a batch below 4 GiB

@@ -105,7 +105,11 @@ __global__ __launch_bounds__(64) void mappm_sweep_kernel(const SweepArgs a)
     const int64_t plane = a.n_inner;
     // uniform row bases of the wave's batch, first column of the wave
     const char *pe1_row = static_cast<const char *>(a.pe1) + (b * (km + 1) * plane + c0) * ESZ;  // walks down the levels
-    const char *pe2_b = static_cast<const char *>(a.pe2) + (b * (kn + 1) * plane + c0) * ESZ;
+    // target interfaces: same grid, or a grid coarser by pe2_f in y and x (the lane's column offset is then its coarse column's)
+    const bool coarse2 = a.pe2_f > 1;
+    const int64_t plane2 = coarse2 ? a.pe2_plane : plane;
+    const char *pe2_b = static_cast<const char *>(a.pe2) + (b * (kn + 1) * plane2 + (coarse2 ? 0 : c0)) * ESZ;
+    const unsigned int row_p2 = (unsigned int)plane2 * ESZ;  // bytes between target interfaces
     const char *q1_row[NF];
     char *q2_b[NF];
 #pragma unroll
@@ -238,12 +242,16 @@ __global__ __launch_bounds__(64) void mappm_sweep_kernel(const SweepArgs a)
     constexpr int kRing = 16, kAhead = 9;
     __shared__ float ring_lds[kRing * 64];
     float *ring = ring_lds + lane;
-    const unsigned int lane2 = (unsigned int)lane * ESZ;
+    unsigned int lane2 = (unsigned int)lane * ESZ;
+    if (coarse2) {
+        const unsigned int c = (unsigned int)c0 + lane, y = c / (unsigned int)a.nx, x = c - y * (unsigned int)a.nx;
+        lane2 = ((y / (unsigned int)a.pe2_f) * (unsigned int)a.pe2_nx + x / (unsigned int)a.pe2_f) * ESZ;
+    }
     int jl, jr;  // interface rows (0-based) [0, jl) have landed in the ring, [jl, jr) are in flight (pv0, pv1)
     {
         float tmp[kRing];
 #pragma unroll
-        for (int i = 0; i < kRing; ++i) tmp[i] = ld<Tin>(pe2_b, (unsigned int)(i <= kn ? i : kn) * row_in + lane2);
+        for (int i = 0; i < kRing; ++i) tmp[i] = ld<Tin>(pe2_b, (unsigned int)(i <= kn ? i : kn) * row_p2 + lane2);
 #pragma unroll
         for (int i = 0; i < kRing; ++i) ring[i * 64] = tmp[i];
         jl = jr = (kRing < kn + 1) ? kRing : kn + 1;
@@ -255,7 +263,7 @@ __global__ __launch_bounds__(64) void mappm_sweep_kernel(const SweepArgs a)
         // would stall every lane on everything the wave has in flight)
         float v = ring[(i & (kRing - 1)) * 64];
         if (!((unsigned int)(jl - 1 - i) < (unsigned int)kRing)) {
-            v = ld<Tin>(pe2_b, (unsigned int)i * row_in + lane2);
+            v = ld<Tin>(pe2_b, (unsigned int)i * row_p2 + lane2);
             __builtin_amdgcn_s_waitcnt(0x0F70);  // vmcnt(0)
         }
         return v;
@@ -363,10 +371,10 @@ __global__ __launch_bounds__(64) void mappm_sweep_kernel(const SweepArgs a)
         {   // ... and up to two target-interface rows, kept kAhead ahead of lane 0's cursor
             const int want = __builtin_amdgcn_readfirstlane(k) + kAhead;
             if (jr <= kn && jr < want) {
-                pv0 = ld<Tin>(pe2_b + (size_t)jr * row_in, lane2);
+                pv0 = ld<Tin>(pe2_b + (size_t)jr * row_p2, lane2);
                 ++jr;
                 if (jr <= kn && jr < want) {
-                    pv1 = ld<Tin>(pe2_b + (size_t)jr * row_in, lane2);
+                    pv1 = ld<Tin>(pe2_b + (size_t)jr * row_p2, lane2);
                     ++jr;
                 }
             }

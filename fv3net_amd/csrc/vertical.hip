@@ -87,6 +87,22 @@ __global__ __launch_bounds__(256) void mask_weights_rows_kernel(const Tw *__rest
     for (int i = 0; i < 4; ++i) o[i] = r4[i];
 }
 
+// ... with the compared pressures on a grid coarser by f in y and x (never upsampled): column (y, x) compares (y / f, x / f)
+template <typename Tw, typename Tp>
+__global__ __launch_bounds__(256) void mask_weights_coarse_kernel(const Tw *__restrict__ w, const Tp *__restrict__ pc, const Tp *__restrict__ pf,
+                                                                  Tw *__restrict__ out, int nz, int64_t n_inner, int nx, int f, int nxc,
+                                                                  int64_t plane2, int64_t w_repeat, int cmp_levels, int cmp_offset)
+{
+    const int64_t c = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    if (c >= n_inner) return;
+    const int64_t b = blockIdx.y / nz;
+    const int k = (int)(blockIdx.y - b * nz);
+    const unsigned int y = (unsigned int)c / (unsigned int)nx, x = (unsigned int)c - y * (unsigned int)nx;
+    const Tp level = pc[(b * cmp_levels + (k + cmp_offset)) * plane2 + (int64_t)(y / f) * nxc + x / f];
+    const Tp ps = pf[(b * (nz + 1) + nz) * n_inner + c];
+    out[(b * nz + k) * n_inner + c] = (level < ps) ? w[(b / w_repeat) * n_inner + c] : (Tw)0;
+}
+
 // pressure_at_midpoint_log: delp / diff(log(p_interface)), sequential down the column
 template <typename T>
 __global__ void pressure_at_midpoint_log_kernel(const T *__restrict__ delp, T *__restrict__ out,
@@ -173,25 +189,37 @@ __device__ __forceinline__ void ppm_limiters1(float dm, float a1, float &a2, flo
 // element (column, level k) of an array with `nlev` levels lives at base + (k-1)*ks
 struct ColumnAddr {
     int64_t ks, o_pe1, o_q1, o_pe2, o_q2;
+    int64_t ks2;  // level stride of pe2 (= ks unless the target interfaces live on a coarser grid)
 };
 
 __device__ __forceinline__ ColumnAddr column_addr(int64_t col, int64_t n_inner, int km, int kn, int layout)
 {
     ColumnAddr a;
     if (layout == FV3HIP_LAYOUT_COL_LEVEL) {
-        a.ks = 1;
+        a.ks = a.ks2 = 1;
         a.o_pe1 = col * (km + 1);
         a.o_q1 = col * km;
         a.o_pe2 = col * (kn + 1);
         a.o_q2 = col * kn;
     } else {
-        a.ks = n_inner;
+        a.ks = a.ks2 = n_inner;
         const int64_t b = col / n_inner, c = col % n_inner;
         a.o_pe1 = b * (km + 1) * n_inner + c;
         a.o_q1 = b * km * n_inner + c;
         a.o_pe2 = b * (kn + 1) * n_inner + c;
         a.o_q2 = b * kn * n_inner + c;
     }
+    return a;
+}
+
+// LEVEL_COL layout with the target interfaces on a grid coarser by f in y and x (rows of nx columns)
+__device__ __forceinline__ ColumnAddr column_addr_coarse_target(int64_t col, int64_t n_inner, int km, int kn, int f, int nx, int nxc,
+                                                                int64_t plane2)
+{
+    ColumnAddr a = column_addr(col, n_inner, km, kn, FV3HIP_LAYOUT_LEVEL_COL);
+    const int64_t b = col / n_inner, c = col % n_inner, y = c / nx, x = c - y * nx;
+    a.ks2 = plane2;
+    a.o_pe2 = b * (kn + 1) * plane2 + (y / f) * nxc + x / f;
     return a;
 }
 
@@ -205,7 +233,7 @@ __device__ __noinline__ void mappm_column_exact(const Tin *__restrict__ pe1_, co
     const int64_t ks = addr.ks, o_pe1 = addr.o_pe1, o_q1 = addr.o_q1, o_pe2 = addr.o_pe2, o_q2 = addr.o_q2;
     auto PE1 = [&](int k) { return (float)pe1_[o_pe1 + (int64_t)(k - 1) * ks]; };
     auto Q = [&](int k) { return (float)q1_[o_q1 + (int64_t)(k - 1) * ks]; };
-    auto PE2 = [&](int k) { return (float)pe2_[o_pe2 + (int64_t)(k - 1) * ks]; };
+    auto PE2 = [&](int k) { return (float)pe2_[o_pe2 + (int64_t)(k - 1) * addr.ks2]; };
     auto DP = [&](int k) { return PE1(k + 1) - PE1(k); };          // dp1(i,k)
     auto DELQ = [&](int k) { return Q(k + 1) - Q(k); };            // delq(i,k)
     auto D4 = [&](int k) { return DP(k - 1) + DP(k); };            // d4(i,k)
@@ -971,14 +999,15 @@ __global__ __launch_bounds__(256) void mappm_fallback_kernel(
     const Tin *__restrict__ pe1_, const Tin *__restrict__ q1_, const Tin *__restrict__ pe2_,
     float *__restrict__ q2_, int64_t col0, int64_t n_inner, int km, int kn, int iv, int kord, int layout,
     const unsigned int *__restrict__ n_bad, const unsigned int *__restrict__ bad_cols,
-    float *__restrict__ ws, int64_t ws_cols)
+    float *__restrict__ ws, int64_t ws_cols, int pe2_f = 0, int nx = 0, int nxc = 0, int64_t plane2 = 0)
 {
     const unsigned int count = *n_bad;
     const int64_t slot = blockIdx.x * (int64_t)blockDim.x + threadIdx.x;
     for (int64_t i = slot; i < count; i += (int64_t)gridDim.x * blockDim.x) {
         const int64_t col = col0 + bad_cols[i];
-        mappm_column_exact<Tin>(pe1_, q1_, pe2_, q2_, column_addr(col, n_inner, km, kn, layout), km, kn, iv,
-                                kord, ws, slot, ws_cols);
+        const ColumnAddr addr =
+            pe2_f > 1 ? column_addr_coarse_target(col, n_inner, km, kn, pe2_f, nx, nxc, plane2) : column_addr(col, n_inner, km, kn, layout);
+        mappm_column_exact<Tin>(pe1_, q1_, pe2_, q2_, addr, km, kn, iv, kord, ws, slot, ws_cols);
     }
 }
 
@@ -1198,6 +1227,44 @@ extern "C" int fv3hip_mask_weights(const void *weights, int w_dtype, const void 
     return check_launch("mask_weights_kernel");
 }
 
+// the coarse extent of a fine extent under block_upsample's rule (coarsen.py:843-897): an odd extent is a staggered dim whose last
+// point is not repeated
+inline int coarse_extent(int n, int factor) { return (n % 2 == 1) ? (n - 1) / factor + 1 : n / factor; }
+inline bool coarse_divides(int n, int factor) { return ((n % 2 == 1) ? (n - 1) : n) % factor == 0; }
+
+// fv3hip_mask_weights with p_cmp on a grid coarser by `factor` in y and x: [n_batch][cmp_levels][ny / factor][nx / factor]
+extern "C" int fv3hip_mask_weights_coarse(const void *weights, int w_dtype, const void *p_cmp_coarse, int cmp_levels, int cmp_offset,
+                                          const void *p_fine, int p_dtype, int64_t n_batch, int nz, int ny, int nx, int factor,
+                                          int64_t w_repeat, void *out, void *stream)
+{
+    FV3HIP_REQUIRE(w_dtype == FV3HIP_F32 || w_dtype == FV3HIP_F64, "weights dtype must be F32 or F64");
+    FV3HIP_REQUIRE(p_dtype == FV3HIP_F32 || p_dtype == FV3HIP_F64, "pressure dtype must be F32 or F64");
+    FV3HIP_REQUIRE(w_repeat >= 1 && n_batch % w_repeat == 0, "bad w_repeat %lld", (long long)w_repeat);
+    FV3HIP_REQUIRE(cmp_offset >= 0 && cmp_levels >= nz + cmp_offset, "p_cmp has %d levels, need at least nz + cmp_offset = %d", cmp_levels,
+                   nz + cmp_offset);
+    FV3HIP_REQUIRE(factor >= 1 && ny >= 0 && nx >= 0 && coarse_divides(ny, factor) && coarse_divides(nx, factor),
+                   "extents (%d, %d) are not multiples of the factor %d (an odd extent is staggered: n - 1 must be)", ny, nx, factor);
+    const int64_t n_inner = (int64_t)ny * nx;
+    if (n_batch * nz * n_inner <= 0) return FV3HIP_OK;
+    FV3HIP_REQUIRE(weights && p_cmp_coarse && p_fine && out, "null pointer");
+    if (n_batch * nz > 65535 || n_inner >= ((int64_t)1 << 31))
+        return fail(FV3HIP_EUNSUPPORTED, "coarse-grid mask_weights needs n_batch * nz <= 65535 and fewer than 2^31 columns per plane");
+    hipStream_t st = as_stream(stream);
+    const int nyc = coarse_extent(ny, factor), nxc = coarse_extent(nx, factor);
+    const int64_t plane2 = (int64_t)nyc * nxc;
+    const dim3 grid((unsigned)ceil_div(n_inner, 256), (unsigned)(n_batch * nz));
+#define LAUNCH_(TW, TP)                                                                                                            \
+    hipLaunchKernelGGL((mask_weights_coarse_kernel<TW, TP>), grid, dim3(256), 0, st, static_cast<const TW *>(weights),            \
+                       static_cast<const TP *>(p_cmp_coarse), static_cast<const TP *>(p_fine), static_cast<TW *>(out), nz, n_inner, nx, factor, \
+                       nxc, plane2, w_repeat, cmp_levels, cmp_offset)
+    if (w_dtype == FV3HIP_F32 && p_dtype == FV3HIP_F32) LAUNCH_(float, float);
+    else if (w_dtype == FV3HIP_F32) LAUNCH_(float, double);
+    else if (p_dtype == FV3HIP_F32) LAUNCH_(double, float);
+    else LAUNCH_(double, double);
+#undef LAUNCH_
+    return check_launch("mask_weights_coarse_kernel");
+}
+
 extern "C" size_t fv3hip_mappm_workspace_bytes(int64_t ncol, int km)
 {
     if (ncol <= 0 || km <= 0) return 0;
@@ -1370,6 +1437,80 @@ extern "C" int fv3hip_mappm_multi(const void *pe1, const void *const *q1, const 
             if (in_dtype == FV3HIP_F32) { LAUNCH_(float); } else { LAUNCH_(double); }
 #undef LAUNCH_
             const int rc = check_launch("mappm multi-field kernel");
+            if (rc) return rc;
+        }
+    }
+    return FV3HIP_OK;
+}
+
+// mappm_multi with the target interfaces on a horizontally coarser grid: pe2 is [n_batch][kn + 1][nyc][nxc] and every fine column
+// (y, x) is remapped to the interfaces of coarse column (y / factor, x / factor) -- what regridz.py:119-185 does through an
+// upsampled copy of the coarse pressures.  LEVEL_COL layout ([n_batch][level][ny][nx]); the sweep kernel only:
+// FV3HIP_EUNSUPPORTED where it does not apply (the caller then upsamples and calls fv3hip_mappm_multi).
+extern "C" int fv3hip_mappm_multi_coarse_target(const void *pe1, const void *const *q1, const void *pe2_coarse, int in_dtype, float *const *q2,
+                                                int n_fields, int64_t n_batch, int ny, int nx, int factor, int km, int kn, int iv, int kord,
+                                                int arith, void *workspace, size_t workspace_bytes, void *stream)
+{
+    FV3HIP_REQUIRE(arith == FV3HIP_ARITH_EXACT || arith == FV3HIP_ARITH_FAST, "unknown arithmetic mode %d", arith);
+    FV3HIP_REQUIRE(n_fields >= 0, "negative field count");
+    if (n_fields == 0) return FV3HIP_OK;
+    FV3HIP_REQUIRE(q1 && q2, "null pointer");
+    FV3HIP_REQUIRE(in_dtype == FV3HIP_F32 || in_dtype == FV3HIP_F64, "in_dtype must be F32 or F64, got %d", in_dtype);
+    FV3HIP_REQUIRE(n_batch >= 0 && ny >= 0 && nx >= 0 && kn >= 0, "negative extent");
+    FV3HIP_REQUIRE(factor >= 1 && coarse_divides(ny, factor) && coarse_divides(nx, factor),
+                   "extents (%d, %d) are not multiples of the factor %d (an odd extent is staggered: n - 1 must be)", ny, nx, factor);
+    FV3HIP_REQUIRE(iv >= -2 && iv <= 2, "iv must be in [-2, 2], got %d", iv);
+    FV3HIP_REQUIRE(km >= 4, "km must be >= 4 (ppm_profile reads a4(2,i,3)), got %d", km);
+    const int64_t n_inner = (int64_t)ny * nx, ncol = n_batch * n_inner;
+    if (ncol == 0 || kn == 0) return FV3HIP_OK;
+    if (factor < 2 || !mappm_sweep_eligible(n_inner, km, kn, kord, FV3HIP_LAYOUT_LEVEL_COL, in_dtype))
+        return fail(FV3HIP_EUNSUPPORTED, "coarse-target remap needs factor >= 2 and a shape the sweep kernel takes");
+    const int nyc = coarse_extent(ny, factor), nxc = coarse_extent(nx, factor);
+    const int64_t plane2 = (int64_t)nyc * nxc;
+    FV3HIP_REQUIRE(pe1 && pe2_coarse, "null pointer");
+    for (int f = 0; f < n_fields; ++f) FV3HIP_REQUIRE(q1[f] && q2[f], "null field pointer");
+    FV3HIP_REQUIRE(workspace && workspace_bytes >= fv3hip_mappm_workspace_bytes(ncol, km),
+                   "workspace too small: need %zu bytes, got %zu", fv3hip_mappm_workspace_bytes(ncol, km), workspace_bytes);
+    hipStream_t st = as_stream(stream);
+    const int64_t ws_cols = ws_slots(ncol);
+    unsigned int *n_bad = static_cast<unsigned int *>(workspace);
+    unsigned int *bad_cols = reinterpret_cast<unsigned int *>(static_cast<char *>(workspace) + kCounterBytes);
+    float *planes = reinterpret_cast<float *>(static_cast<char *>(workspace) + kCounterBytes + ws_list_bytes(ncol));
+    for (int64_t col0 = 0; col0 < ncol; col0 += kMappmChunk) {
+        const int64_t col_end = (col0 + kMappmChunk < ncol) ? col0 + kMappmChunk : ncol;
+        const int64_t fb_threads = (col_end - col0 < kFallbackSlots) ? (col_end - col0) : kFallbackSlots;
+        const int64_t fb_blocks = ceil_div(fb_threads, 256);
+        for (int f0 = 0; f0 < n_fields; f0 += kMaxMultiFields) {
+            const int nf = (n_fields - f0 < kMaxMultiFields) ? n_fields - f0 : kMaxMultiFields;
+            FV3HIP_CHECK_HIP(hipMemsetAsync(n_bad, 0, 16, st));
+            SweepArgs sa;
+            memset(&sa, 0, sizeof(sa));
+            sa.pe1 = pe1;
+            sa.pe2 = pe2_coarse;
+            for (int f = 0; f < nf; ++f) {
+                sa.q1[f] = q1[f0 + f];
+                sa.q2[f] = q2[f0 + f];
+            }
+            sa.col0 = col0;
+            sa.n_inner = n_inner;
+            sa.km = km;
+            sa.kn = kn;
+            sa.iv = iv;
+            sa.n_bad = n_bad;
+            sa.bad_cols = bad_cols;
+            sa.pe2_f = factor;
+            sa.nx = nx;
+            sa.pe2_nx = nxc;
+            sa.pe2_plane = plane2;
+            mappm_sweep_launch(sa, nf, in_dtype, col_end, arith == FV3HIP_ARITH_FAST, st);
+#define LAUNCH_(T)                                                                                                                  \
+    for (int f = 0; f < nf; ++f)                                                                                                    \
+        hipLaunchKernelGGL((mappm_fallback_kernel<T>), dim3((unsigned)fb_blocks), dim3(256), 0, st, static_cast<const T *>(pe1),    \
+                           static_cast<const T *>(q1[f0 + f]), static_cast<const T *>(pe2_coarse), q2[f0 + f], col0, n_inner, km, kn, iv, \
+                           kord, (int)FV3HIP_LAYOUT_LEVEL_COL, n_bad, bad_cols, planes, ws_cols, factor, nx, nxc, plane2)
+            if (in_dtype == FV3HIP_F32) { LAUNCH_(float); } else { LAUNCH_(double); }
+#undef LAUNCH_
+            const int rc = check_launch("mappm coarse-target kernels");
             if (rc) return rc;
         }
     }

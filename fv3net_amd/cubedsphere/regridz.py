@@ -45,9 +45,10 @@ def regrid_vertical(p_in, f_in, p_out, iv: int = 1, kord: int = 1, z_dim_center:
 
 
 def _regrid_vertical_many(p_in, fields, p_out, iv: int = 1, kord: int = 1, z_dim_center: str = RESTART_Z_CENTER,
-                          z_dim_outer: str = RESTART_Z_OUTER):
+                          z_dim_outer: str = RESTART_Z_OUTER, p_out_factor: int = None, hor_dims=None):
     """``regrid_vertical`` of several fields between the same two pressure grids (what regridz.py:180-185
-    loops over): fields with the same dims share one multi-field remap sweep."""
+    loops over): fields with the same dims share one multi-field remap sweep.  ``p_out_factor``: ``p_out`` is still on the
+    grid coarsened by that factor along ``hor_dims`` = (y_dim, x_dim) and stands for its block-upsampled copy."""
     if z_dim_center == z_dim_outer:
         raise ValueError("'z_dim_center' and 'z_dim_outer' must not be equal.")
     pi, po = to_compat(p_in), to_compat(p_out)
@@ -57,14 +58,30 @@ def _regrid_vertical_many(p_in, fields, p_out, iv: int = 1, kord: int = 1, z_dim
         groups.setdefault((fi.dims, tuple(fi.shape)), []).append(n)
     results = [None] * len(compat)
     for members in groups.values():
-        outs = _regrid_group(pi, [compat[n] for n in members], po, iv, kord, z_dim_center, z_dim_outer)
+        outs = _regrid_group(pi, [compat[n] for n in members], po, iv, kord, z_dim_center, z_dim_outer, p_out_factor, hor_dims)
         for n, out in zip(members, outs):
             results[n] = from_compat(out, fields[n])
     return results
 
 
-def _regrid_group(pi, group, po, iv, kord, z_dim_center, z_dim_outer):
+def _regrid_group(pi, group, po, iv, kord, z_dim_center, z_dim_outer, po_factor=None, hor_dims=None):
     fi = group[0]
+    if po_factor is not None and po_factor > 1:
+        # the fused path needs [..., z, y, x]; any other order goes through the upsampled copy
+        if tuple(fi.dims[-3:]) == (z_dim_center,) + tuple(hor_dims):
+            order_p = [z_dim_outer if d == z_dim_center else d for d in fi.dims]
+            if set(pi.dims) != set(order_p) or set(po.dims) != set(order_p):
+                raise ValueError("All dimensions except vertical must be same size for p_in, f_in and p_out")
+            pi_t, po_t = pi.transpose(*order_p), po.transpose(*order_p)
+            if fi.sizes[z_dim_center] != pi_t.sizes[z_dim_outer] - 1:
+                raise ValueError("f_in must have a vertical dimension one shorter than p_in")
+            res = ops.mappm_multi_coarse_target(on_device(pi_t.data), [on_device(f.data) for f in group], on_device(po_t.data), po_factor,
+                                                iv=iv, kord=kord, z_axis=-3)
+            return [DataArray(like_input(r, f.data), dims=f.dims, coords={k: v for k, v in f.coords.items() if k != z_dim_center},
+                              name=f.name, attrs=f.attrs) for r, f in zip(res, group)]
+        from .coarsen import block_upsample
+
+        po = to_compat(block_upsample(po, po_factor, list(hor_dims)))
     dims_except_z = [d for d in fi.dims if d != z_dim_center]
     # same dim order for all three, the vertical dim where f_in has it
     order_f = list(fi.dims)
@@ -88,10 +105,15 @@ def _regrid_group(pi, group, po, iv, kord, z_dim_center, z_dim_outer):
 
 
 def _mask_weights(weights, pfull_coarse_on_fine, phalf_coarse_on_fine, phalf_fine, dim_center: str = RESTART_Z_CENTER,
-                  dim_outer: str = RESTART_Z_OUTER, extrapolate: bool = False):
-    """regridz.py:200-220: weights where the coarse level lies above the fine surface, else 0."""
+                  dim_outer: str = RESTART_Z_OUTER, extrapolate: bool = False, coarse_factor: int = None, hor_dims=None):
+    """regridz.py:200-220: weights where the coarse level lies above the fine surface, else 0.  ``coarse_factor``: the
+    coarse pressures are passed on their own grid (coarsened by that factor along ``hor_dims``), not upsampled."""
     w, pf = to_compat(weights), to_compat(phalf_fine)
     pc = to_compat(pfull_coarse_on_fine if extrapolate else phalf_coarse_on_fine)
+    if coarse_factor is not None and coarse_factor > 1 and tuple(pf.dims[-3:]) != (dim_outer,) + tuple(hor_dims):
+        from .coarsen import block_upsample
+
+        pc, coarse_factor = to_compat(block_upsample(pc, coarse_factor, list(hor_dims))), None
     zc = dim_center if extrapolate else dim_outer
     order = list(pf.dims)
     axis = order.index(dim_outer)
@@ -106,7 +128,8 @@ def _mask_weights(weights, pfull_coarse_on_fine, phalf_coarse_on_fine, phalf_fin
         data = data.expand(*[pf.sizes[d] for d in missing], *w.shape).contiguous()
         w = DataArray(data, dims=tuple(missing) + w.dims, coords=w.coords, attrs=w.attrs, name=w.name)
     w_t = w.transpose(*w_order)
-    res = ops.mask_weights(on_device(w_t.data), on_device(pc_t.data), on_device(pf.data), axis, extrapolate=extrapolate)
+    res = ops.mask_weights(on_device(w_t.data), on_device(pc_t.data), on_device(pf.data), axis, extrapolate=extrapolate,
+                           coarse_factor=coarse_factor)
     dims = tuple(dim_center if d == dim_outer else d for d in order)
     coords = {k: v for k, v in w.coords.items()}
     out = DataArray(like_input(res, to_compat(weights).data), dims=dims, coords=coords, name=w.name, attrs=w.attrs)
@@ -119,24 +142,25 @@ def _regrid_given_delp(ds, delp_fine, delp_coarse, weights, toa_pressure, x_dim:
     # The reference upsamples the coarse thicknesses and integrates them on the fine grid; the column sums of a block are
     # those of its coarse column, bit for bit, so the interfaces are integrated on the coarse grid (1/f^2 of the columns)
     # and upsampled -- one fine-size pass instead of two.
+    # ... and never upsampled at all where the remap and the mask can read them through (y // f, x // f).
     phalf_fine = pressure_at_interface(delp_fine, dim_center=z_dim, dim_outer=RESTART_Z_OUTER, toa_pressure=toa_pressure)
     phalf_coarse = pressure_at_interface(delp_coarse, dim_center=z_dim, dim_outer=RESTART_Z_OUTER, toa_pressure=toa_pressure)
-    phalf_coarse_on_fine = block_upsample_like(phalf_coarse, phalf_fine, x_dim=x_dim, y_dim=y_dim)
+    dc, df = to_compat(delp_coarse), to_compat(delp_fine)
+    staggered = dc.sizes[x_dim] % 2 == 1
+    factor = (df.sizes[x_dim] - 1) // (dc.sizes[x_dim] - 1) if staggered else df.sizes[x_dim] // dc.sizes[x_dim]
+    hor = (y_dim, x_dim)
     d = to_compat(ds)
     if isinstance(d, Dataset):
         regridded = Dataset(attrs=d.attrs)
         names = list(d)
-        for var, out in zip(names, _regrid_vertical_many(phalf_fine, [d[v] for v in names], phalf_coarse_on_fine,
-                                                         z_dim_center=z_dim)):
+        for var, out in zip(names, _regrid_vertical_many(phalf_fine, [d[v] for v in names], phalf_coarse, z_dim_center=z_dim,
+                                                         p_out_factor=factor, hor_dims=hor)):
             regridded[var] = out
     else:
-        regridded = regrid_vertical(phalf_fine, d, phalf_coarse_on_fine, z_dim_center=z_dim)
-    pfull_coarse_on_fine = None
-    if extrapolate:
-        pfull_coarse_on_fine = block_upsample_like(pressure_at_midpoint_log(delp_coarse, dim=z_dim, toa_pressure=toa_pressure),
-                                                   delp_fine, x_dim=x_dim, y_dim=y_dim)
-    masked_weights = _mask_weights(weights, pfull_coarse_on_fine, phalf_coarse_on_fine, phalf_fine, dim_center=z_dim,
-                                   extrapolate=extrapolate)
+        regridded = _regrid_vertical_many(phalf_fine, [d], phalf_coarse, z_dim_center=z_dim, p_out_factor=factor, hor_dims=hor)[0]
+    pfull_coarse = pressure_at_midpoint_log(delp_coarse, dim=z_dim, toa_pressure=toa_pressure) if extrapolate else None
+    masked_weights = _mask_weights(weights, pfull_coarse, phalf_coarse, phalf_fine, dim_center=z_dim, extrapolate=extrapolate,
+                                   coarse_factor=factor, hor_dims=hor)
     return from_compat(regridded, ds), masked_weights
 
 

@@ -541,13 +541,36 @@ def pressure_at_midpoint_log(delp: torch.Tensor, toa_pressure: float, z_axis: in
 
 
 def mask_weights(
-    weights: torch.Tensor, p_coarse: torch.Tensor, p_fine: torch.Tensor, z_axis: int, extrapolate: bool = False
+    weights: torch.Tensor, p_coarse: torch.Tensor, p_fine: torch.Tensor, z_axis: int, extrapolate: bool = False,
+    coarse_factor: Optional[int] = None,
 ) -> torch.Tensor:
     """``weights where p_level < p_fine[surface] else 0`` (regridz.py:200-220).
     ``extrapolate=False``: ``p_coarse`` holds the nz+1 coarse interface pressures and level k is
     compared through its bottom interface; ``extrapolate=True``: ``p_coarse`` holds the nz coarse
     midpoint pressures.  ``p_fine`` has nz+1 levels along ``z_axis``; ``weights`` has the pressure
-    shape without the z axis."""
+    shape without the z axis.  ``coarse_factor``: ``p_coarse`` is still on its horizontally coarser grid (last two dims;
+    the z axis third from last) and is read through (y // factor, x // factor) instead of an upsampled copy."""
+    if coarse_factor is not None and int(coarse_factor) > 1:
+        if z_axis % p_fine.dim() != p_fine.dim() - 3:
+            return mask_weights(weights, block_upsample(p_coarse, int(coarse_factor)), p_fine, z_axis, extrapolate)
+        dev = _require_device(weights, p_coarse, p_fine)
+        if p_coarse.dtype != p_fine.dtype:
+            raise ValueError("p_coarse and p_fine must have the same dtype")
+        p_coarse, p_fine, weights = p_coarse.contiguous(), p_fine.contiguous(), weights.contiguous()
+        nz, ny, nx = int(p_fine.shape[-3]) - 1, int(p_fine.shape[-2]), int(p_fine.shape[-1])
+        cmp_levels, cmp_offset = (nz, 0) if extrapolate else (nz + 1, 1)
+        batch_shape = tuple(p_fine.shape[:-3])
+        if tuple(weights.shape) != batch_shape + (ny, nx) or int(p_coarse.shape[-3]) != cmp_levels:
+            raise ValueError("weights / p_coarse do not match the fine pressures' shape")
+        out = torch.empty(batch_shape + (nz, ny, nx), dtype=weights.dtype, device=dev)
+        try:
+            _lib.call_on(dev, "fv3hip_mask_weights_coarse", _ptr(weights), _float_code(weights), _ptr(p_coarse), cmp_levels, cmp_offset,
+                         _ptr(p_fine), _float_code(p_fine), _prod(batch_shape), nz, ny, nx, int(coarse_factor), 1, _ptr(out), _stream(dev))
+        except _lib.Fv3HipError as err:
+            if err.code != _lib.EUNSUPPORTED:
+                raise
+            return mask_weights(weights, block_upsample(p_coarse, int(coarse_factor)), p_fine, z_axis, extrapolate)
+        return out
     dev = _require_device(weights, p_coarse, p_fine)
     if p_coarse.dtype != p_fine.dtype:
         raise ValueError("p_coarse and p_fine must have the same dtype")
@@ -690,6 +713,56 @@ def mappm_multi(pe1: torch.Tensor, fields: Sequence[torch.Tensor], pe2: torch.Te
     o_ptrs = (ctypes.c_void_p * n)(*[o.data_ptr() for o in outs])
     _lib.call_on(dev, "fv3hip_mappm_multi", _ptr(pe1), q_ptrs, _ptr(pe2), _float_code(q1), o_ptrs, n, nb, ni, km, kn, int(iv), int(kord),
               layout, _arith_code(arith), _ptr(ws), ws.numel(), _stream(dev))
+    return outs
+
+
+def mappm_multi_coarse_target(pe1: torch.Tensor, fields: Sequence[torch.Tensor], pe2_coarse: torch.Tensor, factor: int, iv: int = 1,
+                              kord: int = 1, z_axis: int = -3, arith: Optional[str] = None) -> list:
+    """``mappm_multi(pe1, fields, block_upsample(pe2_coarse, factor), ...)`` without the upsampled copy: the target interfaces
+    stay on their coarse grid ``[..., z, ny_c, nx_c]`` and fine column (y, x) reads coarse column (y // factor, x // factor)
+    (regridz.py:119-185; a staggered dim's last point maps to the last coarse point, as ``block_upsample`` repeats it).  The
+    vertical axis must be third from last; shapes the fused kernel does not take go through the upsampled copy.  Same results."""
+    fields = list(fields)
+    if not fields:
+        return []
+    factor = int(factor)
+    q1 = fields[0]
+    nd = q1.dim()
+
+    def fallback():
+        return mappm_multi(pe1, fields, block_upsample(pe2_coarse, factor), iv=iv, kord=kord, z_axis=z_axis, arith=arith)
+
+    if nd < 3 or z_axis % nd != nd - 3 or factor < 2:
+        return fallback()
+    dev = _require_device(pe1, pe2_coarse, *fields)
+    dtypes = {t.dtype for t in (pe1, pe2_coarse, *fields)}
+    if len(dtypes) > 1:
+        common = torch.float64 if torch.float64 in dtypes else torch.float32
+        pe1, pe2_coarse, fields = pe1.to(common), pe2_coarse.to(common), [q.to(common) for q in fields]
+    pe1, pe2_coarse, fields = pe1.contiguous(), pe2_coarse.contiguous(), [q.contiguous() for q in fields]
+    q1 = fields[0]
+    km, kn = int(q1.shape[-3]), int(pe2_coarse.shape[-3]) - 1
+    ny, nx = int(q1.shape[-2]), int(q1.shape[-1])
+    if int(pe1.shape[-3]) != km + 1:
+        raise ValueError("f_in must have a vertical dimension one shorter than p_in")
+    coarse = lambda n: (n - 1) // factor + 1 if n % 2 == 1 else n // factor
+    if (any(tuple(q.shape) != tuple(q1.shape) for q in fields) or tuple(pe1.shape[:-3]) != tuple(q1.shape[:-3])
+            or tuple(pe1.shape[-2:]) != (ny, nx) or tuple(pe2_coarse.shape[:-3]) != tuple(q1.shape[:-3])
+            or tuple(pe2_coarse.shape[-2:]) != (coarse(ny), coarse(nx))):
+        raise ValueError("All dimensions except vertical must be same size for p_in, f_in and (the upsampled) p_out")
+    nb = _prod(q1.shape[:-3])
+    outs = [torch.empty(tuple(q1.shape[:-3]) + (kn, ny, nx), dtype=torch.float32, device=dev) for _ in fields]
+    ws = _workspace(dev, int(_lib.load().fv3hip_mappm_workspace_bytes(nb * ny * nx, km)))
+    n = len(fields)
+    q_ptrs = (ctypes.c_void_p * n)(*[q.data_ptr() for q in fields])
+    o_ptrs = (ctypes.c_void_p * n)(*[o.data_ptr() for o in outs])
+    try:
+        _lib.call_on(dev, "fv3hip_mappm_multi_coarse_target", _ptr(pe1), q_ptrs, _ptr(pe2_coarse), _float_code(q1), o_ptrs, n, nb, ny, nx,
+                     factor, km, kn, int(iv), int(kord), _arith_code(arith), _ptr(ws), ws.numel(), _stream(dev))
+    except _lib.Fv3HipError as err:
+        if err.code != _lib.EUNSUPPORTED:
+            raise
+        return fallback()
     return outs
 
 

@@ -254,6 +254,13 @@ int fv3hip_mask_weights(const void *weights, int w_dtype, const void *p_cmp, int
                         int cmp_offset, const void *p_fine, int p_dtype, int64_t n_batch, int nz,
                         int64_t n_inner, int64_t w_repeat, void *out, void *stream);
 
+/* fv3hip_mask_weights with p_cmp on a horizontally coarser grid, [n_batch][cmp_levels][ny / factor][nx / factor]: column (y, x)
+ * compares the level of coarse column (y / factor, x / factor) -- regridz.py:119-121 upsamples it first; this does not.
+ * FV3HIP_EUNSUPPORTED unless nx % 4 == 0 and n_batch * nz <= 65535 (upsample and call fv3hip_mask_weights then). */
+int fv3hip_mask_weights_coarse(const void *weights, int w_dtype, const void *p_cmp_coarse, int cmp_levels, int cmp_offset,
+                               const void *p_fine, int p_dtype, int64_t n_batch, int nz, int ny, int nx, int factor,
+                               int64_t w_repeat, void *out, void *stream);
+
 /*
  * Replaces the f2py module function mappm.mappm(p_in, f_in, p_out, i1, i2, iv, kord, ptop)
  * (external/mappm/mappm/mappm.f90:10-126 with ppm_profile :614-851 and ppm_limiters
@@ -283,6 +290,18 @@ int fv3hip_mappm_multi(const void *pe1, const void *const *q1, const void *pe2, 
                        float *const *q2, int n_fields, int64_t n_batch, int64_t n_inner, int km,
                        int kn, int iv, int kord, int layout, int arith, void *workspace,
                        size_t workspace_bytes, void *stream);
+
+/*
+ * fv3hip_mappm_multi with the target interfaces on a horizontally coarser grid: pe2_coarse is [n_batch][kn + 1][ny / factor]
+ * [nx / factor], the fields and pe1 [n_batch][level][ny][nx]; fine column (y, x) is remapped to the interfaces of coarse column
+ * (y / factor, x / factor).  regridz.py:119-185 reaches the same result through an upsampled copy of the coarse pressures
+ * (block_upsample_like); here that copy is never made and the 64 columns of a wave share 64 / factor target columns.  Results are
+ * identical to upsampling and calling fv3hip_mappm_multi.  FV3HIP_EUNSUPPORTED unless factor >= 2, nx % 64 == 0 and the shape is
+ * one the sweep kernel takes (kord <= 3, km >= 8, ny * nx % 64 == 0); same workspace as fv3hip_mappm for n_batch * ny * nx columns.
+ */
+int fv3hip_mappm_multi_coarse_target(const void *pe1, const void *const *q1, const void *pe2_coarse, int in_dtype, float *const *q2,
+                                     int n_fields, int64_t n_batch, int ny, int nx, int factor, int km, int kn, int iv, int kord,
+                                     int arith, void *workspace, size_t workspace_bytes, void *stream);
 
 /* ------------------------------------------------------------------------------------------
  * Column MLP (fv3fit dense model / Zhao-Carr microphysics emulator)

@@ -579,3 +579,31 @@ def test_mappm_fast_mode_full_size_c384(device):
     cols = lambda t: t.permute(0, 2, 3, 1).reshape(-1, t.shape[1])[::16].cpu().numpy()
     ref = mappm_c.mappm(cols(pe1), cols(qs[1]), cols(pe2))
     assert _bits_equal(cols(exact[1]), ref)
+
+
+@pytest.mark.parametrize("dtype", [torch.float32, torch.float64])
+@pytest.mark.parametrize("ny,nx,nfields", [(64, 64, 1), (64, 128, 4), (65, 64, 3), (64, 65, 2), (65, 16, 2)])
+def test_coarse_target_remap_equals_the_upsampled_one(device, dtype, ny, nx, nfields):
+    """``mappm_multi_coarse_target`` (target interfaces read through (y // f, x // f)) gives bit for bit what the reference's
+    route gives -- upsample the coarse interfaces, then remap (regridz.py:119-185) -- for centred and staggered (odd) dims,
+    1..4 fields, both input dtypes, shapes the sweep kernel takes and one it does not (65 x 16 columns are not whole waves: the fallback inside the op);
+    so does ``mask_weights`` with the coarse pressures."""
+    from fv3net_amd import ops
+
+    f, nb, km = 8, 3, 19
+    g = torch.Generator(device=device).manual_seed(ny * 1000 + nx)
+    coarse = lambda n: (n - 1) // f + 1 if n % 2 else n // f
+    delp = torch.rand((nb, km, ny, nx), device=device, generator=g, dtype=dtype) * 1200 + 300
+    delp_c = torch.rand((nb, km, coarse(ny), coarse(nx)), device=device, generator=g, dtype=dtype) * 1200 + 300
+    pe1 = ops.pressure_at_interface(delp, 300.0, 1)
+    pe2_c = ops.pressure_at_interface(delp_c, 300.0, 1)
+    qs = [torch.rand((nb, km, ny, nx), device=device, generator=g, dtype=dtype) * 200 - 100 for _ in range(nfields)]
+    want = ops.mappm_multi(pe1, qs, ops.block_upsample(pe2_c, f), z_axis=1)
+    got = ops.mappm_multi_coarse_target(pe1, qs, pe2_c, f, z_axis=1)
+    for a, b in zip(got, want):
+        assert torch.equal(a, b)
+    w = torch.rand((nb, ny, nx), device=device, generator=g, dtype=torch.float32)
+    for extrapolate, pc in ((False, pe2_c), (True, 0.5 * (pe2_c[:, 1:] + pe2_c[:, :-1]))):
+        want = ops.mask_weights(w, ops.block_upsample(pc, f), pe1, 1, extrapolate=extrapolate)
+        got = ops.mask_weights(w, pc, pe1, 1, extrapolate=extrapolate, coarse_factor=f)
+        assert torch.equal(got, want) and 0 < float((got == 0).float().mean()) < 1
