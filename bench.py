@@ -415,7 +415,8 @@ def secondary_benchmarks(dev, steps):
     return out
 
 
-def restart_pipeline_benchmark(dev, n=384, f=8, reps=3, tiles=tuple(range(6)), which=("sigma", "pressure", "blended"), sync=None):
+def restart_pipeline_benchmark(dev, n=384, f=8, reps=3, tiles=tuple(range(6)), which=("sigma", "pressure", "blended"), sync=None,
+                               graph=True):
     """BASELINE configs[2] end to end: the three restart coarse-graining pipelines (vcm coarsen_restarts_on_sigma /
     _on_pressure / _via_blended_method, all four restart categories, 'complex' surface method) C384 -> C48 on float64
     restarts resident in HBM, through the drop-in Python API.  Wall time of a whole pipeline call.  ``tiles``: the cube
@@ -426,6 +427,7 @@ def restart_pipeline_benchmark(dev, n=384, f=8, reps=3, tiles=tuple(range(6)), w
     from fv3net_amd.xr_compat import DataArray, Dataset
 
     nt = len(tiles)
+    sync_is_default = sync is None
     sync = sync or (lambda: torch.cuda.synchronize(dev))
     g = torch.Generator(device=dev).manual_seed(3 + 17 * int(tiles[0]))
     u = lambda lo, hi, *shape: torch.rand(shape, device=dev, generator=g, dtype=torch.float64) * (hi - lo) + lo
@@ -469,12 +471,31 @@ def restart_pipeline_benchmark(dev, n=384, f=8, reps=3, tiles=tuple(range(6)), w
             fn()
         sync()
         ms = (time.perf_counter() - t0) / reps * 1e3
-        out.append({"kernel": f"{label} (whole pipeline, Python API)",
-                    "workload": f"C{n}->C{n // f}, 4 restart categories, {nt} tile(s), {nbytes / 1e9:.2f} GB of float64 restarts in HBM",
-                    "ms": ms, "bytes": nbytes,
-                    "roofline": {"bound": "hbm", "achieved": nbytes / ms / 1e6, "peak": PEAK_HBM_GBPS, "unit": "GB/s",
-                                 "frac": nbytes / ms / 1e6 / PEAK_HBM_GBPS, "traffic": None,
-                                 "note": "input bytes / wall time"}})
+        entry = {"kernel": f"{label} (whole pipeline, Python API)",
+                 "workload": f"C{n}->C{n // f}, 4 restart categories, {nt} tile(s), {nbytes / 1e9:.2f} GB of float64 restarts in HBM",
+                 "ms": ms, "bytes": nbytes,
+                 "roofline": {"bound": "hbm", "achieved": nbytes / ms / 1e6, "peak": PEAK_HBM_GBPS, "unit": "GB/s",
+                              "frac": nbytes / ms / 1e6 / PEAK_HBM_GBPS, "traffic": None,
+                              "note": "input bytes / wall time"}}
+        if graph and nt == 6 and sync_is_default:  # the same call captured as a HIP graph and replayed (fv3net_amd.graphs)
+            try:
+                from fv3net_amd.graphs import GraphedCall
+
+                gc = GraphedCall(fn, device=dev)
+                for _ in range(3):
+                    gc.replay()
+                sync()
+                t0 = time.perf_counter()
+                for _ in range(reps * 2):
+                    gc.replay()
+                sync()
+                gms = (time.perf_counter() - t0) / (reps * 2) * 1e3
+                entry["graph_replay_ms"] = gms
+                entry["graph_replay_frac"] = nbytes / gms / 1e6 / PEAK_HBM_GBPS
+                del gc
+            except Exception as err:  # noqa: BLE001
+                entry["graph_replay_error"] = f"{type(err).__name__}: {err}"
+        out.append(entry)
     return out
 
 
