@@ -187,6 +187,11 @@ __device__ __forceinline__ void rows_read(uint32_t rows, f32x2 (&r)[4])
                  : "memory");
 }
 typedef __attribute__((address_space(1))) f32x4 global_f32x4;
+// (Non-temporal hints on the streaming accesses -- `nt` on the x loads, the `before` loads or the output stores, to keep them from
+// displacing the weight stream in L2 -- were measured: each of the three made the launch 3-6 % slower.  Plain accesses.)
+#define MLP3_NT_AUX 0
+#define MLP3_NT_LOAD(p) (*(p))
+#define MLP3_NT_STORE(v, p) (*(p) = (v))
 // 4 rows of 64 bytes, 128 bytes apart (the bias rows of four feature tiles)
 __device__ __forceinline__ void lds_read4x64_sync(uint32_t addr, f32x4 (&r)[4][4])
 {
@@ -408,7 +413,7 @@ __global__ __launch_bounds__(256, 1) void mlp3_kernel(const Mlp3Launch p)
             const __amdgpu_buffer_rsrc_t r = __builtin_amdgcn_make_buffer_rsrc(reinterpret_cast<void *>(s.base), 0, s.rows * s.fs4, 0x00020000);
             const uint32_t voff = nb + (half ? 8u * s.fs4 : 0u);
 #pragma unroll
-            for (int j = 0; j < 8; ++j) x[j] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(r, voff + j * s.fs4, 0, 0));
+            for (int j = 0; j < 8; ++j) x[j] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(r, voff + j * s.fs4, 0, MLP3_NT_AUX));
         };
         auto xstep = [&](int ks) { return p.xk[ks < p.n_ks1 ? ks : p.n_ks1 - 1]; };   // (past the end: the last k-step's rows again)
         // normalise (log / centre); `t` = the k-step's table row {centre[8], epsilon[8]} of this half
@@ -542,7 +547,7 @@ __global__ __launch_bounds__(256, 1) void mlp3_kernel(const Mlp3Launch p)
                 rows_read(rowsF + OT * 256 + t * 256, rq);   // (the prefetch of the first window; later tiles get their rows from the exchange)
 #pragma unroll
                 for (int i = 0; i < 4; ++i) {
-                    const f32x4 v = *reinterpret_cast<const global_f32x4 *>(__builtin_bit_cast(int64_t, rq[i]) + qb64);
+                    const f32x4 v = MLP3_NT_LOAD(reinterpret_cast<const global_f32x4 *>(__builtin_bit_cast(int64_t, rq[i]) + qb64));
 #pragma unroll
                     for (int e = 0; e < 4; ++e) dst[i * 4 + e] = v[e];
                 }
@@ -550,7 +555,7 @@ __global__ __launch_bounds__(256, 1) void mlp3_kernel(const Mlp3Launch p)
                 f32x4 rr[8];
                 lds_read2x64_sync(table_addr(1, t), rr);
 #pragma unroll
-                for (int r = 0; r < 16; ++r) dst[r] = *reinterpret_cast<const global_float *>(row_of(rr, r) + nb64);
+                for (int r = 0; r < 16; ++r) dst[r] = MLP3_NT_LOAD(reinterpret_cast<const global_float *>(row_of(rr, r) + nb64));
             }
         };
         // `before` rows of the residual outputs: a rolling window of WIN tiles; the first WIN are requested during the last
@@ -595,21 +600,21 @@ __global__ __launch_bounds__(256, 1) void mlp3_kernel(const Mlp3Launch p)
                     for (int e = 0; e < 4; ++e) tq[i][e] += bf[i];
                 if (qvalid) {
 #pragma unroll
-                    for (int i = 0; i < 4; ++i) *reinterpret_cast<global_f32x4 *>(__builtin_bit_cast(int64_t, rq[i]) + qb64) = tq[i];
+                    for (int i = 0; i < 4; ++i) MLP3_NT_STORE(tq[i], reinterpret_cast<global_f32x4 *>(__builtin_bit_cast(int64_t, rq[i]) + qb64));
                     if constexpr (RES) {
 #pragma unroll
                         for (int i = 0; i < 4; ++i) {
                             f32x4 o;
 #pragma unroll
                             for (int e = 0; e < 4; ++e) o[e] = before[T % WIN][i * 4 + e] + tq[i][e];
-                            *reinterpret_cast<global_f32x4 *>(__builtin_bit_cast(int64_t, ra[i]) + qb64) = o;
+                            MLP3_NT_STORE(o, reinterpret_cast<global_f32x4 *>(__builtin_bit_cast(int64_t, ra[i]) + qb64));
                         }
                     }
                 }
                 if constexpr (RES && T + WIN < OT) {
 #pragma unroll
                     for (int i = 0; i < 4; ++i) {
-                        const f32x4 nv = *reinterpret_cast<const global_f32x4 *>(__builtin_bit_cast(int64_t, rn[i]) + qb64);
+                        const f32x4 nv = MLP3_NT_LOAD(reinterpret_cast<const global_f32x4 *>(__builtin_bit_cast(int64_t, rn[i]) + qb64));
 #pragma unroll
                         for (int e = 0; e < 4; ++e) before[T % WIN][i * 4 + e] = nv[e];
                     }
@@ -624,7 +629,7 @@ __global__ __launch_bounds__(256, 1) void mlp3_kernel(const Mlp3Launch p)
 #pragma unroll
                 for (int r = 0; r < 16; ++r) {
                     y[T][r] += bq[r >> 2][r & 3];
-                    *reinterpret_cast<global_float *>(row_of(rr, r) + nb64) = y[T][r];
+                    MLP3_NT_STORE(y[T][r], reinterpret_cast<global_float *>(row_of(rr, r) + nb64));
                 }
             });
             if constexpr (RES)
@@ -633,7 +638,7 @@ __global__ __launch_bounds__(256, 1) void mlp3_kernel(const Mlp3Launch p)
                     f32x4 rr[8];
                     lds_read2x64_sync(table_addr(2, T), rr);
 #pragma unroll
-                    for (int r = 0; r < 16; ++r) *reinterpret_cast<global_float *>(row_of(rr, r) + nb64) = before[T % WIN][r] + y[T][r];
+                    for (int r = 0; r < 16; ++r) MLP3_NT_STORE(before[T % WIN][r] + y[T][r], reinterpret_cast<global_float *>(row_of(rr, r) + nb64));
                     if constexpr (T + WIN < OT) load_before(T + WIN, before[T % WIN]);
                 });
         }
@@ -945,9 +950,16 @@ extern "C" int fv3hip_mlp3_predict(fv3hip_mlp3_t m, const void *const *sources, 
     } else {                                                                                                             \
         if (fast) LAUNCH3R_(OT, false, true) else LAUNCH3R_(OT, false, false)                                            \
     }
+    // The kernel's chunk waits count memory operations (s_waitcnt vmcnt(N)); a register spill is a memory operation the
+    // count does not know -- an instantiation that needs scratch memory must not run.
 #define LAUNCH3R_(OT, RES, FAST)                                                                                         \
     {                                                                                                                    \
         auto kern = mlp3_kernel<OT, RES, FAST>;                                                                          \
+        hipFuncAttributes attr;                                                                                          \
+        FV3HIP_CHECK_HIP(hipFuncGetAttributes(&attr, reinterpret_cast<const void *>(kern)));                              \
+        if (attr.localSizeBytes != 0)                                                                                    \
+            return fail(FV3HIP_EUNSUPPORTED, "mlp3_kernel<%d,%d,%d> was built with %zu bytes of scratch per lane (register spills)", OT, \
+                        (int)RES, (int)FAST, (size_t)attr.localSizeBytes);                                               \
         FV3HIP_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds)); \
         hipLaunchKernelGGL(kern, dim3(grid), dim3(256), lds, st, lp);                                                    \
     }
