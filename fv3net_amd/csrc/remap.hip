@@ -345,17 +345,6 @@ __global__ __launch_bounds__(64) void mappm_sweep_kernel(const SweepArgs a)
         if (jr > jl + 1) ring[((jl + 1) & (kRing - 1)) * 64] = pv1;
         jl = jr;
         flush_rows(2);
-        if (L > 1) {  // level L becomes the current one
-            if (!(pe_in >= pe_e)) bad = true;
-#pragma unroll
-            for (int v = 0; v < NV; ++v) {
-                q0[v] = qp1[v]; qp1[v] = qp2[v]; qp2[v] = qp3[v]; qp3[v] = q_in[v];
-                al0[v] = al1[v]; al1[v] = al2[v];
-                dc0[v] = dc1[v]; dc1[v] = dc2[v];
-            }
-            d0 = dp1; dp1 = dp2; dp2 = dp3; dp3 = pe_in - pe_e;
-            pe_a = pe_b; pe_b = pe_c; pe_c = pe_d; pe_d = pe_e; pe_e = pe_in;
-        }
         // Order inside an iteration: the requests for the next iteration first, then layer L's finalisation and its
         // emits, then the reconstruction of level L + 2 -- the wait at the top of the next iteration also waits for
         // whatever was stored here, so the reconstruction sits behind the stores.
@@ -471,6 +460,17 @@ __global__ __launch_bounds__(64) void mappm_sweep_kernel(const SweepArgs a)
                 ar_km[v] = ark;
             }
         }
+        // ---- level L + 1 becomes the current one (at the bottom of the iteration, unconditionally: with the rotation under
+        // `if (L > 1)` at the top the compiler shuffled the window forth at the top and back at the bottom, 18 moves a level)
+        if (!(pe_in >= pe_e)) bad = bad | (L < km);
+#pragma unroll
+        for (int v = 0; v < NV; ++v) {
+            q0[v] = qp1[v]; qp1[v] = qp2[v]; qp2[v] = qp3[v]; qp3[v] = q_in[v];
+            al0[v] = al1[v]; al1[v] = al2[v];
+            dc0[v] = dc1[v]; dc1[v] = dc2[v];
+        }
+        d0 = dp1; dp1 = dp2; dp2 = dp3; dp3 = pe_in - pe_e;
+        pe_a = pe_b; pe_b = pe_c; pe_c = pe_d; pe_d = pe_e; pe_e = pe_in;
     }
 
     // ---- past the old surface (mappm.f90:115-121), then the run that copies q1(km) ----
