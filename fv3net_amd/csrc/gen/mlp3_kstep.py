@@ -12,6 +12,8 @@ Per tile the six significant products of (w_hi + w_mid + w_lo)(x_hi + x_mid + x_
 Run:  python3 gen/mlp3_kstep.py   (from fv3net_amd/csrc; the output is committed)."""
 import os
 
+EARLY_SPLIT = 0  # VALU instructions of the split issued before the first wait (measured: 22 makes the launch 2 % slower -- there is
+                 # no LDS bubble to fill there; so does moving the chunk request in front of the first wait: 6 % slower)
 PRODUCTS = [(1, "bm"), (0, "bl"), (2, "bh"), (0, "bm"), (1, "bh"), (0, "bh")]  # (weight piece, activation piece)
 
 
@@ -75,6 +77,9 @@ def block(nt, first, tab, split, per):
             emit(f"ds_read_b128 %[x{i}], %[tb] offset:{16 * i}")
     request(0)
     pending1 = request(1) if len(pairs) > 1 else 0
+    if split:
+        for _ in range(EARLY_SPLIT):
+            emit(side.pop(len(dma_lines(per)) if per else 0))
     for p, (t0, t1) in enumerate(pairs):
         s = p & 1
         if p == 0:
