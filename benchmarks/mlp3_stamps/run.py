@@ -24,8 +24,8 @@ model.predict(src)
 torch.cuda.synchronize()
 s = stamps.cpu().numpy().astype(np.float64)
 tiles = N/128/256
-names = ['tile start', 'layer1 ksteps', 'bias+relu', 'hidden ksteps', 'output ksteps', 'epilogue']
-tot = s[:, :6].sum(1).mean()
+names = ['tile start', 'layer1 ksteps', 'bias+relu', 'hidden ksteps', 'output ksteps', 'epilogue', 'hidden fences']
+tot = s[:, :7].sum(1).mean()
 for i, n in enumerate(names):
     print(f"{n:14s} {s[:, i].mean()/tiles:10.0f} ticks/tile  {100*s[:, i].mean()/tot:5.1f}%")
 print('total/tile', tot/tiles)

@@ -518,7 +518,9 @@ __global__ __launch_bounds__(256, 1) void mlp3_kernel(const Mlp3Launch p)
                 B3 bn;
                 if constexpr (KS + 1 < 16) x_of(h, std::integral_constant<int, (KS + 1 < 16 ? KS + 1 : 0)>{}, xn);
                 kstep_mfma<kHT, KS == 0, (KS + 1 < 16), (KS < 14)>(h2, a_lane + b0, b, xn, bn, dsc);
+                STAMP3_END(3);
                 fence(std::integral_constant<int, 0>{}, ah);
+                STAMP3_END(6);   // (the hidden layers' waits + barriers alone)
                 if constexpr (KS + 1 < 16) b = bn;
                 ++g;
             });
