@@ -692,6 +692,21 @@ def dense_local_benchmark(dev, steps):
                      "frac": achieved / PEAK_FP32_MFMA_TFLOPS, "traffic": None},
     }]
     del model
+    try:  # the same emulator on the opt-in split-bf16 arithmetic (EXPLORATORY)
+        model = LocalMlpModel(spec, device=dev, arithmetic="split-bf16")
+        fn = lambda: model.predict(st)
+        fn()
+        torch.cuda.synchronize(dev)
+        ms3 = time_kernel(fn, max(3, min(steps, 5)), dev, warm=1)
+        tf = flops * NZ * ncol / (ms3 * 1e-3) / 1e12
+        out.append({
+            "kernel": "dense-local emulator on mlp3_kernel<1> (EXPLORATORY split-bf16 arithmetic, opt-in)",
+            "workload": out[0]["workload"], "ms": ms3, "columns_per_s": ncol / ms3 * 1e3, "fp32_kernel_ms_same_run": ms,
+            "roofline": {"bound": "mfma", "achieved": tf, "peak": PEAK_FP32_MFMA_TFLOPS, "unit": "TFLOP/s (fp32-equivalent)",
+                         "frac": tf / PEAK_FP32_MFMA_TFLOPS, "traffic": None}})
+        del model
+    except Exception as err:  # noqa: BLE001
+        out.append({"kernel": "dense-local emulator on mlp3_kernel<1>", "error": f"{type(err).__name__}: {err}"})
     # the production precpd emulator (configs/models/precpd.yaml: "rnn-v1-shared-weights", 2 stacked SimpleRNN(256) over the
     # 79 levels, 4 outputs): 79 x 2 launches of the fused kernel, the states ping-ponging in HBM
     from fv3net_amd.local_mlp import RnnLayer, RnnModel, RnnSpec

@@ -148,11 +148,11 @@ def function(nt, tab, split, per):
 def main():
     here = os.path.dirname(os.path.abspath(__file__))
     parts = ["// GENERATED by gen/mlp3_kstep.py -- do not edit; see the generator for the schedule.\n"]
-    # (tiles, with the layer-1 table row, chunk loads inside: 6 = a hidden-type chunk, 10 / 4 / 3 = the output-type chunk of
-    # 13 / 5 / 3 tiles, 0 = requested by the caller)
-    per_o = {13: 10, 5: 4, 3: 3}
+    # (tiles, with the layer-1 table row, chunk loads inside: 6 = a hidden-type chunk, 10 / 4 / 3 / 1 = the output-type chunk of
+    # 13 / 5 / 3 / 1 tiles, 0 = requested by the caller)
+    per_o = {13: 10, 5: 4, 3: 3, 1: 1}
     shapes = [(8, False, 0), (8, False, 6), (8, True, 0), (8, True, 6)]
-    for nt in (13, 5, 3):
+    for nt in (13, 5, 3, 1):
         shapes += [(nt, False, 0), (nt, False, per_o[nt])]
     for nt, tab, per in shapes:
         for split in (False, True):

@@ -10,7 +10,7 @@
 // Same graph as mlp.hip (reference lines there): log / centre inputs (1/std folded into the layer-1 weights), Dense + ReLU
 // stack, output heads with scale / centre folded in, optional residual outputs `after = before + difference`.
 // Restrictions: hidden width 256, float32 sources and outputs that are sample-contiguous, every log epsilon >= FLT_MIN (the
-// fast log), no output limits / masks, 3 / 5 / 13 output tiles of 32 features.  Anything else: FV3HIP_EUNSUPPORTED.
+// fast log), no output limits / masks, 1 / 3 / 5 / 13 output tiles of 32 features.  Anything else: FV3HIP_EUNSUPPORTED.
 //
 // Structure: a workgroup is 4 waves x 32 samples and walks 128-sample tiles persistently.  A layer is a sequence of k-steps
 // of 16 contraction indices; per k-step the wave holds its B operand (8 activations per lane as three bf16x8 pieces) and runs
@@ -77,6 +77,7 @@ struct Mlp3Launch {
     float *sink;           // a row of n_samples floats nobody reads: where padding features / absent residuals are stored
     unsigned long long *stamps;  // diagnostic builds only (-DMLP3_STAMPS): [workgroup][wave][8] cycle sums per phase
     int n_ks1, n_log_ks, n_hidden, n_ot, n_residual;
+    int x_wrap;            // 16 feature rows span 4 GiB or more: a padding row's 32-bit offset could wrap into range
     int64_t n_samples, n_tiles;
     XStep xk[kMaxKs1];
     const float *src[kMaxSrc];
@@ -242,7 +243,7 @@ struct Dma {
 template <int NT, bool FIRST, bool SPLIT, bool INSIDE>
 __device__ __forceinline__ void kstep_mfma(f32x16 (&acc)[NT], uint32_t ab, const B3 &b, const float (&xn)[8], B3 &bn, const Dma &d)
 {
-    static_assert(NT == 8 || NT == 13 || NT == 5 || NT == 3, "k-step shapes generated: 8, 13, 5, 3 tiles");
+    static_assert(NT == 8 || NT == 13 || NT == 5 || NT == 3 || NT == 1, "k-step shapes generated: 8, 13, 5, 3, 1 tiles");
 #define KSTEP3_(NTV, PERV)                                                                                                  \
     if constexpr (NT == NTV) {                                                                                              \
         if constexpr (SPLIT && INSIDE) kstep_asm_##NTV##_split_dma##PERV<FIRST>(acc, ab, b, xn, bn, d.rsrc, d.goff, d.lds, d.voff); \
@@ -254,6 +255,7 @@ __device__ __forceinline__ void kstep_mfma(f32x16 (&acc)[NT], uint32_t ab, const
     KSTEP3_(13, 10)
     KSTEP3_(5, 4)
     KSTEP3_(3, 3)
+    KSTEP3_(1, 1)
 #undef KSTEP3_
 }
 
@@ -412,6 +414,14 @@ __global__ __launch_bounds__(256, 1) void mlp3_kernel(const Mlp3Launch p)
             // would not be bounds-checked): row 8 half + j of a k-step with fewer rows is out of range and reads 0
             const __amdgpu_buffer_rsrc_t r = __builtin_amdgcn_make_buffer_rsrc(reinterpret_cast<void *>(s.base), 0, s.rows * s.fs4, 0x00020000);
             const uint32_t voff = nb + (half ? 8u * s.fs4 : 0u);
+            if (p.x_wrap) {   // (rows of 256 MiB and more: the offsets of the rows past the last real one are forced out of range)
+#pragma unroll
+                for (int j = 0; j < 8; ++j) {
+                    const uint32_t o = (uint32_t)(8 * half + j) < s.rows ? voff + j * s.fs4 : 0xFFFFFFFFu;
+                    x[j] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(r, o, 0, MLP3_NT_AUX));
+                }
+                return;
+            }
 #pragma unroll
             for (int j = 0; j < 8; ++j) x[j] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(r, voff + j * s.fs4, 0, MLP3_NT_AUX));
         };
@@ -733,8 +743,8 @@ extern "C" int fv3hip_mlp3_create(const fv3hip_mlp_desc_t *d, fv3hip_mlp3_t *out
     for (int i = 0; i < d->n_inputs; ++i) K += d->in_nfeat[i];
     for (int j = 0; j < d->n_outputs; ++j) F += d->out_nfeat[j];
     const int n_ot = (F + 31) / 32;
-    if (n_ot != 13 && n_ot != 3 && n_ot != 5)
-        return fail(FV3HIP_EUNSUPPORTED, "the split-bf16 kernel is compiled for 3, 5 or 13 output tiles of 32 (got %d outputs)", F);
+    if (n_ot != 13 && n_ot != 3 && n_ot != 5 && n_ot != 1)
+        return fail(FV3HIP_EUNSUPPORTED, "the split-bf16 kernel is compiled for 1, 3, 5 or 13 output tiles of 32 (got %d outputs)", F);
     // k-slots of layer 1: every input padded to whole k-steps of 16 (a k-step reads 16 consecutive rows of one source), the
     // log-transformed inputs first
     struct Slot { int src, feat; float center, rscale, eps; int orig; };
@@ -921,9 +931,10 @@ extern "C" int fv3hip_mlp3_predict(fv3hip_mlp3_t m, const void *const *sources, 
         const int sidx = m->ks_src[ks];
         const int64_t fs4 = src_feat_stride[sidx] * 4;
         FV3HIP_REQUIRE(fs4 >= n_samples * 4, "source %d: feature stride %lld < n_samples", sidx, (long long)src_feat_stride[sidx]);
-        if (fs4 * 16 >= ((int64_t)1 << 32))
-            return fail(FV3HIP_EUNSUPPORTED, "the split-bf16 kernel addresses 16 feature rows with 32-bit offsets (feature stride %lld too large)",
-                        (long long)src_feat_stride[sidx]);
+        if (fs4 * m->ks_rows[ks] >= ((int64_t)1 << 32))
+            return fail(FV3HIP_EUNSUPPORTED, "the split-bf16 kernel addresses the %d feature rows of a k-step with 32-bit offsets (feature stride %lld too large)",
+                        m->ks_rows[ks], (long long)src_feat_stride[sidx]);
+        if (fs4 * 16 >= ((int64_t)1 << 32)) lp.x_wrap = 1;
         lp.xk[ks].base = reinterpret_cast<uint64_t>(sources[sidx]) + (uint64_t)m->ks_feat0[ks] * (uint64_t)fs4;
         lp.xk[ks].rows = (uint32_t)m->ks_rows[ks];
         lp.xk[ks].fs4 = (uint32_t)fs4;
@@ -965,7 +976,7 @@ extern "C" int fv3hip_mlp3_predict(fv3hip_mlp3_t m, const void *const *sources, 
         FV3HIP_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds)); \
         hipLaunchKernelGGL(kern, dim3(grid), dim3(256), lds, st, lp);                                                    \
     }
-    if (m->n_ot == 13) LAUNCH3_(13) else if (m->n_ot == 5) LAUNCH3_(5) else LAUNCH3_(3)
+    if (m->n_ot == 13) LAUNCH3_(13) else if (m->n_ot == 5) LAUNCH3_(5) else if (m->n_ot == 3) LAUNCH3_(3) else LAUNCH3_(1)
 #undef LAUNCH3_
 #undef LAUNCH3R_
     return check_launch("mlp3_kernel");

@@ -12,13 +12,14 @@ three device steps: ``fv3hip_local_pack`` per input -> ``fv3hip_mlp_predict`` on
 ``[n_inputs][nz * ncol]`` array (a point is a sample) -> ``fv3hip_local_unpack`` per output channel.
 """
 import dataclasses
+import os
 from typing import Dict, List, Mapping, Optional, Tuple
 
 import numpy as np
 import torch
 
 from . import _lib
-from .mlp import InputSpec, MlpModel, MlpSpec, OutputSpec
+from .mlp import InputSpec, MlpModel, MlpModelSplitBf16, MlpSpec, OutputSpec
 from .ops import _ptr, _require_device, _stream
 
 
@@ -363,10 +364,17 @@ class _PointModel:
 class LocalMlpModel(_PointModel):
     """Device handle of a dense-local emulator."""
 
-    def __init__(self, spec: LocalMlpSpec, device="cuda"):
+    def __init__(self, spec: LocalMlpSpec, device="cuda", arithmetic: Optional[str] = None):
+        """``arithmetic``: "fp32" (the product kernel) or "split-bf16" (opt-in, experimental: the network on the bf16 matrix
+        cores with every operand split into three bf16 pieces, csrc/mlp_bf16x3.hip); default: the environment variable
+        FV3NET_AMD_EMULATOR_ARITHMETIC, else "fp32".  A network the split kernel does not implement raises here."""
         super().__init__(spec, device)
         k, c = len(spec.inputs), spec.n_channels
-        self._inner = MlpModel(MlpSpec(
+        self.arithmetic = arithmetic or os.environ.get("FV3NET_AMD_EMULATOR_ARITHMETIC", "fp32")
+        if self.arithmetic not in ("fp32", "split-bf16"):
+            raise ValueError(f"arithmetic must be 'fp32' or 'split-bf16', got {self.arithmetic!r}")
+        inner_cls = MlpModelSplitBf16 if self.arithmetic == "split-bf16" else MlpModel
+        self._inner = inner_cls(MlpSpec(
             inputs=[InputSpec("X", k)], hidden_kernels=spec.hidden_kernels, hidden_biases=spec.hidden_biases,
             outputs=[OutputSpec("Y", c)], out_kernel=spec.out_kernel, out_bias=spec.out_bias), device=self.device)
         self.flops_per_point = self._inner.flops_per_sample

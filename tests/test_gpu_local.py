@@ -26,14 +26,18 @@ def _check(got, truth, name, tol=1e-5):
     assert np.max(np.abs(got - truth)) <= tol * scale, (name, np.max(np.abs(got - truth)) / scale)
 
 
+@pytest.mark.parametrize("arithmetic", ["fp32", "split-bf16"])
 @pytest.mark.parametrize("nz,ncol,dtype", [(79, 1024, np.float64), (79, 333, np.float32), (5, 64, np.float64), (1, 97, np.float32)])
-def test_local_regressor_matches_oracle(nz, ncol, dtype):
+def test_local_regressor_matches_oracle(nz, ncol, dtype, arithmetic):
+    """... on the product kernel and on the opt-in split-bf16 arithmetic (1 output tile, a 12-feature first layer)."""
     from fv3net_amd.local_mlp import LocalMlpModel
 
     rng = np.random.default_rng(nz * 1000 + ncol)
     st = cases.state(rng, nz, ncol, dtype)
-    spec = cases.regressor(rng, st, nz, make=cases.product_makers())
-    model = LocalMlpModel(spec, device="cuda")
+    # (the split kernel is built for the production width, 256; the product kernel is also exercised at 64)
+    spec = cases.regressor(rng, st, nz, width=256 if arithmetic == "split-bf16" else 64, make=cases.product_makers())
+    model = LocalMlpModel(spec, device="cuda", arithmetic=arithmetic)
+    assert type(model._inner).__name__ == ("MlpModelSplitBf16" if arithmetic == "split-bf16" else "MlpModel")
     got = model.predict(_dev(st))
     truth = mlp_np.forward_local(spec, {k: v.T for k, v in st.items()}, dtype=np.float64)
     assert list(got) == spec.output_names

@@ -323,6 +323,23 @@ def test_split_bf16_kernel_other_architectures(device, n_hidden, out_feats, n, p
         assert err <= 4 * np.max(np.abs(cpu32[name] - t)) + 2e-7 * scale, (name, err, np.max(np.abs(cpu32[name] - t)))
 
 
+def test_split_bf16_kernel_rows_of_256_mib(device):
+    """Feature rows of 256 MiB and more (the dense-local emulators run 79 x 884 736 points per call): 16 rows no longer fit
+    32-bit offsets, the offsets of the padding rows of a k-step are forced out of range instead of wrapping into it."""
+    from fv3net_amd.mlp import MlpModelSplitBf16
+
+    rng = np.random.default_rng(3)
+    n = 68 * 1024 * 1024  # 272 MiB per row
+    spec = _random_spec(rng, {"a": ("a", 2, 0)}, 256, 2, {"y": 1})
+    x = torch.randn((2, n), device=device, generator=torch.Generator(device=device).manual_seed(1))
+    out = MlpModelSplitBf16(spec, device=device).predict({"a": x})["y"]
+    for lo in (0, n // 2 - 17, n - 4096):
+        host = {"a": np.ascontiguousarray(x[:, lo:lo + 4096].T.cpu().numpy())}
+        truth = mlp_np.forward(spec, host, dtype=np.float64)["y"]
+        got = out[:, lo:lo + 4096].cpu().numpy().T
+        assert np.max(np.abs(got - truth)) <= 1e-5 * np.max(np.abs(truth))
+
+
 def test_split_bf16_kernel_refuses_what_it_does_not_implement(device):
     from fv3net_amd._lib import Fv3HipError
     from fv3net_amd.mlp import MlpModelSplitBf16
