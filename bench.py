@@ -731,6 +731,7 @@ def dense_local_benchmark(dev, steps):
     ms = time_kernel(fn, 2, dev, warm=1)
     flops = 2 * (k * width + 3 * width * width + width * 4)  # the recurrences themselves, without the identity output layers
     achieved = flops * NZ * ncol / (ms * 1e-3) / 1e12
+    ms_rnn_fp32 = ms
     out.append({
         "kernel": "RNN emulator (local_pack + 79 x 2 mlp_fused_kernel launches + local_unpack)",
         "workload": f"C384 precpd regressor: {k} inputs -> 2 x SimpleRNN({width}) over 79 levels -> 4 outputs, {ncol} columns, float32 state",
@@ -738,6 +739,22 @@ def dense_local_benchmark(dev, steps):
         "roofline": {"bound": "mfma", "achieved": achieved, "peak": PEAK_FP32_MFMA_TFLOPS, "unit": "TFLOP/s",
                      "frac": achieved / PEAK_FP32_MFMA_TFLOPS, "traffic": None},
     })
+    del rmodel
+    try:  # the same recurrence on the opt-in split-bf16 arithmetic (EXPLORATORY)
+        rmodel = RnnModel(rspec, device=dev, arithmetic="split-bf16")
+        fn = lambda: rmodel.predict(st)
+        fn()
+        torch.cuda.synchronize(dev)
+        ms3 = time_kernel(fn, 2, dev, warm=1)
+        tf = flops * NZ * ncol / (ms3 * 1e-3) / 1e12
+        out.append({
+            "kernel": "RNN emulator on mlp3_kernel<1> cells (EXPLORATORY split-bf16 arithmetic, opt-in)",
+            "workload": out[-1]["workload"], "ms": ms3, "columns_per_s": ncol / ms3 * 1e3, "fp32_kernel_ms_same_run": ms_rnn_fp32,
+            "roofline": {"bound": "mfma", "achieved": tf, "peak": PEAK_FP32_MFMA_TFLOPS, "unit": "TFLOP/s (fp32-equivalent)",
+                         "frac": tf / PEAK_FP32_MFMA_TFLOPS, "traffic": None}})
+        del rmodel
+    except Exception as err:  # noqa: BLE001
+        out.append({"kernel": "RNN emulator on mlp3_kernel<1> cells", "error": f"{type(err).__name__}: {err}"})
     return out
 
 

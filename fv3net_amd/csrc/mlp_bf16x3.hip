@@ -8,7 +8,8 @@
 // validated against the same float64 oracle (tests/test_gpu_mlp.py::test_split_bf16_kernel_against_oracle).
 //
 // Same graph as mlp.hip (reference lines there): log / centre inputs (1/std folded into the layer-1 weights), Dense + ReLU
-// stack, output heads with scale / centre folded in, optional residual outputs `after = before + difference`.
+// stack, output heads with scale / centre folded in, optional residual outputs `after = before + difference`, optionally the
+// last hidden layer's activations as an output (a recurrent cell's state) and no output layer at all.
 // Restrictions: hidden width 256, float32 sources and outputs that are sample-contiguous, every log epsilon >= FLT_MIN (the
 // fast log), no output limits / masks, 1 / 3 / 5 / 13 output tiles of 32 features.  Anything else: FV3HIP_EUNSUPPORTED.
 //
@@ -78,6 +79,9 @@ struct Mlp3Launch {
     unsigned long long *stamps;  // diagnostic builds only (-DMLP3_STAMPS): [workgroup][wave][8] cycle sums per phase
     int n_ks1, n_log_ks, n_hidden, n_ot, n_residual;
     int x_wrap;            // 16 feature rows span 4 GiB or more: a padding row's 32-bit offset could wrap into range
+    int has_out;           // 0: no output layer at all (a recurrent cell that only returns its state)
+    float *hout;           // the last hidden layer's activations [256][hout_fs] (`hidden_output` of the descriptor), or null
+    int64_t hout_fs;
     int64_t n_samples, n_tiles;
     XStep xk[kMaxKs1];
     const float *src[kMaxSrc];
@@ -179,6 +183,23 @@ __device__ __forceinline__ void patch_exchange_res(uint32_t pw, uint32_t pr, uin
                  : "memory");
 }
 #undef PATCH_V_
+// the exchange alone (hidden activations: no bias, rows by arithmetic)
+__device__ __forceinline__ void patch_exchange_plain(uint32_t pw, uint32_t pr, const float (&v)[16], f32x4 (&t)[4])
+{
+    asm volatile("ds_write_b32 %[pw], %[v0]\n\tds_write_b32 %[pw], %[v1] offset:144\n\tds_write_b32 %[pw], %[v2] offset:288\n\t"
+                 "ds_write_b32 %[pw], %[v3] offset:432\n\tds_write_b32 %[pw], %[v4] offset:1152\n\tds_write_b32 %[pw], %[v5] offset:1296\n\t"
+                 "ds_write_b32 %[pw], %[v6] offset:1440\n\tds_write_b32 %[pw], %[v7] offset:1584\n\tds_write_b32 %[pw], %[v8] offset:2304\n\t"
+                 "ds_write_b32 %[pw], %[v9] offset:2448\n\tds_write_b32 %[pw], %[v10] offset:2592\n\tds_write_b32 %[pw], %[v11] offset:2736\n\t"
+                 "ds_write_b32 %[pw], %[v12] offset:3456\n\tds_write_b32 %[pw], %[v13] offset:3600\n\tds_write_b32 %[pw], %[v14] offset:3744\n\t"
+                 "ds_write_b32 %[pw], %[v15] offset:3888\n\t"
+                 "ds_read_b128 %[t0], %[pr]\n\tds_read_b128 %[t1], %[pr] offset:1152\n\tds_read_b128 %[t2], %[pr] offset:2304\n\t"
+                 "ds_read_b128 %[t3], %[pr] offset:3456\n\ts_waitcnt lgkmcnt(0)"
+                 : [t0] "=&v"(t[0]), [t1] "=&v"(t[1]), [t2] "=&v"(t[2]), [t3] "=&v"(t[3])
+                 : [pw] "v"(pw), [pr] "v"(pr), [v0] "v"(v[0]), [v1] "v"(v[1]), [v2] "v"(v[2]), [v3] "v"(v[3]), [v4] "v"(v[4]), [v5] "v"(v[5]),
+                   [v6] "v"(v[6]), [v7] "v"(v[7]), [v8] "v"(v[8]), [v9] "v"(v[9]), [v10] "v"(v[10]), [v11] "v"(v[11]), [v12] "v"(v[12]),
+                   [v13] "v"(v[13]), [v14] "v"(v[14]), [v15] "v"(v[15])
+                 : "memory");
+}
 __device__ __forceinline__ void rows_read(uint32_t rows, f32x2 (&r)[4])
 {
     asm volatile("ds_read_b64 %0, %4\n\tds_read_b64 %1, %4 offset:64\n\tds_read_b64 %2, %4 offset:128\n\tds_read_b64 %3, %4 offset:192\n\t"
@@ -315,7 +336,7 @@ __global__ __launch_bounds__(256, 1) void mlp3_kernel(const Mlp3Launch p)
     // ---- the weight stream: chunk g of a tile's G = n_ks1 + 16 (n_hidden - 1) + 16 chunks; three LDS buffers, the chunk of
     // k-step g + 2 is requested at the start of k-step g and awaited (this wave's share, then the barrier) at the end of g + 1
     const int n_hid_chunks = p.n_ks1 + 16 * (p.n_hidden - 1);
-    const int G = n_hid_chunks + 16;
+    const int G = n_hid_chunks + (p.has_out ? 16 : 0);
     const __amdgpu_buffer_rsrc_t w_rsrc = __builtin_amdgcn_make_buffer_rsrc(const_cast<f32x4 *>(p.w), 0, p.w_bytes, 0x00020000);
     uint32_t b0 = 0, b1 = CHB, b2 = 2 * CHB;   // LDS byte offsets of the buffers holding chunks g, g + 1, g + 2
     auto chunk_bytes = [&](int g) -> uint32_t {
@@ -343,7 +364,9 @@ __global__ __launch_bounds__(256, 1) void mlp3_kernel(const Mlp3Launch p)
     auto request_ahead = [&](int g, auto kind_c) -> bool {
         constexpr int KIND = decltype(kind_c)::value;
         if constexpr (KIND == 0 || KIND == 1) {   // (made inside the k-step's block: only say where from and where to)
-            dsc.goff = __builtin_amdgcn_readfirstlane(chunk_bytes(g + 2) + wave * 1024);
+            int g2 = g + 2;   // (past the tile's last chunk: the first chunks of the next tile)
+            if (g2 >= G) g2 -= G;
+            dsc.goff = __builtin_amdgcn_readfirstlane(chunk_bytes(g2) + wave * 1024);
             dsc.lds = __builtin_amdgcn_readfirstlane(lds0 + b2 + wave * 1024);
             return KIND == 0;
         } else {
@@ -475,6 +498,10 @@ __global__ __launch_bounds__(256, 1) void mlp3_kernel(const Mlp3Launch p)
             ++g;
         };
         STAMP3_END(0);
+        // The chunk two k-steps ahead of a layer-1 k-step is hidden-type -- and requested inside the block -- when there are more
+        // hidden layers (a later hidden chunk) or no output layer (a first chunk of the next tile).  A single hidden layer in
+        // front of an output layer asks for output-type chunks in its last two k-steps: that layer 1 requests through the
+        // compiler's builtin throughout (two instantiations of the loop, not two of every step: the registers are full).
         auto layer1 = [&](auto kind_c) __attribute__((always_inline)) {
             layer1_step(std::true_type{}, kind_c, 0, xB, tB, tA);
             int ks = 1;
@@ -484,8 +511,8 @@ __global__ __launch_bounds__(256, 1) void mlp3_kernel(const Mlp3Launch p)
             }
             if (ks < p.n_ks1) layer1_step(std::false_type{}, kind_c, ks, xA, tA, tB);
         };
-        if (p.n_hidden >= 2)
-            layer1(std::integral_constant<int, 0>{});   // (every chunk two k-steps ahead of layer 1 is hidden-type)
+        if (p.n_hidden >= 2 || !p.has_out)
+            layer1(std::integral_constant<int, 0>{});
         else
             layer1(std::integral_constant<int, 2>{});
         STAMP3_END(1);
@@ -539,7 +566,37 @@ __global__ __launch_bounds__(256, 1) void mlp3_kernel(const Mlp3Launch p)
             bias_relu(h, h2, l);
             STAMP3_END(2);
         }
+        // ================= the hidden output (`hidden_output` of the descriptor: a recurrent cell's new state) =================
+        if (p.hout) {
+            if constexpr (FAST) {   // through the wave's LDS patch, 16 bytes per lane: 4 stores per 32-feature tile
+                const int64_t qh = tile * 128 + wave * 32 + (lane & 7) * 4;
+                const bool qv = qh < p.n_samples;
+                char *hrow = reinterpret_cast<char *>(p.hout) + ((int64_t)(lane >> 3) * p.hout_fs + (qv ? qh : 0)) * 4;
+                static_for<kHT>([&](auto t_c) {
+                    constexpr int T = decltype(t_c)::value;
+                    float v[16];
+#pragma unroll
+                    for (int r = 0; r < 16; ++r) v[r] = h[T][r];
+                    f32x4 tq[4];
+                    patch_exchange_plain(patch_w, patch_r, v, tq);
+                    if (qv) {
+#pragma unroll
+                        for (int i = 0; i < 4; ++i)   // features 32 T + lane / 8 + 8 i
+                            *reinterpret_cast<global_f32x4 *>(reinterpret_cast<int64_t>(hrow) + (int64_t)(32 * T + 8 * i) * p.hout_fs * 4) = tq[i];
+                    }
+                });
+            } else if (valid) {
+                char *hrow = reinterpret_cast<char *>(p.hout) + (int64_t)nb + (int64_t)(4 * half) * p.hout_fs * 4;
+                static_for<kHT>([&](auto t_c) {
+                    constexpr int T = decltype(t_c)::value;
+#pragma unroll
+                    for (int r = 0; r < 16; ++r)
+                        *reinterpret_cast<global_float *>(reinterpret_cast<int64_t>(hrow) + (int64_t)(32 * T + rho3(r)) * p.hout_fs * 4) = h[T][r];
+                });
+            }
+        }
         // ================= hidden -> outputs =================
+        if (p.has_out) {
         f32x16 y[OT];
         b = b_of(h, std::integral_constant<int, 0>{});
         const int64_t nb64 = nb;
@@ -582,7 +639,10 @@ __global__ __launch_bounds__(256, 1) void mlp3_kernel(const Mlp3Launch p)
             B3 bn;
             if constexpr (KS + 1 < 16) x_of(h, std::integral_constant<int, (KS + 1 < 16 ? KS + 1 : 0)>{}, xn);
             kstep_mfma<OT, KS == 0, (KS + 1 < 16), (KS < 14)>(y, a_lane + b0, b, xn, bn, dsc);
-            fence(std::integral_constant<int, PRE ? (FAST ? 4 : 16) : 0>{}, ah);
+            if (KS == 0 && FAST && p.hout)   // (the 32 stores of the hidden output sit between the last chunk request and this one)
+                fence(std::integral_constant<int, (PRE ? 4 : 0) + (KS == 0 ? 32 : 0)>{}, ah);
+            else
+                fence(std::integral_constant<int, PRE ? (FAST ? 4 : 16) : 0>{}, ah);
             if constexpr (KS + 1 < 16) b = bn;
             ++g;
         });
@@ -654,6 +714,7 @@ __global__ __launch_bounds__(256, 1) void mlp3_kernel(const Mlp3Launch p)
                     if constexpr (T + WIN < OT) load_before(T + WIN, before[T % WIN]);
                 });
         }
+        }   // (has_out)
         STAMP3_END(5);
     }
     // (chunks requested for a tile this workgroup does not have are still in flight towards its LDS)
@@ -689,7 +750,7 @@ using namespace fv3hip;
 
 struct fv3hip_mlp3 {
     int device = 0, n_cu = 256;
-    int n_sources = 0, n_outputs = 0, n_residual = 0, n_hidden = 0, n_ks1 = 0, n_log_ks = 0, n_ot = 0;
+    int n_sources = 0, n_outputs = 0, n_residual = 0, n_hidden = 0, n_ks1 = 0, n_log_ks = 0, n_ot = 0, has_out = 1, hout = 0;
     int64_t flops = 0;
     void *d_w = nullptr, *d_bias = nullptr, *d_center = nullptr, *d_eps = nullptr, *d_ofeat = nullptr, *d_ores = nullptr;
     size_t lds_bytes = 0, lds_fast = 0, w_bytes = 0;
@@ -732,17 +793,20 @@ extern "C" int fv3hip_mlp3_create(const fv3hip_mlp_desc_t *d, fv3hip_mlp3_t *out
 {
     FV3HIP_REQUIRE(d && out, "null pointer");
     *out = nullptr;
-    FV3HIP_REQUIRE(d->n_sources >= 1 && d->n_sources <= kMaxSrc && d->n_inputs >= 1 && d->n_outputs >= 1, "bad counts");
-    FV3HIP_REQUIRE(d->n_outputs + d->n_residual <= kMaxOut, "too many outputs");
-    if (d->width != 256 || d->n_hidden < 1 || d->hidden_activation != FV3HIP_ACT_RELU || d->hidden_output)
-        return fail(FV3HIP_EUNSUPPORTED, "the split-bf16 kernel takes ReLU networks of hidden width 256 without a hidden output");
+    const int hout = d->hidden_output ? 1 : 0;
+    FV3HIP_REQUIRE(d->n_sources >= 1 && d->n_sources <= kMaxSrc && d->n_inputs >= 1, "bad counts");
+    FV3HIP_REQUIRE(d->n_outputs >= 1 || (d->n_outputs == 0 && hout), "n_outputs must be >= 1 (or 0 with hidden_output)");
+    FV3HIP_REQUIRE(d->n_outputs + d->n_residual + hout <= kMaxOut, "too many outputs");
+    if (d->width != 256 || d->n_hidden < 1 || d->hidden_activation != FV3HIP_ACT_RELU)
+        return fail(FV3HIP_EUNSUPPORTED, "the split-bf16 kernel takes ReLU networks of hidden width 256");
     if (d->out_min || d->out_max || d->out_mask)
         return fail(FV3HIP_EUNSUPPORTED, "the split-bf16 kernel does not implement output limits / masks");
     const int W = 256;
     int K = 0, F = 0;
     for (int i = 0; i < d->n_inputs; ++i) K += d->in_nfeat[i];
     for (int j = 0; j < d->n_outputs; ++j) F += d->out_nfeat[j];
-    const int n_ot = (F + 31) / 32;
+    const int has_out = F > 0 ? 1 : 0;
+    const int n_ot = has_out ? (F + 31) / 32 : 1;   // (no output layer: the one-tile instantiation, its output phase skipped)
     if (n_ot != 13 && n_ot != 3 && n_ot != 5 && n_ot != 1)
         return fail(FV3HIP_EUNSUPPORTED, "the split-bf16 kernel is compiled for 1, 3, 5 or 13 output tiles of 32 (got %d outputs)", F);
     // k-slots of layer 1: every input padded to whole k-steps of 16 (a k-step reads 16 consecutive rows of one source), the
@@ -788,6 +852,8 @@ extern "C" int fv3hip_mlp3_create(const fv3hip_mlp_desc_t *d, fv3hip_mlp3_t *out
         m->n_ks1 = (int)slots.size() / 16;
         m->n_log_ks = n_log_slots / 16;
         m->n_ot = n_ot;
+        m->has_out = has_out;
+        m->hout = hout;
         m->flops = 2 * ((int64_t)K * W + (int64_t)(d->n_hidden - 1) * W * W + (int64_t)W * F);
         m->ks_src = ks_src;
         m->ks_feat0 = ks_feat0;
@@ -799,7 +865,9 @@ extern "C" int fv3hip_mlp3_create(const fv3hip_mlp_desc_t *d, fv3hip_mlp3_t *out
     const int n_ks1 = m->n_ks1;
     const int CH_H = 3 * kHT * 64, CH_O = ((3 * n_ot * 64 + 255) / 256) * 256;
     const int n_hid_chunks = n_ks1 + 16 * (d->n_hidden - 1);
-    std::vector<unsigned short> w(((size_t)n_hid_chunks * CH_H + (size_t)16 * CH_O) * 8, 0);
+    if (n_hid_chunks + (has_out ? 16 : 0) < 2)
+        return fail(FV3HIP_EUNSUPPORTED, "the split-bf16 kernel needs at least two k-steps per tile");
+    std::vector<unsigned short> w(((size_t)n_hid_chunks * CH_H + (size_t)(has_out ? 16 : 0) * CH_O) * 8, 0);
     auto put = [&](size_t chunk_base_f4, int nt, int t, int lane, int j, float value) {
         float r = value;
         for (int q = 0; q < 3; ++q) {
@@ -827,7 +895,7 @@ extern "C" int fv3hip_mlp3_create(const fv3hip_mlp_desc_t *d, fv3hip_mlp3_t *out
                     for (int j = 0; j < 8; ++j)
                         put((size_t)(n_ks1 + 16 * (l - 1) + ks) * CH_H, kHT, t, lane, j,
                             d->hidden_kernels[l][(size_t)kfeat(ks, lane >> 5, j) * W + 32 * t + (lane & 31)]);
-    for (int ks = 0; ks < 16; ++ks)
+    for (int ks = 0; ks < (has_out ? 16 : 0); ++ks)
         for (int t = 0; t < n_ot; ++t)
             for (int lane = 0; lane < 64; ++lane)
                 for (int j = 0; j < 8; ++j) {
@@ -911,6 +979,14 @@ extern "C" int fv3hip_mlp3_predict(fv3hip_mlp3_t m, const void *const *sources, 
         lp.out[j] = static_cast<float *>(outputs[j]);
         lp.out_fs[j] = out_feat_stride[j];
     }
+    lp.has_out = m->has_out;
+    if (m->hout) {   // (the hidden output is the last entry of `outputs`, as for fv3hip_mlp_predict)
+        const int j = m->n_outputs + m->n_residual;
+        FV3HIP_REQUIRE(outputs[j], "the hidden output (output %d) is null", j);
+        FV3HIP_REQUIRE(out_feat_stride[j] >= n_samples, "hidden output: feature stride %lld < n_samples", (long long)out_feat_stride[j]);
+        lp.hout = static_cast<float *>(outputs[j]);
+        lp.hout_fs = out_feat_stride[j];
+    }
     lp.w = static_cast<const f32x4 *>(m->d_w);
     lp.bias = static_cast<const float *>(m->d_bias);
     lp.center = static_cast<const float *>(m->d_center);
@@ -956,6 +1032,7 @@ extern "C" int fv3hip_mlp3_predict(fv3hip_mlp3_t m, const void *const *sources, 
         fast = reinterpret_cast<uintptr_t>(outputs[j]) % 16 == 0 && out_feat_stride[j] % 4 == 0;
     for (int r = 0; r < m->n_residual && fast; ++r)
         fast = reinterpret_cast<uintptr_t>(sources[m->res_source[r]]) % 16 == 0 && src_feat_stride[m->res_source[r]] % 4 == 0;
+    if (fast && lp.hout) fast = reinterpret_cast<uintptr_t>(lp.hout) % 16 == 0 && lp.hout_fs % 4 == 0;
     const size_t lds = fast ? m->lds_fast : m->lds_bytes;
 #define LAUNCH3_(OT)                                                                                                     \
     if (m->n_residual) {                                                                                                 \

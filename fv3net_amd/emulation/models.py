@@ -129,8 +129,7 @@ class HipLocalEmulator:
     @property
     def model(self):
         if self._model is None:
-            # (a dense-local model follows FV3NET_AMD_EMULATOR_ARITHMETIC like HipEmulator; the RNN cells use a hidden output,
-            # which the split-bf16 kernel does not implement: they stay on the fp32 kernel)
+            # (both follow FV3NET_AMD_EMULATOR_ARITHMETIC, like HipEmulator)
             cls = RnnModel if isinstance(self.spec, RnnSpec) else LocalMlpModel
             self._model = cls(self.spec, device=compute_device())
         return self._model

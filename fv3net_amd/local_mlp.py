@@ -405,8 +405,13 @@ class RnnModel(_PointModel):
     convolutions, whose rows go straight into the level's slice of the output array.  79 levels x depth launches
     per call, each with ``ncol`` samples; the states ping-pong between two buffers per layer."""
 
-    def __init__(self, spec: RnnSpec, device="cuda", use_graph: bool = False):
+    def __init__(self, spec: RnnSpec, device="cuda", use_graph: bool = False, arithmetic: Optional[str] = None):
+        """``arithmetic``: as for ``LocalMlpModel`` ("fp32" / opt-in "split-bf16"; default from FV3NET_AMD_EMULATOR_ARITHMETIC)."""
         super().__init__(spec, device)
+        self.arithmetic = arithmetic or os.environ.get("FV3NET_AMD_EMULATOR_ARITHMETIC", "fp32")
+        if self.arithmetic not in ("fp32", "split-bf16"):
+            raise ValueError(f"arithmetic must be 'fp32' or 'split-bf16', got {self.arithmetic!r}")
+        cell_cls = MlpModelSplitBf16 if self.arithmetic == "split-bf16" else MlpModel
         # ``use_graph``: capture the level sweep (nz x depth launches) once per (nz, ncol) into a HIP graph on static
         # buffers and replay it.  Bit-identical, but measured to gain nothing (9.90 vs 9.93 ms at the 2 304 columns of a
         # C48 rank): a step there is bound by the ~60 us one 128-sample tile needs on each of the 18 CUs it occupies,
@@ -418,7 +423,7 @@ class RnnModel(_PointModel):
         for n, layer in enumerate(spec.layers):
             fan, ch = int(layer.kernel.shape[0]), int(layer.kernel.shape[1])
             last = n == len(spec.layers) - 1
-            self._cells.append(MlpModel(MlpSpec(
+            self._cells.append(cell_cls(MlpSpec(
                 inputs=[InputSpec("in", fan), InputSpec("rec", ch)],
                 hidden_kernels=[np.concatenate([layer.kernel, layer.recurrent_kernel], axis=0).astype(np.float32)],
                 hidden_biases=[np.asarray(layer.bias, np.float32)], outputs=[OutputSpec("y", c)] if last else [],

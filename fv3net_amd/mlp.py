@@ -408,7 +408,10 @@ class MlpModelSplitBf16:
         self.flops_per_sample = int(_lib.load().fv3hip_mlp3_flops_per_sample(self._handle))
         self.last_variant = "mlp3_kernel"
 
-    def predict(self, sources: Mapping[str, torch.Tensor]) -> Dict[str, torch.Tensor]:
+    def predict(self, sources: Mapping[str, torch.Tensor], out: Optional[Mapping[str, torch.Tensor]] = None) -> Dict[str, torch.Tensor]:
+        """``sources``: name -> float32 ``[feature, sample]`` device array with unit sample stride.  ``out``: preallocated
+        float32 ``[feature, sample]`` arrays (unit sample stride) for any of the outputs -- the hidden output included, as
+        ``MlpModel.predict`` takes them; the others are allocated."""
         spec = self.spec
         tensors = []
         for name in spec.sources:
@@ -422,7 +425,18 @@ class MlpModelSplitBf16:
         nfeat = {o.name: o.nfeat for o in spec.outputs}
         for r in spec.residuals:
             nfeat[r.name] = nfeat[r.output]
-        outs = {name: torch.empty((nfeat[name], n), dtype=torch.float32, device=dev) for name in spec.output_names}
+        if spec.hidden_output:
+            nfeat[spec.hidden_output] = spec.width
+        outs = {}
+        for name in spec.output_names:
+            given = None if out is None else out.get(name)
+            if given is None:
+                outs[name] = torch.empty((nfeat[name], n), dtype=torch.float32, device=dev)
+                continue
+            g2 = given.unsqueeze(0) if given.dim() == 1 else given
+            if g2.dtype != torch.float32 or tuple(g2.shape) != (nfeat[name], n) or g2.stride(1) != 1 or g2.device != dev:
+                raise TypeError(f"out[{name!r}] must be a float32 [{nfeat[name]}, {n}] array with unit sample stride on {dev}")
+            outs[name] = g2
         ol = [outs[name] for name in spec.output_names]
         ns, no = len(tensors), len(ol)
         _lib.call_on(dev, "fv3hip_mlp3_predict", self._handle, (ctypes.c_void_p * ns)(*[t.data_ptr() for t in tensors]),

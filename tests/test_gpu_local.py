@@ -187,6 +187,28 @@ def test_hook_with_classifier_and_classifier_masks(tmp_path):
         np.testing.assert_array_equal(state[k], before[k])
 
 
+@pytest.mark.parametrize("nz,ncol,dtype", [(79, 256, np.float64), (17, 333, np.float32)])
+def test_rnn_emulator_on_split_bf16_arithmetic(nz, ncol, dtype):
+    """The same recurrence with its cells on the opt-in split-bf16 kernel (hidden output = the new state, cells without an
+    output layer, a cell with one): against the float64 oracle with the bar of the fp32 path."""
+    from fv3net_amd.local_mlp import RnnModel
+
+    rng = np.random.default_rng(nz + ncol)
+    st = cases.state(rng, nz, ncol, dtype)
+    spec = cases.precpd_rnn(rng, st, nz, channels=256, make=cases.product_makers())
+    model = RnnModel(spec, device="cuda", arithmetic="split-bf16")
+    assert all(type(c).__name__ == "MlpModelSplitBf16" for c in model._cells)
+    got = model.predict(_dev(st))
+    truth = mlp_np.forward_rnn(spec, {k: v.T for k, v in st.items()}, dtype=np.float64)
+    f32 = mlp_np.forward_rnn(spec, {k: v.T for k, v in st.items()}, dtype=np.float32)
+    for name in spec.output_names:
+        g, t = got[name].cpu().numpy(), truth[name].T
+        assert g.shape == t.shape, name
+        scale = np.max(np.abs(t))
+        e_gpu, e_f32 = np.max(np.abs(g - t)), np.max(np.abs(f32[name].T - t))
+        assert e_gpu <= 1e-5 * scale + 4 * e_f32, (name, e_gpu / scale, e_f32 / scale)
+
+
 @pytest.mark.parametrize("nz,ncol,dtype,channels", [(79, 256, np.float64, 256), (17, 333, np.float32, 64), (5, 64, np.float64, 32)])
 def test_rnn_emulator_matches_oracle(nz, ncol, dtype, channels, tmp_path):
     """The production precpd architecture (stacked SimpleRNNs over the levels, surface-step single-level output,
