@@ -415,7 +415,7 @@ def secondary_benchmarks(dev, steps):
     return out
 
 
-def restart_pipeline_benchmark(dev, n=384, f=8, reps=3, tiles=tuple(range(6)), which=("sigma", "pressure", "blended"), sync=None,
+def restart_pipeline_benchmark(dev, n=384, f=8, reps=6, tiles=tuple(range(6)), which=("sigma", "pressure", "blended"), sync=None,
                                graph=True):
     """BASELINE configs[2] end to end: the three restart coarse-graining pipelines (vcm coarsen_restarts_on_sigma /
     _on_pressure / _via_blended_method, all four restart categories, 'complex' surface method) C384 -> C48 on float64
