@@ -79,7 +79,9 @@ struct Mlp3Launch {
     unsigned long long *stamps;  // diagnostic builds only (-DMLP3_STAMPS): [workgroup][wave][8] cycle sums per phase
     int n_ks1, n_log_ks, n_hidden, n_ot, n_residual;
     int x_wrap;            // 16 feature rows span 4 GiB or more: a padding row's 32-bit offset could wrap into range
-    int has_out;           // 0: no output layer at all (a recurrent cell that only returns its state)
+    int has_out;           // 0: no output layer on the matrix cores (none at all, or the small one below)
+    int small_out;         // 1..4 output features without residuals: the output layer is 128 x F fp32 FMAs per lane
+    const float *wsmall;   // its weights [8 tiles][4 outputs][2 halves][16 registers] (scale folded in) + [4] biases (centre folded in)
     float *hout;           // the last hidden layer's activations [256][hout_fs] (`hidden_output` of the descriptor), or null
     int64_t hout_fs;
     int64_t n_samples, n_tiles;
@@ -330,6 +332,12 @@ __global__ __launch_bounds__(256, 1) void mlp3_kernel(const Mlp3Launch p)
             const int t = i >> 5, fl = i & 31, hf = (fl >> 2) & 1, r = (fl & 3) + 4 * (fl >> 3);   // fl = rho3(r) + 4 hf
             bias_f[i] = p.bias[((p.n_hidden * kHT + t) * 2 + hf) * 16 + r];
         }
+    }
+    // the small output layer's weights behind everything else: [8 tiles][4 outputs][2 halves][16] floats + 4 biases
+    const uint32_t tail_off = 3 * CHB + (p.n_hidden * kHT + OT) * 128 + p.n_ks1 * 128 + 3 * OT * 256 + (FAST ? 4 * (32 * kPatchRow) + OT * 128 : 0);
+    if (p.small_out) {
+        float *ws = reinterpret_cast<float *>(smem + tail_off);
+        for (int i = tid; i < 8 * 4 * 2 * 16 + 4; i += 256) ws[i] = p.wsmall[i];
     }
     __syncthreads();
 
@@ -595,6 +603,38 @@ __global__ __launch_bounds__(256, 1) void mlp3_kernel(const Mlp3Launch p)
                 });
             }
         }
+        // ================= a small output layer (<= 4 features, no residuals) on the vector ALU =================
+        // 16 k-steps of 6 MFMAs each would cost ~10 000 cycles of barriers and LDS round trips for 1.5 % of the tile's
+        // arithmetic; here: 128 x 4 fp32 FMAs per lane on its half of the features, one cross-half exchange, one store per output.
+        if (p.small_out) {
+            float acc[4] = {0.f, 0.f, 0.f, 0.f};
+            const uint32_t wl = lds0 + tail_off + half * 64;
+            auto two_outputs = [&](auto cp_c) {   // outputs CP and CP + 1 (two at a time: 32 registers of weights beside the 128 of h)
+                constexpr int CP = decltype(cp_c)::value;
+                static_for<kHT>([&](auto t_c) {
+                    constexpr int T = decltype(t_c)::value;
+                    f32x4 wq[8];
+                    lds_read2x64_sync(wl + T * 512 + CP * 128, wq);
+#pragma unroll
+                    for (int c = 0; c < 2; ++c)
+#pragma unroll
+                        for (int r = 0; r < 16; ++r) acc[CP + c] = __builtin_fmaf(h[T][r], wq[c * 4 + (r >> 2)][r & 3], acc[CP + c]);
+                });
+            };
+            two_outputs(std::integral_constant<int, 0>{});
+            if (p.small_out > 2) two_outputs(std::integral_constant<int, 2>{});
+            const float *bs = reinterpret_cast<const float *>(smem + tail_off) + 8 * 4 * 2 * 16;
+#pragma unroll
+            for (int c = 0; c < 4; ++c) {
+                const float other = __shfl_xor(acc[c], 32);   // the other half's 128 features of the same sample
+                const float yv = acc[c] + other + bs[c];
+                if (c < p.small_out) {
+                    const int of = p.ofeat[c];
+                    const int64_t row = reinterpret_cast<int64_t>(p.out[of >> 20]) + (int64_t)(of & 0xFFFFF) * p.out_fs[of >> 20] * 4;
+                    if (valid && half == 0) *reinterpret_cast<global_float *>(row + (int64_t)nb) = yv;
+                }
+            }
+        }
         // ================= hidden -> outputs =================
         if (p.has_out) {
         f32x16 y[OT];
@@ -750,7 +790,8 @@ using namespace fv3hip;
 
 struct fv3hip_mlp3 {
     int device = 0, n_cu = 256;
-    int n_sources = 0, n_outputs = 0, n_residual = 0, n_hidden = 0, n_ks1 = 0, n_log_ks = 0, n_ot = 0, has_out = 1, hout = 0;
+    int n_sources = 0, n_outputs = 0, n_residual = 0, n_hidden = 0, n_ks1 = 0, n_log_ks = 0, n_ot = 0, has_out = 1, hout = 0, small_out = 0;
+    void *d_wsmall = nullptr;
     int64_t flops = 0;
     void *d_w = nullptr, *d_bias = nullptr, *d_center = nullptr, *d_eps = nullptr, *d_ofeat = nullptr, *d_ores = nullptr;
     size_t lds_bytes = 0, lds_fast = 0, w_bytes = 0;
@@ -780,7 +821,7 @@ extern "C" void fv3hip_diag_set_mlp3_stamps(void *p) { g_mlp3_stamps = static_ca
 extern "C" int fv3hip_mlp3_destroy(fv3hip_mlp3_t m)
 {
     if (!m) return FV3HIP_OK;
-    for (void *q : {m->d_w, m->d_bias, m->d_center, m->d_eps, m->d_ofeat, m->d_ores})
+    for (void *q : {m->d_w, m->d_bias, m->d_center, m->d_eps, m->d_ofeat, m->d_ores, m->d_wsmall})
         if (q) hipFree(q);
     if (m->d_sink) hipFree(m->d_sink);
     delete m;
@@ -805,8 +846,9 @@ extern "C" int fv3hip_mlp3_create(const fv3hip_mlp_desc_t *d, fv3hip_mlp3_t *out
     int K = 0, F = 0;
     for (int i = 0; i < d->n_inputs; ++i) K += d->in_nfeat[i];
     for (int j = 0; j < d->n_outputs; ++j) F += d->out_nfeat[j];
-    const int has_out = F > 0 ? 1 : 0;
-    const int n_ot = has_out ? (F + 31) / 32 : 1;   // (no output layer: the one-tile instantiation, its output phase skipped)
+    const int small_out = (F >= 1 && F <= 4 && d->n_residual == 0) ? F : 0;   // (output layer on the vector ALU, see the kernel)
+    const int has_out = (F > 0 && !small_out) ? 1 : 0;
+    const int n_ot = has_out ? (F + 31) / 32 : 1;   // (no output layer on the matrix cores: the one-tile instantiation, that phase skipped)
     if (n_ot != 13 && n_ot != 3 && n_ot != 5 && n_ot != 1)
         return fail(FV3HIP_EUNSUPPORTED, "the split-bf16 kernel is compiled for 1, 3, 5 or 13 output tiles of 32 (got %d outputs)", F);
     // k-slots of layer 1: every input padded to whole k-steps of 16 (a k-step reads 16 consecutive rows of one source), the
@@ -853,6 +895,7 @@ extern "C" int fv3hip_mlp3_create(const fv3hip_mlp_desc_t *d, fv3hip_mlp3_t *out
         m->n_log_ks = n_log_slots / 16;
         m->n_ot = n_ot;
         m->has_out = has_out;
+        m->small_out = small_out;
         m->hout = hout;
         m->flops = 2 * ((int64_t)K * W + (int64_t)(d->n_hidden - 1) * W * W + (int64_t)W * F);
         m->ks_src = ks_src;
@@ -936,8 +979,20 @@ extern "C" int fv3hip_mlp3_create(const fv3hip_mlp_desc_t *d, fv3hip_mlp3_t *out
             }
         }
     }
+    std::vector<float> wsmall;
+    if (small_out) {   // [tile][output c][half][register r] <- out_kernel[feature 32 t + rho3(r) + 4 half][c] * scale_c; then the biases
+        wsmall.assign(8 * 4 * 2 * 16 + 4, 0.f);
+        for (int t = 0; t < kHT; ++t)
+            for (int c = 0; c < F; ++c)
+                for (int hf = 0; hf < 2; ++hf)
+                    for (int r = 0; r < 16; ++r)
+                        wsmall[((t * 4 + c) * 2 + hf) * 16 + r] =
+                            d->out_kernel[(size_t)(32 * t + rho3(r) + 4 * hf) * F + c] * (d->out_scale ? d->out_scale[c] : 1.f);
+        for (int c = 0; c < F; ++c)
+            wsmall[8 * 4 * 2 * 16 + c] = (float)((double)d->out_bias[c] * (d->out_scale ? d->out_scale[c] : 1.f) + (d->out_center ? d->out_center[c] : 0.f));
+    }
     int rc;
-    if ((rc = upload3(w, &m->d_w)) || (rc = upload3(bias, &m->d_bias)) || (rc = upload3(center, &m->d_center)) ||
+    if ((rc = upload3(wsmall, &m->d_wsmall)) || (rc = upload3(w, &m->d_w)) || (rc = upload3(bias, &m->d_bias)) || (rc = upload3(center, &m->d_center)) ||
         (rc = upload3(eps, &m->d_eps)) || (rc = upload3(ofeat, &m->d_ofeat)) || (rc = upload3(ores, &m->d_ores))) {
         fv3hip_mlp3_destroy(m);
         *out = nullptr;
@@ -947,6 +1002,10 @@ extern "C" int fv3hip_mlp3_create(const fv3hip_mlp_desc_t *d, fv3hip_mlp3_t *out
     m->w_bytes = w.size() * sizeof(unsigned short);
     m->lds_bytes = 3 * ch_max * 16 + (size_t)(d->n_hidden * kHT + n_ot) * 128 + (size_t)slots.size() * 8 + (size_t)n_ot * 32 * 24;
     m->lds_fast = m->lds_bytes + 4 * 32 * 36 * 4 + (size_t)n_ot * 128;   // + a transposition patch per wave and the output biases by feature
+    if (small_out) {   // + the small output layer's table (behind everything else in both layouts)
+        m->lds_bytes += 8 * 4 * 2 * 16 * 4 + 16;
+        m->lds_fast += 8 * 4 * 2 * 16 * 4 + 16;
+    }
     if (m->lds_bytes > 160 * 1024) {
         fv3hip_mlp3_destroy(m);
         *out = nullptr;
@@ -980,6 +1039,8 @@ extern "C" int fv3hip_mlp3_predict(fv3hip_mlp3_t m, const void *const *sources, 
         lp.out_fs[j] = out_feat_stride[j];
     }
     lp.has_out = m->has_out;
+    lp.small_out = m->small_out;
+    lp.wsmall = static_cast<const float *>(m->d_wsmall);
     if (m->hout) {   // (the hidden output is the last entry of `outputs`, as for fv3hip_mlp_predict)
         const int j = m->n_outputs + m->n_residual;
         FV3HIP_REQUIRE(outputs[j], "the hidden output (output %d) is null", j);
