@@ -255,3 +255,15 @@ def test_interval_schedule_and_time_mask_known_answers():
     mask = TimeMask(IntervalSchedule(datetime.timedelta(hours=2), (2016, 8, 1)))
     assert mask({"a": 5.0, "model_time": [2016, 8, 1, 0, 0, 30]}, {"a": 1.0}) == {"a": 5.0}   # 00:30 -> first half: physics
     assert mask({"a": 5.0, "model_time": [2016, 8, 1, 0, 1, 30]}, {"a": 1.0}) == {"a": 1.0}   # 01:30 -> second half: emulator
+
+
+def test_graphed_call_needs_a_gpu():
+    """No silent eager fallback: without a ROCm device GraphedCall refuses."""
+    import torch
+
+    from fv3net_amd.graphs import GraphedCall
+
+    if torch.cuda.is_available():
+        pytest.skip("a GPU is present")
+    with pytest.raises(RuntimeError, match="cuda"):
+        GraphedCall(lambda: None)
