@@ -103,6 +103,37 @@ __global__ __launch_bounds__(256) void mask_weights_coarse_kernel(const Tw *__re
     out[(b * nz + k) * n_inner + c] = (level < ps) ? w[(b / w_repeat) * n_inner + c] : (Tw)0;
 }
 
+// ... four columns of one row per thread (nx % 4 == 0, f >= 4: the four share their row and at most two coarse columns), 16-byte
+// accesses, one division per four elements
+template <typename Tw, typename Tp>
+__global__ __launch_bounds__(256) void mask_weights_coarse4_kernel(const Tw *__restrict__ w, const Tp *__restrict__ pc, const Tp *__restrict__ pf,
+                                                                   Tw *__restrict__ out, int nz, int64_t n_inner, int nx, int f, int nxc,
+                                                                   int64_t plane2, int64_t w_repeat, int cmp_levels, int cmp_offset)
+{
+    const int64_t c = ((int64_t)blockIdx.x * 256 + threadIdx.x) * 4;
+    if (c >= n_inner) return;
+    const int64_t b = blockIdx.y / nz;
+    const int k = (int)(blockIdx.y - b * nz);
+    const unsigned int y = (unsigned int)c / (unsigned int)nx, x = (unsigned int)c - y * (unsigned int)nx;
+    const unsigned int xc = x / (unsigned int)f, rem = x - xc * (unsigned int)f;
+    const Tp *lv = pc + (b * cmp_levels + (k + cmp_offset)) * plane2 + (int64_t)(y / f) * nxc + xc;
+    const Tp l0 = lv[0], l1 = (rem + 3 >= (unsigned int)f) ? lv[1] : l0;   // (x + 3 stays inside the row: its coarse column exists)
+    const Tp *ps = pf + (b * (nz + 1) + nz) * n_inner + c;
+    const Tw *wr = w + (b / w_repeat) * n_inner + c;
+    Tw *o = out + (b * nz + k) * n_inner + c;
+    Tp p4[4];
+    Tw w4[4], r4[4];
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        p4[i] = ps[i];
+        w4[i] = wr[i];
+    }
+#pragma unroll
+    for (int i = 0; i < 4; ++i) r4[i] = (((rem + i >= (unsigned int)f) ? l1 : l0) < p4[i]) ? w4[i] : (Tw)0;
+#pragma unroll
+    for (int i = 0; i < 4; ++i) o[i] = r4[i];
+}
+
 // pressure_at_midpoint_log: delp / diff(log(p_interface)), sequential down the column
 template <typename T>
 __global__ void pressure_at_midpoint_log_kernel(const T *__restrict__ delp, T *__restrict__ out,
@@ -1253,10 +1284,19 @@ extern "C" int fv3hip_mask_weights_coarse(const void *weights, int w_dtype, cons
     const int nyc = coarse_extent(ny, factor), nxc = coarse_extent(nx, factor);
     const int64_t plane2 = (int64_t)nyc * nxc;
     const dim3 grid((unsigned)ceil_div(n_inner, 256), (unsigned)(n_batch * nz));
+    // four columns per thread where a row is whole quads of 16-byte aligned columns (a staggered x dim is not: 385 columns)
+    const bool quads = nx % 4 == 0 && factor >= 4 && reinterpret_cast<uintptr_t>(weights) % 16 == 0 &&
+                       reinterpret_cast<uintptr_t>(p_fine) % 32 == 0 && reinterpret_cast<uintptr_t>(out) % 16 == 0;
+    const dim3 grid4((unsigned)ceil_div(n_inner, 1024), (unsigned)(n_batch * nz));
 #define LAUNCH_(TW, TP)                                                                                                            \
-    hipLaunchKernelGGL((mask_weights_coarse_kernel<TW, TP>), grid, dim3(256), 0, st, static_cast<const TW *>(weights),            \
-                       static_cast<const TP *>(p_cmp_coarse), static_cast<const TP *>(p_fine), static_cast<TW *>(out), nz, n_inner, nx, factor, \
-                       nxc, plane2, w_repeat, cmp_levels, cmp_offset)
+    if (quads)                                                                                                                     \
+        hipLaunchKernelGGL((mask_weights_coarse4_kernel<TW, TP>), grid4, dim3(256), 0, st, static_cast<const TW *>(weights),      \
+                           static_cast<const TP *>(p_cmp_coarse), static_cast<const TP *>(p_fine), static_cast<TW *>(out), nz, n_inner, nx, \
+                           factor, nxc, plane2, w_repeat, cmp_levels, cmp_offset);                                                 \
+    else                                                                                                                           \
+        hipLaunchKernelGGL((mask_weights_coarse_kernel<TW, TP>), grid, dim3(256), 0, st, static_cast<const TW *>(weights),        \
+                           static_cast<const TP *>(p_cmp_coarse), static_cast<const TP *>(p_fine), static_cast<TW *>(out), nz, n_inner, nx, factor, \
+                           nxc, plane2, w_repeat, cmp_levels, cmp_offset)
     if (w_dtype == FV3HIP_F32 && p_dtype == FV3HIP_F32) LAUNCH_(float, float);
     else if (w_dtype == FV3HIP_F32) LAUNCH_(float, double);
     else if (p_dtype == FV3HIP_F32) LAUNCH_(double, float);
