@@ -58,6 +58,23 @@ __device__ __forceinline__ float v_get(f32x2 a, int i) { return a[i]; }
 __device__ __forceinline__ void v_set(float &a, int, float x) { a = x; }
 __device__ __forceinline__ void v_set(f32x2 &a, int i, float x) { a[i] = x; }
 
+// FAST-mode primitives.  The exact mode keeps the reference's compare-and-select minima (a NaN operand picks the second
+// argument, as the compiled Fortran does) and never contracts; the fast mode takes the hardware's v_min3 / v_max3 (one
+// 4-cycle instruction instead of two compares and two selects, 12 cycles -- measured issue costs in
+// benchmarks/valu_ubench) and fused multiply-adds (2 cycles for a multiply and an add).
+__device__ __forceinline__ float hw_min3(float a, float b, float c) { float r; asm("v_min3_f32 %0, %1, %2, %3" : "=v"(r) : "v"(a), "v"(b), "v"(c)); return r; }
+__device__ __forceinline__ float hw_max3(float a, float b, float c) { float r; asm("v_max3_f32 %0, %1, %2, %3" : "=v"(r) : "v"(a), "v"(b), "v"(c)); return r; }
+__device__ __forceinline__ float hw_min3_abs(float a, float b, float c) { float r; asm("v_min3_f32 %0, |%1|, %2, %3" : "=v"(r) : "v"(a), "v"(b), "v"(c)); return r; }
+__device__ __forceinline__ f32x2 hw_min3(f32x2 a, f32x2 b, f32x2 c) { return f32x2{hw_min3(a[0], b[0], c[0]), hw_min3(a[1], b[1], c[1])}; }
+__device__ __forceinline__ f32x2 hw_max3(f32x2 a, f32x2 b, f32x2 c) { return f32x2{hw_max3(a[0], b[0], c[0]), hw_max3(a[1], b[1], c[1])}; }
+__device__ __forceinline__ f32x2 hw_min3_abs(f32x2 a, f32x2 b, f32x2 c) { return f32x2{hw_min3_abs(a[0], b[0], c[0]), hw_min3_abs(a[1], b[1], c[1])}; }
+__device__ __forceinline__ float v_fma(float a, float b, float c) { return __builtin_fmaf(a, b, c); }
+__device__ __forceinline__ f32x2 v_fma(f32x2 a, f32x2 b, f32x2 c) { return __builtin_elementwise_fma(a, b, c); }
+__device__ __forceinline__ f32x2 v_fma(float a, f32x2 b, f32x2 c) { return __builtin_elementwise_fma(f32x2{a, a}, b, c); }
+__device__ __forceinline__ f32x2 v_fma(f32x2 a, float b, f32x2 c) { return __builtin_elementwise_fma(a, f32x2{b, b}, c); }
+__device__ __forceinline__ auto v_or(bool a, bool b) { return a | b; }
+__device__ __forceinline__ i32x2 v_or(i32x2 a, i32x2 b) { return a | b; }
+
 // A denominator (always a pressure-only scalar): EXACT keeps the value and divides (IEEE) at every use, FAST takes the
 // reciprocal once.
 template <bool FAST>
@@ -86,20 +103,49 @@ __device__ __forceinline__ void limit0(V dm, V q, V &al, V &ar, V &a6)
     a6 = v_sel(flat, v_splat(q, 0.f), na6);
 }
 
+// The same constraint for the fast mode: flatten first (al = ar = q makes a6 = 0 and both tests false), then ONE kept edge
+// e -- the left one where the parabola undershoots, the right one where it overshoots -- gives a6 = 3 (e - q) and the other
+// edge e - a6: 3 compares, 6 selects, 11 arithmetic instructions per field.  Also returns da1 = ar - al for the emit code.
+template <typename V>
+__device__ __forceinline__ void limit0_fast(V dm, V q, V &al, V &ar, V &a6, V &da1)
+{
+    const auto flat = (dm == v_splat(dm, 0.f));
+    al = v_sel(flat, q, al);
+    ar = v_sel(flat, q, ar);
+    da1 = ar - al;
+    a6 = 3.f * v_fma(v_splat(q, 2.f), q, -(al + ar));
+    const V da2 = da1 * da1, a6da = a6 * da1;
+    const auto lo = a6da < -da2, hi = a6da > da2;
+    const V e = v_sel(lo, al, ar);
+    const V a6n = 3.f * (e - q);
+    const V oth = e - a6n;
+    a6 = v_sel(v_or(lo, hi), a6n, a6);
+    ar = v_sel(lo, oth, ar);
+    al = v_sel(hi, oth, al);
+    da1 = ar - al;
+}
+
 template <typename Tin>
 __device__ __forceinline__ float ld(const char *base, unsigned int boff)
 {
     return (float)*reinterpret_cast<const Tin *>(base + boff);
 }
 
-template <typename Tin, int NV, int W, bool FAST>
+// Dynamic LDS of a wave: [target interfaces: kRing rows x 64 lanes, or (TGT) the whole (kn + 1) x 8 table][result ring]
+extern __shared__ float sweep_lds[];
+constexpr int kSweepRing = 16, kSweepOut = 8;
+
+template <typename Tin, int NV, int W, bool FAST, bool TGT>
 __global__ __launch_bounds__(64) void mappm_sweep_kernel(const SweepArgs a)
 {
     using V = typename FieldVec<W>::type;
     constexpr int NF = NV * W;
     constexpr unsigned int ESZ = sizeof(Tin);
     const int lane = threadIdx.x;
-    const int64_t wcol = a.col0 + (int64_t)blockIdx.x * 64;  // first column of the wave (uniform)
+    // Workgroups go round-robin over the 8 XCDs (each with its own L2): give every XCD a contiguous eighth of the waves, so
+    // the waves resident on one XCD at a time read neighbouring 256 / 512-byte pieces of a row.
+    const unsigned int nwg = gridDim.x, wid = (nwg % 8u == 0u) ? (blockIdx.x % 8u) * (nwg / 8u) + blockIdx.x / 8u : blockIdx.x;
+    const int64_t wcol = a.col0 + (int64_t)wid * 64;  // first column of the wave (uniform)
     const int64_t b = wcol / a.n_inner, c0 = wcol - b * a.n_inner;
     const int km = a.km, kn = a.kn, iv = a.iv;
     const int64_t plane = a.n_inner;
@@ -157,6 +203,29 @@ __global__ __launch_bounds__(64) void mappm_sweep_kernel(const SweepArgs a)
                      const V *qc, const V *dca, V *dcb, V *alb, float &d4c_out, Den<FAST> &r4c_out) {
         const float d4a = z + x, d4c = y + w;
         const Den<FAST> r4c(d4c);
+        if constexpr (FAST) {
+            // everything that multiplies a field difference is folded into pressure-only factors first:
+            //   df2 = k1 (qc - qb) + k2 (qb - qa),   al = qa + c1f h + m2 dc(k-1) - m1 dc(k),   c1f = (qb - qa) xr
+            const float yr = y * __builtin_amdgcn_rcpf(d4b_ + w);
+            const float k1 = __builtin_fmaf(0.5f, y, x) * r4c.v * yr, k2 = __builtin_fmaf(0.5f, y, w) * r4b.v * yr;
+            const float a1 = d4a * __builtin_amdgcn_rcpf(d4b_ + x), a2 = d4c * __builtin_amdgcn_rcpf(d4b_ + y);
+            const float g = 2.f * __builtin_amdgcn_rcpf(d4a + d4c), gy = g * y;
+            const float h = __builtin_fmaf(gy, a1 - a2, 1.f), m2 = gy * a2, m1 = g * x * a1;
+            const float xr = x * r4b.v;
+#pragma unroll
+            for (int v = 0; v < NV; ++v) {
+                const V dqa = qb[v] - qa[v], dqc = qc[v] - qb[v];
+                const V df2 = v_fma(v_splat(dqc, k1), dqc, k2 * dqa);
+                // (the hardware minima drop a NaN operand where the reference's compare-and-select chain keeps the one of
+                // q(k) or q(k+1): 0 * (qc - qb) puts exactly that NaN back, so a NaN in a field poisons the same levels)
+                const V dc = v_fma(v_splat(dqc, 0.f), dqc,
+                                   v_sign(hw_min3_abs(df2, hw_max3(qa[v], qb[v], qc[v]) - qb[v], qb[v] - hw_min3(qa[v], qb[v], qc[v])), df2));
+                V t = v_fma(dqa * xr, v_splat(dqa, h), qa[v]);
+                t = v_fma(v_splat(dqa, m2), dca[v], t);
+                alb[v] = v_fma(v_splat(dqa, -m1), dc, t);
+                dcb[v] = dc;
+            }
+        } else {
         const float c1 = r4c.under(x + 0.5f * y);          // (dp(k-1) + 0.5 dp(k)) / d4(k+1)
         const float c2 = r4b.under(w + 0.5f * y);          // (dp(k+1) + 0.5 dp(k)) / d4(k)
         const Den<FAST> r3p(d4b_ + w);                     // d4(k) + dp(k+1)
@@ -171,6 +240,7 @@ __global__ __launch_bounds__(64) void mappm_sweep_kernel(const SweepArgs a)
             const V c1f = r4b.under((qb[v] - qa[v]) * x);
             alb[v] = qa[v] + c1f + g * (y * (c1f * a12 + a2 * dca[v]) - xa1 * dc);
             dcb[v] = dc;
+        }
         }
         d4c_out = d4c;
         r4c_out = r4c;
@@ -239,16 +309,42 @@ __global__ __launch_bounds__(64) void mappm_sweep_kernel(const SweepArgs a)
     // cursor is within kAhead rows of it (at most two rows per source layer, scalar bookkeeping) and written to the ring
     // at the top of the next iteration.  A lane whose cursor has left the window [jl - kRing, jl) -- grids whose lanes
     // drift apart by more than the ring holds -- reads its interface from memory instead: slower, same value.
-    constexpr int kRing = 16, kAhead = 9;
-    __shared__ float ring_lds[kRing * 64];
-    float *ring = ring_lds + lane;
+    //
+    // TGT (round 3) -- what the restart pipelines launch: the target grid is coarser by a power of two f >= 8 and a wave's
+    // 64 columns lie in one fine row (nx % 64 == 0), so the wave has only 64 / f <= 8 DISTINCT target columns.  All their
+    // kn + 1 interfaces fit in (kn + 1) x 8 floats of LDS (2.5 KB at kn = 79), read once up front from the (L2-resident)
+    // coarse array: no ring, no window bookkeeping, no interface requests inside the loop and -- the point -- no lane ever
+    // leaves a window.  On BASELINE configs[2]'s synthetic grid (delp ~ U(300, 1500) iid per cell) the lanes of a wave are
+    // spread over ~16 target rows at the bottom of the column and most waves took the ring's memory path (a full round trip
+    // behind `s_waitcnt vmcnt(0)`) on every level of the lower two thirds.
+    constexpr int kRing = kSweepRing, kAhead = 9;
+    float *ring = sweep_lds + lane;
     unsigned int lane2 = (unsigned int)lane * ESZ;
-    if (coarse2) {
+    if (coarse2 && !TGT) {
         const unsigned int c = (unsigned int)c0 + lane, y = c / (unsigned int)a.nx, x = c - y * (unsigned int)a.nx;
         lane2 = ((y / (unsigned int)a.pe2_f) * (unsigned int)a.pe2_nx + x / (unsigned int)a.pe2_f) * ESZ;
     }
-    int jl, jr;  // interface rows (0-based) [0, jl) have landed in the ring, [jl, jr) are in flight (pv0, pv1)
-    {
+    int jl = 0, jr = 0;  // interface rows (0-based) [0, jl) have landed in the ring, [jl, jr) are in flight (pv0, pv1)
+    const float *tgt = sweep_lds;
+    if constexpr (TGT) {
+        const unsigned int y = (unsigned int)c0 / (unsigned int)a.nx, x0 = (unsigned int)c0 - y * (unsigned int)a.nx;
+        const unsigned int sh = 31u - (unsigned int)__builtin_clz((unsigned int)a.pe2_f);  // log2 f
+        const unsigned int cell0 = (y >> sh) * (unsigned int)a.pe2_nx + (x0 >> sh), cells = 64u >> sh;
+        tgt = sweep_lds + (lane >> sh);
+        const int n = (kn + 1) * 8;
+        constexpr int kTrips = 16;  // (kn + 1) * 8 <= 1024 (host)
+        Tin tmp[kTrips];
+#pragma unroll
+        for (int j = 0; j < kTrips; ++j) {
+            const int i = lane + 64 * j, row = i >> 3;
+            const unsigned int cell = (unsigned int)(i & 7);
+            // (unconditional, clamped: sixteen requests in flight, one wait)
+            tmp[j] = *reinterpret_cast<const Tin *>(pe2_b + (size_t)(row <= kn ? row : kn) * row_p2 + (size_t)(cell0 + (cell < cells ? cell : cells - 1u)) * ESZ);
+        }
+#pragma unroll
+        for (int j = 0; j < kTrips; ++j)
+            if (lane + 64 * j < n) sweep_lds[lane + 64 * j] = (float)tmp[j];
+    } else {
         float tmp[kRing];
 #pragma unroll
         for (int i = 0; i < kRing; ++i) tmp[i] = ld<Tin>(pe2_b, (unsigned int)(i <= kn ? i : kn) * row_p2 + lane2);
@@ -256,17 +352,21 @@ __global__ __launch_bounds__(64) void mappm_sweep_kernel(const SweepArgs a)
         for (int i = 0; i < kRing; ++i) ring[i * 64] = tmp[i];
         jl = jr = (kRing < kn + 1) ? kRing : kn + 1;
     }
-    float pv0 = 0.f, pv1 = 0.f;
+    Tin pv0 = (Tin)0, pv1 = (Tin)0;  // raw, converted when they land (see q_raw)
     auto PE2 = [&](int i) -> float {  // interface row i (0-based, <= kn)
-        // (the LDS read is unconditional and the rare memory read sits in a branch of its own that waits for it right
-        // there: a select between the two addresses becomes a flat load, and a wait placed after the branches merge
-        // would stall every lane on everything the wave has in flight)
-        float v = ring[(i & (kRing - 1)) * 64];
-        if (!((unsigned int)(jl - 1 - i) < (unsigned int)kRing)) {
-            v = ld<Tin>(pe2_b, (unsigned int)i * row_p2 + lane2);
-            __builtin_amdgcn_s_waitcnt(0x0F70);  // vmcnt(0)
+        if constexpr (TGT) {
+            return tgt[i * 8];
+        } else {
+            // (the LDS read is unconditional and the rare memory read sits in a branch of its own that waits for it right
+            // there: a select between the two addresses becomes a flat load, and a wait placed after the branches merge
+            // would stall every lane on everything the wave has in flight)
+            float v = ring[(i & (kRing - 1)) * 64];
+            if (!((unsigned int)(jl - 1 - i) < (unsigned int)kRing)) {
+                v = ld<Tin>(pe2_b, (unsigned int)i * row_p2 + lane2);
+                __builtin_amdgcn_s_waitcnt(0x0F70);  // vmcnt(0)
+            }
+            return v;
         }
-        return v;
     };
     unsigned int offq = (unsigned int)lane * 4u;  // offset of q2(k)
     int k = 1;
@@ -294,9 +394,8 @@ __global__ __launch_bounds__(64) void mappm_sweep_kernel(const SweepArgs a)
     // that runs kOut rows ahead of the slowest one writes its own oldest row out first.  Ill-formed lanes count as past
     // every row; whatever the flush writes for them is overwritten by the fallback pass.  (kOut = 16 and 32 were slower:
     // the ring's LDS footprint costs occupancy.)
-    constexpr int kOut = 8;
-    __shared__ float oring_lds[NF * kOut * 64];
-    float *oring = oring_lds + lane;
+    constexpr int kOut = kSweepOut;
+    float *oring = sweep_lds + (TGT ? (kn + 1) * 8 : kRing * 64) + lane;
     int rf = 0;  // uniform: rows [0, rf) are in memory for every lane
     int rl = 0;  // per lane (>= rf where it matters)
     V out_v[NV];
@@ -335,47 +434,76 @@ __global__ __launch_bounds__(64) void mappm_sweep_kernel(const SweepArgs a)
     }
     bool live = (k <= kn) && !bad && !(p2k >= pe1_bot);
 
-    V q_in[NV];
-    float pe_in = pe_e;
+    // ---- row prefetch, two levels deep ----
+    // The rows of level L + 4 (q) / L + 5 (pe1) are consumed at the BOTTOM of iteration L.  Requested at the top of the same
+    // iteration (round 2) they had ~0.8 of an iteration in flight, and a wave holds few enough bytes in flight (5 rows) that
+    // the launch ran at the latency-bandwidth product of its occupancy, not at the VALU or HBM limit (r03 counters: 35 % of
+    // the wave cycles parked at s_waitcnt).  Now iteration L requests the rows of iteration L + 1 into the OTHER of two
+    // staging sets, so a request has a whole iteration more; the loop body is instantiated twice with the sets swapped
+    // (a rotation by register moves would wait for the rows just requested).  The requests are unconditional -- the row
+    // pointers stop at the last row -- and issued after the iteration's other memory operations, so that the counted wait at
+    // the bottom (`vmcnt(NF + 1)`: everything but the newest set) is exact on every path.
+    // The rows stay in the INPUT type until they are consumed: a conversion written next to the load makes the compiler
+    // wait for the load right there (r02's float64 instantiations had `s_waitcnt vmcnt(0)` directly behind the loads).
+    Tin q_setA[NF], q_setB[NF], pe_setA, pe_setB = (Tin)0;
 #pragma unroll
-    for (int v = 0; v < NV; ++v) q_in[v] = v_splat(q0[v], 0.f);
-    for (int L = 1; L <= km; ++L) {
+    for (int f = 0; f < NF; ++f) {
+        q_setA[f] = *reinterpret_cast<const Tin *>(q1_row[f] + lin);  // q(5)  (km >= 8)
+        q1_row[f] += row_in;
+        q_setB[f] = (Tin)0;
+    }
+    pe_setA = *reinterpret_cast<const Tin *>(pe1_row + lin);  // pe1(6)
+    pe1_row += row_in;
+    auto sweep_level = [&](const int L, Tin (&q_ld)[NF], Tin &pe_ld, Tin (&q_use)[NF], Tin &pe_use) {
         // ---- the interface rows requested during the previous iteration land in the ring ----
-        if (jr > jl) ring[(jl & (kRing - 1)) * 64] = pv0;
-        if (jr > jl + 1) ring[((jl + 1) & (kRing - 1)) * 64] = pv1;
-        jl = jr;
-        flush_rows(2);
-        // Order inside an iteration: the requests for the next iteration first, then layer L's finalisation and its
-        // emits, then the reconstruction of level L + 2 -- the wait at the top of the next iteration also waits for
-        // whatever was stored here, so the reconstruction sits behind the stores.
-        // ---- requests for the next iteration: q(L+4), pe1(L+5) ----
-        if (L + 4 <= km) {
-#pragma unroll
-            for (int v = 0; v < NV; ++v) q_in[v] = ldq(v, 0);
-#pragma unroll
-            for (int f = 0; f < NF; ++f) q1_row[f] += row_in;
-            pe_in = ld<Tin>(pe1_row, lin);
-            pe1_row += row_in;
+        if constexpr (!TGT) {
+            if (jr > jl) {
+                asm volatile("" : "+v"(pv0));
+                ring[(jl & (kRing - 1)) * 64] = (float)pv0;
+            }
+            if (jr > jl + 1) {
+                asm volatile("" : "+v"(pv1));
+                ring[((jl + 1) & (kRing - 1)) * 64] = (float)pv1;
+            }
+            jl = jr;
         }
-        {   // ... and up to two target-interface rows, kept kAhead ahead of lane 0's cursor
+        flush_rows(2);
+        // Order inside an iteration: the memory requests first (target-interface rows, then the rows of iteration L + 1),
+        // then layer L's finalisation and its emits, then the reconstruction of level L + 2 -- the wait at the top of the
+        // next iteration also waits for whatever was stored here, so the reconstruction sits behind the stores.
+        if constexpr (!TGT) {  // up to two target-interface rows, kept kAhead ahead of lane 0's cursor
             const int want = __builtin_amdgcn_readfirstlane(k) + kAhead;
             if (jr <= kn && jr < want) {
-                pv0 = ld<Tin>(pe2_b + (size_t)jr * row_p2, lane2);
+                pv0 = *reinterpret_cast<const Tin *>(pe2_b + (size_t)jr * row_p2 + lane2);
                 ++jr;
                 if (jr <= kn && jr < want) {
-                    pv1 = ld<Tin>(pe2_b + (size_t)jr * row_p2, lane2);
+                    pv1 = *reinterpret_cast<const Tin *>(pe2_b + (size_t)jr * row_p2 + lane2);
                     ++jr;
                 }
             }
         }
+        // ---- requests for iteration L + 1: q(L+5), pe1(L+6) (the last row again once the column is exhausted) ----
+#pragma unroll
+        for (int f = 0; f < NF; ++f) q_ld[f] = *reinterpret_cast<const Tin *>(q1_row[f] + lin);
+        pe_ld = *reinterpret_cast<const Tin *>(pe1_row + lin);
+        if (L + 6 <= km) {
+#pragma unroll
+            for (int f = 0; f < NF; ++f) q1_row[f] += row_in;
+            pe1_row += row_in;
+        }
         // ---- finalise layer L: A6 and the monotonicity constraint (mappm.f90:773-849 with lmt = 0) ----
-        V al[NV], ar[NV], a6[NV];
+        V al[NV], ar[NV], a6[NV], da1[NV], a6pd[NV];  // (da1 = ar - al and a6pd = a6 + da1: fast mode only)
 #pragma unroll
         for (int v = 0; v < NV; ++v) {
             al[v] = al0[v];
             ar[v] = (L == km) ? ar_km[v] : al1[v];
-            a6[v] = 3.f * (2.f * q0[v] - (al[v] + ar[v]));
-            limit0(dc0[v], q0[v], al[v], ar[v], a6[v]);
+            if constexpr (FAST) {
+                limit0_fast(dc0[v], q0[v], al[v], ar[v], a6[v], da1[v]);
+                a6pd[v] = a6[v] + da1[v];
+            } else {
+                a6[v] = 3.f * (2.f * q0[v] - (al[v] + ar[v]));
+                limit0(dc0[v], q0[v], al[v], ar[v], a6[v]);
+            }
         }
         const float pL = pe_a, pL1 = pe_b;
         const Den<FAST> rd0(d0);
@@ -386,10 +514,13 @@ __global__ __launch_bounds__(64) void mappm_sweep_kernel(const SweepArgs a)
             const float PR = rd0.under(delp);
             dpsum = dpsum + delp;
             const Den<FAST> rs(dpsum);
-            const float hp = 0.5f * PR, tp = 1.f - r23 * PR;
+            const float hp = 0.5f * PR, tp = FAST ? __builtin_fmaf(-r23, PR, 1.f) : 1.f - r23 * PR;
 #pragma unroll
             for (int v = 0; v < NV; ++v) {
-                qsum[v] = qsum[v] + delp * (al[v] + hp * (ar[v] - al[v] + a6[v] * tp));
+                if constexpr (FAST)
+                    qsum[v] = v_fma(v_splat(qsum[v], delp), v_fma(v_splat(qsum[v], hp), v_fma(a6[v], v_splat(qsum[v], tp), da1[v]), al[v]), qsum[v]);
+                else
+                    qsum[v] = qsum[v] + delp * (al[v] + hp * (ar[v] - al[v] + a6[v] * tp));
                 OUT(v, rs.under(qsum[v]));
             }
             out_end();
@@ -400,9 +531,14 @@ __global__ __launch_bounds__(64) void mappm_sweep_kernel(const SweepArgs a)
         while (live && !accum && (p2k >= pL && p2k <= pL1) && (p2k1 <= pL1)) {
             const float PR = rd0.under(p2k1 - pL);
             const float PL = rd0.under(p2k - pL);
-            const float TT = r3 * (PR * (PR + PL) + PL * PL), sp = PR + PL;
+            const float sp = PR + PL, TT = FAST ? r3 * __builtin_fmaf(PR, sp, PL * PL) : r3 * (PR * (PR + PL) + PL * PL);
 #pragma unroll
-            for (int v = 0; v < NV; ++v) OUT(v, al[v] + 0.5f * (a6[v] + ar[v] - al[v]) * sp - a6[v] * TT);
+            for (int v = 0; v < NV; ++v) {
+                if constexpr (FAST)
+                    OUT(v, v_fma(-a6[v], v_splat(a6[v], TT), v_fma(a6pd[v], v_splat(a6[v], 0.5f * sp), al[v])));
+                else
+                    OUT(v, al[v] + 0.5f * (a6[v] + ar[v] - al[v]) * sp - a6[v] * TT);
+            }
             out_end();
             advance();
             live = (k <= kn) && !bad && !(p2k >= pe1_bot);
@@ -410,15 +546,19 @@ __global__ __launch_bounds__(64) void mappm_sweep_kernel(const SweepArgs a)
         if (live) {
             if (accum) {  // whole layer (mappm.f90:99-104)
 #pragma unroll
-                for (int v = 0; v < NV; ++v) qsum[v] = qsum[v] + d0 * q0[v];
+                for (int v = 0; v < NV; ++v) qsum[v] = FAST ? v_fma(v_splat(q0[v], d0), q0[v], qsum[v]) : qsum[v] + d0 * q0[v];
                 dpsum = dpsum + d0;
             } else if (p2k >= pL && p2k <= pL1) {  // fractional area (mappm.f90:85-92)
                 const float PL = rd0.under(p2k - pL);
                 const float delp = pL1 - p2k;
-                const float TT = r3 * (1.f + PL * (1.f + PL)), sp = 1.f + PL;
+                const float sp = 1.f + PL, TT = FAST ? r3 * __builtin_fmaf(PL, sp, 1.f) : r3 * (1.f + PL * (1.f + PL));
 #pragma unroll
-                for (int v = 0; v < NV; ++v)
-                    qsum[v] = delp * (al[v] + 0.5f * (a6[v] + ar[v] - al[v]) * sp - a6[v] * TT);
+                for (int v = 0; v < NV; ++v) {
+                    if constexpr (FAST)
+                        qsum[v] = delp * v_fma(-a6[v], v_splat(a6[v], TT), v_fma(a6pd[v], v_splat(a6[v], 0.5f * sp), al[v]));
+                    else
+                        qsum[v] = delp * (al[v] + 0.5f * (a6[v] + ar[v] - al[v]) * sp - a6[v] * TT);
+                }
                 dpsum = delp;
                 accum = true;
             }
@@ -462,6 +602,14 @@ __global__ __launch_bounds__(64) void mappm_sweep_kernel(const SweepArgs a)
         }
         // ---- level L + 1 becomes the current one (at the bottom of the iteration, unconditionally: with the rotation under
         // `if (L > 1)` at the top the compiler shuffled the window forth at the top and back at the bottom, 18 moves a level)
+        V q_in[NV];
+#pragma unroll
+        for (int f = 0; f < NF; ++f) {
+            asm volatile("" : "+v"(q_use[f]));  // the conversion stays here, behind the wait for the row
+            v_set(q_in[f / W], f % W, (float)q_use[f]);
+        }
+        asm volatile("" : "+v"(pe_use));
+        const float pe_in = (float)pe_use;
         if (!(pe_in >= pe_e)) bad = bad | (L < km);
 #pragma unroll
         for (int v = 0; v < NV; ++v) {
@@ -471,7 +619,13 @@ __global__ __launch_bounds__(64) void mappm_sweep_kernel(const SweepArgs a)
         }
         d0 = dp1; dp1 = dp2; dp2 = dp3; dp3 = pe_in - pe_e;
         pe_a = pe_b; pe_b = pe_c; pe_c = pe_d; pe_d = pe_e; pe_e = pe_in;
+    };
+    int L = 1;
+    for (; L < km; L += 2) {
+        sweep_level(L, q_setB, pe_setB, q_setA, pe_setA);
+        sweep_level(L + 1, q_setA, pe_setA, q_setB, pe_setB);
     }
+    if (L == km) sweep_level(L, q_setB, pe_setB, q_setA, pe_setA);
 
     // ---- past the old surface (mappm.f90:115-121), then the run that copies q1(km) ----
     if (k <= kn && !bad && accum) {
@@ -498,27 +652,31 @@ __global__ __launch_bounds__(64) void mappm_sweep_kernel(const SweepArgs a)
         }
     }
     flush_rows(kn);  // every lane is done (or ill-formed): the rows still in the ring
-    if (bad) a.bad_cols[atomicAdd(a.n_bad, 1u)] = (unsigned int)(blockIdx.x * 64 + lane);  // redone by mappm_fallback_kernel
+    if (bad) a.bad_cols[atomicAdd(a.n_bad, 1u)] = (unsigned int)(wid * 64 + lane);  // redone by mappm_fallback_kernel
 }
 
 template <typename Tin, int NV, int W>
-void launch_sweep2(const SweepArgs &a, int64_t n_waves, bool fast, hipStream_t st)
+void launch_sweep2(const SweepArgs &a, int64_t n_waves, bool fast, bool tgt, hipStream_t st)
 {
-    if (fast)
-        hipLaunchKernelGGL((mappm_sweep_kernel<Tin, NV, W, true>), dim3((unsigned)n_waves), dim3(64), 0, st, a);
-    else
-        hipLaunchKernelGGL((mappm_sweep_kernel<Tin, NV, W, false>), dim3((unsigned)n_waves), dim3(64), 0, st, a);
+    const size_t lds = (size_t)((tgt ? (a.kn + 1) * 8 : kSweepRing * 64) + NV * W * kSweepOut * 64) * sizeof(float);
+#define SWEEP_(F, T) hipLaunchKernelGGL((mappm_sweep_kernel<Tin, NV, W, F, T>), dim3((unsigned)n_waves), dim3(64), lds, st, a)
+    if (fast) {
+        if (tgt) SWEEP_(true, true); else SWEEP_(true, false);
+    } else {
+        if (tgt) SWEEP_(false, true); else SWEEP_(false, false);
+    }
+#undef SWEEP_
 }
 
 // fields per launch -> (register slots, fields per slot): pairs of fields share packed-math instructions
 template <typename Tin>
-void launch_sweep1(const SweepArgs &a, int nf, int64_t n_waves, bool fast, hipStream_t st)
+void launch_sweep1(const SweepArgs &a, int nf, int64_t n_waves, bool fast, bool tgt, hipStream_t st)
 {
     switch (nf) {
-        case 1: launch_sweep2<Tin, 1, 1>(a, n_waves, fast, st); break;
-        case 2: launch_sweep2<Tin, 1, 2>(a, n_waves, fast, st); break;
-        case 3: launch_sweep2<Tin, 3, 1>(a, n_waves, fast, st); break;
-        default: launch_sweep2<Tin, 2, 2>(a, n_waves, fast, st); break;
+        case 1: launch_sweep2<Tin, 1, 1>(a, n_waves, fast, tgt, st); break;
+        case 2: launch_sweep2<Tin, 1, 2>(a, n_waves, fast, tgt, st); break;
+        case 3: launch_sweep2<Tin, 3, 1>(a, n_waves, fast, tgt, st); break;
+        default: launch_sweep2<Tin, 2, 2>(a, n_waves, fast, tgt, st); break;
     }
 }
 
@@ -535,10 +693,12 @@ bool mappm_sweep_eligible(int64_t n_inner, int km, int kn, int kord, int layout,
 void mappm_sweep_launch(const SweepArgs &a, int nf, int in_dtype, int64_t col_end, bool fast, hipStream_t st)
 {
     const int64_t n_waves = (col_end - a.col0) / 64;
+    // the whole target table in LDS: coarser by a power of two >= 8, waves inside one fine row, (kn + 1) * 8 <= 1024 floats
+    const bool tgt = a.pe2_f >= 8 && a.pe2_f <= 64 && (a.pe2_f & (a.pe2_f - 1)) == 0 && a.nx % 64 == 0 && a.kn + 1 <= 128;
     if (in_dtype == FV3HIP_F32)
-        launch_sweep1<float>(a, nf, n_waves, fast, st);
+        launch_sweep1<float>(a, nf, n_waves, fast, tgt, st);
     else
-        launch_sweep1<double>(a, nf, n_waves, fast, st);
+        launch_sweep1<double>(a, nf, n_waves, fast, tgt, st);
 }
 
 }  // namespace fv3hip
