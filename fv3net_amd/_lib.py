@@ -19,7 +19,7 @@ LAYOUT_COL_LEVEL, LAYOUT_LEVEL_COL = 0, 1
 TRANSFORM_NONE, TRANSFORM_LOG = 0, 1
 ACT_LINEAR, ACT_RELU = 0, 1
 ARITH_EXACT, ARITH_FAST = 0, 1
-ABI_VERSION = 2
+ABI_VERSION = 3
 
 OK, EINVAL, EUNSUPPORTED, EHIP, ENOMEM = 0, -1, -2, -3, -4
 
@@ -143,6 +143,11 @@ SIGNATURES = {
     "fv3hip_cast_many": (c_int, [c_void_p, POINTER(c_int), c_void_p, c_int, POINTER(c_int64), c_int, c_void_p]),
     "fv3hip_interp_center_to_outer": (c_int, [c_void_p, c_int, c_int64, c_int, c_int, c_int, c_void_p, c_void_p,
                                               c_void_p, c_void_p]),
+    "fv3hip_interp_center_to_outer_lines": (c_int, [c_void_p, c_int, c_int64, c_int, c_int, c_int, c_int, c_void_p, c_void_p,
+                                                    c_void_p, c_void_p]),
+    "fv3hip_weighted_window_average": (c_int, [c_void_p, c_int, c_void_p, c_int, c_int64, c_int, c_int, c_int64, c_int, c_int,
+                                               c_int, c_int, c_void_p, c_void_p]),
+    "fv3hip_repeat": (c_int, [c_void_p, c_int, c_int64, c_int, c_int, c_int, c_int, c_void_p, c_void_p]),
     "fv3hip_pressure_at_interface": (
         c_int,
         [c_void_p, c_int, c_int64, c_int, c_int64, c_double, c_void_p, c_void_p],

@@ -693,7 +693,7 @@ int launch_block_reduce(const void *in, void *out, int64_t n_outer, int ny, int 
 // ---------------------------------------------------------------------------------------
 template <typename U>
 __global__ void upsample_kernel(const U *__restrict__ in, U *__restrict__ out, int64_t n_outer,
-                                int ny_in, int nx_in, int ny_out, int nx_out, int f)
+                                int ny_in, int nx_in, int ny_out, int nx_out, int fy, int fx)
 {
     const int64_t total = n_outer * ny_out * nx_out;
     for (int64_t idx = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; idx < total;
@@ -702,7 +702,7 @@ __global__ void upsample_kernel(const U *__restrict__ in, U *__restrict__ out, i
         const int64_t t = idx / nx_out;
         const int y = (int)(t % ny_out);
         const int64_t o = t / ny_out;
-        out[idx] = in[(o * ny_in + y / f) * nx_in + x / f];
+        out[idx] = in[(o * ny_in + y / fy) * nx_in + x / fx];
     }
 }
 
@@ -762,20 +762,22 @@ __global__ void cast_kernel(const Tin *__restrict__ in, Tout *__restrict__ out, 
 }
 
 // out[o][y][x'] = 0.5 * (left + right) along `axis` (0 = x: nx+1 points, 1 = y: ny+1 points); beyond the
-// tile the neighbours come from lo / hi [o][along-edge index]
+// tile the neighbours come from lo / hi [o][along-edge index].  step > 1: only every step-th edge along `axis` (the lines an
+// edge-weighted block average keeps, coarsen.py:221-273): n / step + 1 points, point j' is edge j' * step.
 template <typename T>
 __global__ void interp_to_outer_kernel(const T *__restrict__ in, const T *__restrict__ lo, const T *__restrict__ hi,
-                                       T *__restrict__ out, int64_t n_outer, int ny, int nx, int axis)
+                                       T *__restrict__ out, int64_t n_outer, int ny, int nx, int axis, int step)
 {
-    const int nyo = ny + (axis == 1), nxo = nx + (axis == 0);
+    const int nyo = (axis == 1) ? ny / step + 1 : ny, nxo = (axis == 0) ? nx / step + 1 : nx;
     const int64_t total = n_outer * nyo * nxo;
     for (int64_t idx = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; idx < total;
          idx += (int64_t)gridDim.x * blockDim.x) {
-        const int x = (int)(idx % nxo);
+        int x = (int)(idx % nxo);
         const int64_t r = idx / nxo;
-        const int y = (int)(r % nyo);
+        int y = (int)(r % nyo);
         const int64_t o = r / nyo;
         const T *f = in + o * (int64_t)ny * nx;
+        if (axis == 0) x *= step; else y *= step;
         T a, b;
         if (axis == 0) {
             a = (x == 0) ? lo[o * ny + y] : f[(int64_t)y * nx + x - 1];
@@ -899,6 +901,15 @@ extern "C" int fv3hip_edge_weighted_block_average(const void *obj, int obj_dtype
                       factor, out, stream);
 }
 
+extern "C" int fv3hip_weighted_window_average(const void *obj, int obj_dtype, const void *weights, int w_dtype, int64_t n_outer,
+                                              int ny, int nx, int64_t w_repeat, int by, int bx, int sy, int sx, void *out,
+                                              void *stream)
+{
+    FV3HIP_REQUIRE(by >= 1 && bx >= 1 && sy >= 1 && sx >= 1, "window and stride must be >= 1");
+    FV3HIP_REQUIRE(ny >= by && nx >= bx, "the window (%d x %d) exceeds the field (%d x %d)", by, bx, ny, nx);
+    return wavg_entry(obj, obj_dtype, weights, w_dtype, n_outer, ny, nx, w_repeat, by, bx, sy, sx, out, stream);
+}
+
 extern "C" int fv3hip_block_reduce(const void *in, int dtype, int64_t n_outer, int ny, int nx, int by,
                                    int bx, int sy, int sx, int op, int nan_policy, void *out,
                                    void *stream)
@@ -941,11 +952,33 @@ extern "C" int fv3hip_block_upsample(const void *in, int elem_size, int64_t n_ou
     if (elem_size == 4)
         hipLaunchKernelGGL((upsample_kernel<uint32_t>), dim3((unsigned)blocks), dim3(256), 0, st,
                            static_cast<const uint32_t *>(in), static_cast<uint32_t *>(out), n_outer,
-                           ny_in, nx_in, ny_out, nx_out, factor);
+                           ny_in, nx_in, ny_out, nx_out, factor, factor);
     else
         hipLaunchKernelGGL((upsample_kernel<uint64_t>), dim3((unsigned)blocks), dim3(256), 0, st,
                            static_cast<const uint64_t *>(in), static_cast<uint64_t *>(out), n_outer,
-                           ny_in, nx_in, ny_out, nx_out, factor);
+                           ny_in, nx_in, ny_out, nx_out, factor, factor);
+    return check_launch("upsample_kernel");
+}
+
+extern "C" int fv3hip_repeat(const void *in, int elem_size, int64_t n_outer, int ny_in, int nx_in, int fy, int fx, void *out,
+                             void *stream)
+{
+    FV3HIP_REQUIRE(fy >= 1 && fx >= 1, "repeat counts must be >= 1, got %d, %d", fy, fx);
+    FV3HIP_REQUIRE(elem_size == 4 || elem_size == 8, "elem_size must be 4 or 8, got %d", elem_size);
+    FV3HIP_REQUIRE(n_outer >= 0 && ny_in >= 0 && nx_in >= 0, "negative extent");
+    if (n_outer == 0 || ny_in == 0 || nx_in == 0) return FV3HIP_OK;
+    FV3HIP_REQUIRE(in && out, "null pointer");
+    const int ny_out = ny_in * fy, nx_out = nx_in * fx;
+    const int64_t total = n_outer * ny_out * nx_out;
+    int64_t blocks = ceil_div(total, 256);
+    if (blocks > 256 * 64) blocks = 256 * 64;
+    hipStream_t st = as_stream(stream);
+    if (elem_size == 4)
+        hipLaunchKernelGGL((upsample_kernel<uint32_t>), dim3((unsigned)blocks), dim3(256), 0, st,
+                           static_cast<const uint32_t *>(in), static_cast<uint32_t *>(out), n_outer, ny_in, nx_in, ny_out, nx_out, fy, fx);
+    else
+        hipLaunchKernelGGL((upsample_kernel<uint64_t>), dim3((unsigned)blocks), dim3(256), 0, st,
+                           static_cast<const uint64_t *>(in), static_cast<uint64_t *>(out), n_outer, ny_in, nx_in, ny_out, nx_out, fy, fx);
     return check_launch("upsample_kernel");
 }
 
@@ -1092,27 +1125,34 @@ extern "C" int fv3hip_cast(const void *in, int in_dtype, void *out, int out_dtyp
     }
 }
 
-extern "C" int fv3hip_interp_center_to_outer(const void *in, int dtype, int64_t n_outer, int ny, int nx, int axis,
-                                             const void *lo, const void *hi, void *out, void *stream)
+extern "C" int fv3hip_interp_center_to_outer_lines(const void *in, int dtype, int64_t n_outer, int ny, int nx, int axis, int step,
+                                                   const void *lo, const void *hi, void *out, void *stream)
 {
     FV3HIP_REQUIRE(axis == 0 || axis == 1, "axis must be 0 ('x') or 1 ('y'), got %d", axis);
     FV3HIP_REQUIRE(dtype == FV3HIP_F32 || dtype == FV3HIP_F64, "dtype must be F32 or F64");
     FV3HIP_REQUIRE(n_outer >= 0 && ny >= 0 && nx >= 0, "negative extent");
+    FV3HIP_REQUIRE(step >= 1 && (axis == 0 ? nx : ny) % step == 0, "the extent along the axis must be a multiple of step (%d)", step);
     if (n_outer == 0 || ny == 0 || nx == 0) return FV3HIP_OK;
     FV3HIP_REQUIRE(in && lo && hi && out, "null pointer");
-    const int64_t total = n_outer * (ny + (axis == 1)) * (nx + (axis == 0));
+    const int64_t total = n_outer * ((axis == 1) ? ny / step + 1 : ny) * ((axis == 0) ? nx / step + 1 : nx);
     int64_t blocks = ceil_div(total, 256);
     if (blocks > 256 * 64) blocks = 256 * 64;
     hipStream_t st = as_stream(stream);
     if (dtype == FV3HIP_F32)
         hipLaunchKernelGGL((interp_to_outer_kernel<float>), dim3((unsigned)blocks), dim3(256), 0, st,
                            static_cast<const float *>(in), static_cast<const float *>(lo), static_cast<const float *>(hi),
-                           static_cast<float *>(out), n_outer, ny, nx, axis);
+                           static_cast<float *>(out), n_outer, ny, nx, axis, step);
     else
         hipLaunchKernelGGL((interp_to_outer_kernel<double>), dim3((unsigned)blocks), dim3(256), 0, st,
                            static_cast<const double *>(in), static_cast<const double *>(lo), static_cast<const double *>(hi),
-                           static_cast<double *>(out), n_outer, ny, nx, axis);
+                           static_cast<double *>(out), n_outer, ny, nx, axis, step);
     return check_launch("interp_to_outer_kernel");
+}
+
+extern "C" int fv3hip_interp_center_to_outer(const void *in, int dtype, int64_t n_outer, int ny, int nx, int axis,
+                                             const void *lo, const void *hi, void *out, void *stream)
+{
+    return fv3hip_interp_center_to_outer_lines(in, dtype, n_outer, ny, nx, axis, 1, lo, hi, out, stream);
 }
 
 extern "C" int fv3hip_ew(int op, const void *a, const void *b, const void *c, double scalar, int dtype, int64_t n,

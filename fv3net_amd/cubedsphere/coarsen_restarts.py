@@ -32,8 +32,8 @@ from .constants import (
     SFC_DATA_X_CENTER,
     SFC_DATA_Y_CENTER,
 )
-from .regridz import (compute_edge_delp, pressure_at_midpoint_log, regrid_to_area_weighted_pressure,
-                      regrid_to_edge_weighted_pressure)  # (pressure_at_midpoint_log: thermo imports this package's device helpers)
+from .regridz import (EdgeLines, compute_edge_delp, edge_weighted_pressure_means, pressure_at_midpoint_log,
+                      regrid_to_area_weighted_pressure, regrid_to_edge_weighted_pressure)  # (pressure_at_midpoint_log: thermo imports this package's device helpers)
 from .sfc_data import _coarse_grain_sfc_data_complex
 
 CATEGORY_LIST = ["fv_core.res", "fv_srf_wnd.res", "fv_tracer.res", "sfc_data"]
@@ -124,7 +124,7 @@ def _area_weighted_pressure_means(core, tracer, delp, area, toa_pressure, coarse
 
 
 def _coarse_grain_fv_core_on_pressure(ds, delp, area, dx, dy, toa_pressure, coarsening_factor, coarsen_agrid_winds=False,
-                                      extrapolate=False, area_means=None):
+                                      extrapolate=False, area_means=None, edge_lines=None):
     """coarsen_restarts.py:430-556: delp, DZ, phis on model surfaces, the rest on surfaces of constant pressure.
     ``area_means``: the coarse W, T, (ua, va) when the caller has them already (``_area_weighted_pressure_means``)."""
     area_weighted_vars = ["phis", "delp", "DZ"]
@@ -135,17 +135,18 @@ def _coarse_grain_fv_core_on_pressure(ds, delp, area, dx, dy, toa_pressure, coar
             y_dim=FV_CORE_Y_CENTER, extrapolate=extrapolate)
         area_means = weighted_block_average(area_regridded, masked_area, coarsening_factor, x_dim=FV_CORE_X_CENTER,
                                             y_dim=FV_CORE_Y_CENTER)
-    dx_regridded, masked_dx = regrid_to_edge_weighted_pressure(
-        ds[["u"]], delp, dx, toa_pressure, coarsening_factor, x_dim=FV_CORE_X_CENTER, y_dim=FV_CORE_Y_OUTER, edge="x",
-        extrapolate=extrapolate)
-    dy_regridded, masked_dy = regrid_to_edge_weighted_pressure(
-        ds[["v"]], delp, dy, toa_pressure, coarsening_factor, x_dim=FV_CORE_X_OUTER, y_dim=FV_CORE_Y_CENTER, edge="y",
-        extrapolate=extrapolate)
+    # the D-grid winds: remapped and averaged on the edge lines the average keeps (regridz.edge_weighted_pressure_means ==
+    # edge_weighted_block_average(*regrid_to_edge_weighted_pressure(...)), coarsen_restarts.py:497-540)
+    edge_lines = edge_lines or {}
+    u_mean = edge_weighted_pressure_means(ds[["u"]], delp, dx, toa_pressure, coarsening_factor, x_dim=FV_CORE_X_CENTER,
+                                          y_dim=FV_CORE_Y_OUTER, edge="x", extrapolate=extrapolate, lines=edge_lines.get("x"))
+    v_mean = edge_weighted_pressure_means(ds[["v"]], delp, dy, toa_pressure, coarsening_factor, x_dim=FV_CORE_X_OUTER,
+                                          y_dim=FV_CORE_Y_CENTER, edge="y", extrapolate=extrapolate, lines=edge_lines.get("y"))
     return merge([
         weighted_block_average(ds[area_weighted_vars], area, coarsening_factor, x_dim=FV_CORE_X_CENTER, y_dim=FV_CORE_Y_CENTER),
         area_means,
-        edge_weighted_block_average(dx_regridded, masked_dx, coarsening_factor, x_dim=FV_CORE_X_CENTER, y_dim=FV_CORE_Y_OUTER, edge="x"),
-        edge_weighted_block_average(dy_regridded, masked_dy, coarsening_factor, x_dim=FV_CORE_X_OUTER, y_dim=FV_CORE_Y_CENTER, edge="y"),
+        u_mean,
+        v_mean,
     ])
 
 
@@ -200,16 +201,16 @@ def _compute_blending_weights_agrid(delp, area, toa_pressure, coarsening_factor,
     return compute_blending_weights(blending_pressure, ps_coarse, pfull_coarse)
 
 
-def _compute_blending_weights_dgrid(delp, length, toa_pressure, coarsening_factor, edge, x_dim, y_dim):
-    """coarsen_restarts.py:625-661."""
-    delp_edge = compute_edge_delp(delp, edge, x_dim=x_dim, y_dim=y_dim)
-    delp_edge_coarse = edge_weighted_block_average(delp_edge, length, coarsening_factor, x_dim=x_dim, y_dim=y_dim, edge=edge)
-    pfull_coarse = pressure_at_midpoint_log(delp_edge_coarse, toa_pressure=toa_pressure, dim=RESTART_Z_CENTER)
-    ps = surface_pressure_from_delp(delp_edge, p_toa=toa_pressure, vertical_dim=RESTART_Z_CENTER)
-    ps_coarse = surface_pressure_from_delp(delp_edge_coarse, p_toa=toa_pressure, vertical_dim=RESTART_Z_CENTER)
-    blending_pressure = _scale(block_edge_coarsen(ps, coarsening_factor, edge=edge, x_dim=x_dim, y_dim=y_dim, method="min"),
-                               SIGMA_BLEND)
-    return compute_blending_weights(blending_pressure, ps_coarse, pfull_coarse)
+def _compute_blending_weights_dgrid(delp, length, toa_pressure, coarsening_factor, edge, x_dim, y_dim, lines=None):
+    """coarsen_restarts.py:625-661, on the edge lines the edge-weighted / edge-min reductions keep (``lines``: the
+    pipeline's EdgeLines of this component, else built here)."""
+    L = lines or EdgeLines(delp, length, coarsening_factor, edge, x_dim, y_dim)
+    pfull_coarse = ops.pressure_at_midpoint_log(L.delp_coarse, toa_pressure, -3)
+    ps = ops.column_sum(L.delp, -3, addend=toa_pressure)
+    ps_coarse = ops.column_sum(L.delp_coarse, -3, addend=toa_pressure)
+    blending_pressure = ops.ew("mul_s", ops.block_reduce(ps, L.window, L.window, op="min"), scalar=SIGMA_BLEND)
+    res = ops.blend_weights(blending_pressure, ps_coarse, pfull_coarse, pfull_coarse.dim() - 3)
+    return DataArray(res, dims=tuple(L.order))
 
 
 def _blend_da(weights: DataArray, pressure_level: DataArray, model_level: DataArray) -> DataArray:
@@ -257,15 +258,19 @@ def _names(ds, with_z: bool):
 def _coarse_grain_fv_core_via_blended_method(ds, delp, area, dx, dy, toa_pressure, coarsening_factor, coarsen_agrid_winds=False,
                                              mass_weighted=True, area_means=None):
     """coarsen_restarts.py:679-778."""
+    # the edge thicknesses of u and v on the lines their means keep: one interpolation across the cube faces per component,
+    # shared by the pressure-level remap and the blending weights
+    edge_lines = {"x": EdgeLines(delp, dx, coarsening_factor, "x", FV_CORE_X_CENTER, FV_CORE_Y_OUTER),
+                  "y": EdgeLines(delp, dy, coarsening_factor, "y", FV_CORE_X_OUTER, FV_CORE_Y_CENTER)}
     pressure_level = to_compat(_coarse_grain_fv_core_on_pressure(ds, delp, area, dx, dy, toa_pressure, coarsening_factor,
-                                                                  coarsen_agrid_winds, area_means=area_means))
+                                                                  coarsen_agrid_winds, area_means=area_means, edge_lines=edge_lines))
     model_level = to_compat(_coarse_grain_fv_core(ds, delp, area, dx, dy, coarsening_factor, coarsen_agrid_winds, mass_weighted))
     weights_agrid = _compute_blending_weights_agrid(delp, area, toa_pressure, coarsening_factor, x_dim=FV_CORE_X_CENTER,
                                                     y_dim=FV_CORE_Y_CENTER)
     weights_u = _compute_blending_weights_dgrid(delp, dx, toa_pressure, coarsening_factor, "x", x_dim=FV_CORE_X_CENTER,
-                                                y_dim=FV_CORE_Y_OUTER)
+                                                y_dim=FV_CORE_Y_OUTER, lines=edge_lines["x"])
     weights_v = _compute_blending_weights_dgrid(delp, dy, toa_pressure, coarsening_factor, "y", x_dim=FV_CORE_X_OUTER,
-                                                y_dim=FV_CORE_Y_CENTER)
+                                                y_dim=FV_CORE_Y_CENTER, lines=edge_lines["y"])
     d = to_compat(ds)
     ignore = ["u", "v"] + ([] if coarsen_agrid_winds else ["ua", "va"])
     names_2d = _names(d, False)

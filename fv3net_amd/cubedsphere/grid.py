@@ -54,14 +54,14 @@ def halos_from_rows(rows: torch.Tensor, tiles, axis: str):
     return both[0], both[1]
 
 
-def interp_tiles_to_edges(field: torch.Tensor, axis: str) -> torch.Tensor:
+def interp_tiles_to_edges(field: torch.Tensor, axis: str, step: int = 1) -> torch.Tensor:
     """[6, ..., n, n] cell-centred -> cell edges along ``axis`` ('x': [6, ..., n, n+1]; 'y':
-    [6, ..., n+1, n]), all six tiles resident on one device."""
+    [6, ..., n+1, n]), all six tiles resident on one device.  ``step`` > 1: every step-th edge only."""
     if field.shape[0] != 6:
         raise ValueError("The leading dimension must hold the six tiles of the cube")
     rows = ops.cube_edge_rows(field)
     lo, hi = halos_from_rows(rows, range(6), axis)
-    return ops.interp_center_to_outer(field, lo, hi, 0 if axis == "x" else 1)
+    return ops.interp_center_to_outer(field, lo, hi, 0 if axis == "x" else 1, step=step)
 
 
 def _validate_tile_coord(da: DataArray):
@@ -81,9 +81,11 @@ def _validate_tile_coord(da: DataArray):
 
 
 def interp_center_to_outer(da, axis: str, x_center: Hashable = COORD_X_CENTER, x_outer: Hashable = COORD_X_OUTER,
-                           y_center: Hashable = COORD_Y_CENTER, y_outer: Hashable = COORD_Y_OUTER):
+                           y_center: Hashable = COORD_Y_CENTER, y_outer: Hashable = COORD_Y_OUTER, step: int = 1):
     """``create_fv3_grid(ds, ...).interp(da, axis)`` for a cell-centred array: the result carries the
-    outer dimension name in place of the centre one, with coordinate 0..n (xgcm.py:42-97)."""
+    outer dimension name in place of the centre one, with coordinate 0..n (xgcm.py:42-97).
+    ``step`` > 1 (not in the reference): only every step-th of the n + 1 edges, ``.isel({outer: slice(None, None, step)})`` of the
+    full result without computing the rest."""
     if axis not in ("x", "y"):
         raise ValueError(f"axis must be 'x' or 'y', got {axis!r}")
     d = to_compat(da)
@@ -99,17 +101,17 @@ def interp_center_to_outer(da, axis: str, x_center: Hashable = COORD_X_CENTER, x
         if not np.array_equal(perm, np.arange(len(mine))):
             t = t[torch.as_tensor(perm, device=t.device)]
     if len(mine) == 6:
-        res = interp_tiles_to_edges(t, axis)
+        res = interp_tiles_to_edges(t, axis, step=step)
     else:  # tile-sharded cube: the one exchange step of the path (parallel.exchange_edge_rows)
         from ..parallel import interp_tiles_to_edges_sharded
 
-        res = interp_tiles_to_edges_sharded(t, axis)
+        res = interp_tiles_to_edges_sharded(t, axis, step=step)
     new_dim = x_outer if axis == "x" else y_outer
     old_dim = x_center if axis == "x" else y_center
     dims = tuple(new_dim if dim == old_dim else dim for dim in order)
     coords = {k: v for k, v in d.coords.items() if k != old_dim and k != "tile"}
     coords["tile"] = np.asarray(mine)
-    coords[new_dim] = np.arange(res.shape[-1 if axis == "x" else -2])
+    coords[new_dim] = np.arange(res.shape[-1 if axis == "x" else -2]) * int(step)
     out = DataArray(like_input(res, d.data), dims=dims, coords=coords, name=d.name, attrs=d.attrs)
     out = out.transpose(*[new_dim if dim == old_dim else dim for dim in d.dims])
     return from_compat(out, da)

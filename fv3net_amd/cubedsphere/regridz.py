@@ -174,20 +174,21 @@ def regrid_to_area_weighted_pressure(ds, delp, area, toa_pressure: float, coarse
                               extrapolate=extrapolate)
 
 
-def compute_edge_delp(delp, edge: str, x_dim: str = FV_CORE_X_CENTER, y_dim: str = FV_CORE_Y_CENTER):
+def compute_edge_delp(delp, edge: str, x_dim: str = FV_CORE_X_CENTER, y_dim: str = FV_CORE_Y_CENTER, step: int = 1):
     """Pressure thickness on grid cell edges (coarsen_restarts.py:825-853): ``delp`` interpolated
     across the cube's faces to the edges the ``edge``-directed wind component lives on; the new
-    staggered dimension keeps the name passed for it, with coordinate 1..n+1 (float32)."""
+    staggered dimension keeps the name passed for it, with coordinate 1..n+1 (float32).
+    ``step`` > 1 (not in the reference): every step-th of those edge lines only -- all an edge-weighted block average keeps."""
     hor_dims = {"x": x_dim, "y": y_dim}
     interp_dim = "x" if edge == "y" else "y"
     outer_names = {"x": FV_CORE_X_OUTER, "y": FV_CORE_Y_OUTER}
     staggered = to_compat(interp_center_to_outer(delp, interp_dim, x_center=FV_CORE_X_CENTER, x_outer=FV_CORE_X_OUTER,
-                                                 y_center=FV_CORE_Y_CENTER, y_outer=FV_CORE_Y_OUTER))
+                                                 y_center=FV_CORE_Y_CENTER, y_outer=FV_CORE_Y_OUTER, step=step))
     d = to_compat(delp)
     new_dim = outer_names[interp_dim]
     wanted = hor_dims[interp_dim]
     if wanted == new_dim:  # (with other names the reference attaches a coordinate that indexes no dimension)
-        staggered = staggered.assign_coords({wanted: np.arange(1, d.sizes[hor_dims[edge]] + 2, dtype=np.float32)})
+        staggered = staggered.assign_coords({wanted: np.arange(1, d.sizes[hor_dims[edge]] + 2, dtype=np.float32)[::int(step)]})
     return from_compat(staggered, delp)
 
 
@@ -206,3 +207,87 @@ def regrid_to_edge_weighted_pressure(ds, delp, length, toa_pressure: float, coar
                                                         y_dim=y_dim, edge=edge)
     return _regrid_given_delp(ds, delp_staggered, delp_staggered_coarse, length, toa_pressure, x_dim=x_dim,
                               y_dim=y_dim, z_dim=z_dim, extrapolate=extrapolate)
+
+
+class EdgeLines:
+    """The edge pressure thickness of one D-grid wind component on the lines its edge-weighted means keep
+    (every f-th of the n + 1 edge lines): device tensors in [outer..., z, y, x] order, shared by the pressure-level remap
+    and the blending weights of one pipeline call."""
+
+    def __init__(self, delp, length, factor: int, edge: str, x_dim, y_dim, z_dim=RESTART_Z_CENTER):
+        from .coarsen import _edge_dims
+
+        self.factor, self.edge, self.x_dim, self.y_dim, self.z_dim = int(factor), edge, x_dim, y_dim, z_dim
+        self.coarsen_dim, self.down_dim = _edge_dims(edge, x_dim, y_dim)
+        f = self.factor
+        d = to_compat(compute_edge_delp(delp, edge, x_dim=x_dim, y_dim=y_dim, step=f))
+        self.outer = [dim for dim in d.dims if dim not in (z_dim, y_dim, x_dim)]
+        self.order = self.outer + [z_dim, y_dim, x_dim]
+        self.delp = on_device(d.transpose(*self.order).data)                      # [outer, z, lines..]
+        ln = to_compat(length)
+        w_outer = [dim for dim in ln.dims if dim not in (y_dim, x_dim)]
+        if w_outer != self.outer[: len(w_outer)]:
+            raise ValueError(f"the edge lengths' dims {ln.dims} do not lead the field's {tuple(self.order)}")
+        self.axis = 1 if self.down_dim == y_dim else 0                             # ops convention: 0 = x, 1 = y
+        self.length = ops.take_lines(on_device(ln.transpose(*w_outer, y_dim, x_dim).data), f, self.axis)
+        self.window = (1, f) if edge == "x" else (f, 1)
+        self.delp_coarse = ops.weighted_window_average(self.delp, self.length, self.window, self.window)
+
+    def lines_of(self, da):
+        return ops.take_lines(on_device(da.transpose(*self.order).data), self.factor, self.axis)
+
+    def mean_along_edge(self, field, weights):
+        return ops.weighted_window_average(field, weights, self.window, self.window)
+
+    def coarse_like(self, tensor, da, drop_z=False):
+        """The coarse result ``tensor`` labelled as ``edge_weighted_block_average`` labels the mean of ``da``."""
+        from .coarsen import _coarsen_downsample_coordinate, _coarsened_coords, coarsen_coords_coord_func
+
+        coords = _coarsened_coords(da, {self.coarsen_dim: self.factor}, coarsen_coords_coord_func)
+        down = _coarsen_downsample_coordinate(da, self.down_dim, self.factor, coarsen_coords_coord_func)
+        if down is not None:
+            coords[self.down_dim] = down
+        dims = [dim for dim in self.order if not (drop_z and dim == self.z_dim)]
+        coords = {k: v for k, v in coords.items() if not (drop_z and k == self.z_dim)}
+        out = DataArray(like_input(tensor, da.data), dims=tuple(dims), name=da.name, attrs=da.attrs, coords=coords)
+        return out.transpose(*[dim for dim in da.dims if dim in dims])
+
+
+def edge_weighted_pressure_means(ds, delp, length, toa_pressure: float, coarsening_factor: int, x_dim: str = FV_CORE_X_CENTER,
+                                 y_dim: str = FV_CORE_Y_OUTER, z_dim: str = RESTART_Z_CENTER, edge: str = "x",
+                                 extrapolate: bool = False, lines: EdgeLines = None):
+    """``edge_weighted_block_average(*regrid_to_edge_weighted_pressure(ds, delp, length, ...), edge=edge)``
+    (coarsen_restarts.py:497-556) without the seven eighths of the work the reference throws away: the edge-weighted mean
+    keeps every f-th edge line only (coarsen.py:265-271), so the edge thicknesses are interpolated, integrated, remapped and
+    masked on those lines alone -- column for column the same arithmetic, hence the same values."""
+    if edge not in ("x", "y"):
+        raise ValueError(f"'edge' most be either 'x' or 'y'; got {edge}.")
+    L = lines or EdgeLines(delp, length, coarsening_factor, edge, x_dim, y_dim, z_dim)
+    f = L.factor
+    d = to_compat(ds)
+    names = list(d) if isinstance(d, Dataset) else None
+    das = [d[v] for v in names] if names is not None else [d]
+    for a in das:
+        if set(a.dims) != set(L.order):
+            raise ValueError(f"field dims {a.dims} do not match the edge thickness' {tuple(L.order)}")
+    fields = [L.lines_of(a) for a in das]
+    rep = (1, f) if edge == "x" else (f, 1)
+    phalf_fine = ops.pressure_at_interface(L.delp, toa_pressure, -3)
+    phalf_coarse = ops.repeat(ops.pressure_at_interface(L.delp_coarse, toa_pressure, -3), *rep)
+    regridded = ops.mappm_multi(phalf_fine, fields, phalf_coarse, iv=1, kord=1, z_axis=-3)
+    w = L.length
+    batch = tuple(phalf_fine.shape[:-3])
+    if tuple(w.shape[:-2]) != batch:  # the lengths [tile, y, x] shared by the time axis
+        w = w.reshape(tuple(w.shape[:-2]) + (1,) * (len(batch) - (w.dim() - 2)) + tuple(w.shape[-2:])).expand(*batch, *w.shape[-2:]).contiguous()
+    if extrapolate:
+        level = ops.repeat(ops.pressure_at_midpoint_log(L.delp_coarse, toa_pressure, -3), *rep)
+    else:
+        level = phalf_coarse
+    masked = ops.mask_weights(w, level, phalf_fine, -3, extrapolate=extrapolate)
+    means = [L.coarse_like(L.mean_along_edge(r, masked), a) for r, a in zip(regridded, das)]
+    if names is None:
+        return from_compat(means[0], ds)
+    out = Dataset(attrs=d.attrs)
+    for v, m in zip(names, means):
+        out[v] = m
+    return from_compat(out, ds)

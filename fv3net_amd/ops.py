@@ -238,6 +238,44 @@ def edge_weighted_block_average(
     return out
 
 
+def weighted_window_average(obj: torch.Tensor, weights: torch.Tensor, window: Sequence[int], stride: Sequence[int]) -> torch.Tensor:
+    """``sum(obj * weights) / sum(weights)`` over windows (by, bx) every (sy, sx) cells of the last two dims -- the general
+    form of ``weighted_block_average`` (f, f / f, f) and ``edge_weighted_block_average`` ('x': (1, f) / (f, f)); on fields
+    already reduced to the lines the edge-weighted mean keeps: (1, f) / (1, f)."""
+    dev = _require_device(obj, weights)
+    by, bx = (int(v) for v in window)
+    sy, sx = (int(v) for v in stride)
+    obj = obj.contiguous()
+    weights, w_repeat = _weights_repeat(obj, weights)
+    ny, nx = int(obj.shape[-2]), int(obj.shape[-1])
+    if ny < by or nx < bx:
+        raise ValueError(f"window ({by}, {bx}) is larger than the field ({ny}, {nx})")
+    out = torch.empty(tuple(obj.shape[:-2]) + ((ny - by) // sy + 1, (nx - bx) // sx + 1), dtype=_promoted(obj, weights), device=dev)
+    _lib.call_on(dev, "fv3hip_weighted_window_average", _ptr(obj), _float_code(obj), _ptr(weights), _float_code(weights),
+                 _prod(obj.shape[:-2]), ny, nx, w_repeat, by, bx, sy, sx, _ptr(out), _stream(dev))
+    return out
+
+
+def take_lines(x: torch.Tensor, step: int, axis: int) -> torch.Tensor:
+    """Every ``step``-th line of the last (``axis`` = 0, x) or second-to-last (``axis`` = 1, y) dim, starting with the
+    first: ``x.isel(dim=slice(None, None, step))`` as a device gather (coarsen.py:265-271 keeps these lines)."""
+    window, stride = (1, 1), ((1, int(step)) if axis == 0 else (int(step), 1))
+    return block_reduce(x, window, stride, op="max", nan_policy="propagate")
+
+
+def repeat(x: torch.Tensor, fy: int, fx: int) -> torch.Tensor:
+    """Repeat each value ``fy`` times along the second-to-last and ``fx`` times along the last dim
+    (``xarray_utils.repeat``, vcm/xarray_utils.py:37-82, a count per horizontal dim)."""
+    dev = _require_device(x)
+    x = x.contiguous()
+    if x.element_size() not in (4, 8):
+        raise TypeError(f"unsupported dtype {x.dtype}")
+    ny, nx = int(x.shape[-2]), int(x.shape[-1])
+    out = torch.empty(tuple(x.shape[:-2]) + (ny * int(fy), nx * int(fx)), dtype=x.dtype, device=dev)
+    _lib.call_on(dev, "fv3hip_repeat", _ptr(x), x.element_size(), _prod(x.shape[:-2]), ny, nx, int(fy), int(fx), _ptr(out), _stream(dev))
+    return out
+
+
 def block_reduce(
     x: torch.Tensor,
     window: Sequence[int],
@@ -488,10 +526,10 @@ def cube_edge_rows(x: torch.Tensor) -> torch.Tensor:
     return rows
 
 
-def interp_center_to_outer(x: torch.Tensor, lo: torch.Tensor, hi: torch.Tensor, axis: int) -> torch.Tensor:
+def interp_center_to_outer(x: torch.Tensor, lo: torch.Tensor, hi: torch.Tensor, axis: int, step: int = 1) -> torch.Tensor:
     """``0.5 * (left + right)`` from cell centres to the n+1 cell edges along the last (``axis`` = 0,
     x) or second-to-last (``axis`` = 1, y) dim; ``lo`` / ``hi`` [..., n_edge] hold the neighbours
-    beyond the two ends (regridz.py:123-135)."""
+    beyond the two ends (regridz.py:123-135).  ``step`` > 1: only every step-th edge (n / step + 1 of them)."""
     dev = _require_device(x)
     code = _float_code(x)
     x = x.contiguous()
@@ -501,8 +539,12 @@ def interp_center_to_outer(x: torch.Tensor, lo: torch.Tensor, hi: torch.Tensor, 
     want = tuple(x.shape[:-2]) + ((ny,) if axis == 0 else (nx,))
     if tuple(lo.shape) != want or tuple(hi.shape) != want:
         raise ValueError(f"halo shape must be {want}, got {tuple(lo.shape)} and {tuple(hi.shape)}")
-    out = torch.empty(tuple(x.shape[:-2]) + (ny + (axis == 1), nx + (axis == 0)), dtype=x.dtype, device=dev)
-    _lib.call_on(dev, "fv3hip_interp_center_to_outer", _ptr(x), code, _prod(x.shape[:-2]), ny, nx, int(axis),
+    step = int(step)
+    if step < 1 or (nx if axis == 0 else ny) % step:
+        raise ValueError(f"the extent along the axis must be a multiple of step={step}")
+    oshape = (ny // step + 1 if axis == 1 else ny, nx // step + 1 if axis == 0 else nx)
+    out = torch.empty(tuple(x.shape[:-2]) + oshape, dtype=x.dtype, device=dev)
+    _lib.call_on(dev, "fv3hip_interp_center_to_outer_lines", _ptr(x), code, _prod(x.shape[:-2]), ny, nx, int(axis), step,
               _ptr(lo), _ptr(hi), _ptr(out), _stream(dev))
     return out
 

@@ -183,7 +183,7 @@ def exchange_edge_rows(local_rows: torch.Tensor, n_tiles: int = 6) -> torch.Tens
     return torch.cat([b[:c] for b, c in zip(bufs, counts)], dim=0)
 
 
-def interp_tiles_to_edges_sharded(local: torch.Tensor, axis: str, n_tiles: int = 6) -> torch.Tensor:
+def interp_tiles_to_edges_sharded(local: torch.Tensor, axis: str, n_tiles: int = 6, step: int = 1) -> torch.Tensor:
     """``cubedsphere.grid.interp_tiles_to_edges`` for tile-sharded data: ``local`` [n_local, ..., n, n]
     holds this rank's tiles (:func:`tiles_of_rank`); the halo rows come from one all-gather."""
     from . import ops
@@ -192,4 +192,4 @@ def interp_tiles_to_edges_sharded(local: torch.Tensor, axis: str, n_tiles: int =
     rank, size = world()
     rows = exchange_edge_rows(ops.cube_edge_rows(local), n_tiles)
     lo, hi = halos_from_rows(rows, tiles_of_rank(size, rank, n_tiles), axis)
-    return ops.interp_center_to_outer(local, lo, hi, 0 if axis == "x" else 1)
+    return ops.interp_center_to_outer(local, lo, hi, 0 if axis == "x" else 1, step=step)

@@ -29,7 +29,7 @@
 extern "C" {
 #endif
 
-#define FV3HIP_ABI_VERSION 2
+#define FV3HIP_ABI_VERSION 3
 
 /* status codes */
 #define FV3HIP_OK 0
@@ -127,6 +127,12 @@ int fv3hip_mass_weighted_block_average(const void *const *fields, int n_fields, 
  * `factor` cells along x, every factor-th row kept along y (out [n_outer][ceil(ny/f)][nx/f]);
  * edge = 1 ('y'): the transpose of that (out [n_outer][ny/f][ceil(nx/f)]).
  */
+/* The general form of the two weighted means above: windows of by x bx cells every (sy, sx) cells,
+ * out [n_outer][(ny - by) / sy + 1][(nx - bx) / sx + 1] (weights as in fv3hip_weighted_block_average; ABI v3).
+ * weighted_block_average = (f, f, f, f); edge_weighted 'x' = (1, f, f, f); on fields already reduced to the kept lines: (1, f, 1, f). */
+int fv3hip_weighted_window_average(const void *obj, int obj_dtype, const void *weights, int w_dtype,
+                                   int64_t n_outer, int ny, int nx, int64_t w_repeat, int by, int bx,
+                                   int sy, int sx, void *out, void *stream);
 int fv3hip_edge_weighted_block_average(const void *obj, int obj_dtype, const void *spacing,
                                        int w_dtype, int64_t n_outer, int ny, int nx,
                                        int64_t w_repeat, int factor, int edge, void *out,
@@ -152,6 +158,10 @@ int fv3hip_block_reduce(const void *in, int dtype, int64_t n_outer, int ny, int 
  * (ny_out = (ny_in-1)*f+1) and an even one is repeated uniformly (ny_out = ny_in*f).
  * elem_size is 4 or 8 bytes.
  */
+/* out[o][y][x] = in[o][y / fy][x / fx], out is [n_outer][ny_in * fy][nx_in * fx] (xarray_utils.repeat, vcm/xarray_utils.py:37-82,
+ * with a count per horizontal dim; ABI v3) */
+int fv3hip_repeat(const void *in, int elem_size, int64_t n_outer, int ny_in, int nx_in, int fy,
+                  int fx, void *out, void *stream);
 int fv3hip_block_upsample(const void *in, int elem_size, int64_t n_outer, int ny_in, int nx_in,
                           int factor, void *out, void *stream);
 
@@ -218,6 +228,12 @@ int fv3hip_cube_edge_rows(const void *in, int elem_size, int n_tiles, int64_t n_
 int fv3hip_interp_center_to_outer(const void *in, int dtype, int64_t n_outer, int ny, int nx,
                                   int axis, const void *lo, const void *hi, void *out,
                                   void *stream);
+/* ... only every step-th edge along the axis (n / step + 1 points; point j' is edge j' * step): the lines
+ * vcm.cubedsphere.edge_weighted_block_average (coarsen.py:221-273) keeps -- the pressure-level D-grid wind path
+ * (regridz.py:81-146, coarsen_restarts.py:497-556) needs the edge pressures on those lines only (ABI v3). */
+int fv3hip_interp_center_to_outer_lines(const void *in, int dtype, int64_t n_outer, int ny, int nx,
+                                        int axis, int step, const void *lo, const void *hi,
+                                        void *out, void *stream);
 
 /* ------------------------------------------------------------------------------------------
  * Vertical: interface pressures and the PPM remap

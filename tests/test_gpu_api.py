@@ -392,6 +392,45 @@ def test_coarsen_restarts_pipelines_medium_size_against_oracle(method):
     assert checked >= 55
 
 
+@pytest.mark.parametrize("edge", ["x", "y"])
+@pytest.mark.parametrize("extrapolate", [False, True])
+def test_edge_weighted_pressure_means_equal_the_full_route(edge, extrapolate):
+    """The pressure-level D-grid wind means computed on the edge lines the edge-weighted mean keeps
+    (regridz.edge_weighted_pressure_means) are bit for bit the reference's route -- remap every fine column, then keep every
+    f-th line (regridz.py:81-146 + coarsen.py:221-273) -- on a whole cube (all 12 edges), both components, with and without
+    extrapolation; so are the D-grid blending weights."""
+    from fv3net_amd.cubedsphere import coarsen_restarts as cr
+    from fv3net_amd.cubedsphere import edge_weighted_block_average
+    from fv3net_amd.cubedsphere.regridz import EdgeLines, edge_weighted_pressure_means, regrid_to_edge_weighted_pressure
+
+    rng = np.random.default_rng(5 if edge == "x" else 6)
+    n, nz, f, toa = 16, 9, 4, 300.0
+    x_dim, y_dim = ("xaxis_1", "yaxis_1") if edge == "x" else ("xaxis_2", "yaxis_2")
+    shape = (6, 1, nz, n + 1, n) if edge == "x" else (6, 1, nz, n, n + 1)
+    name = "u" if edge == "x" else "v"
+    ds = Dataset({name: DataArray(rng.uniform(-30, 30, shape), dims=["tile", "Time", "zaxis_1", y_dim, x_dim],
+                                  coords={y_dim: np.arange(1.0, shape[-2] + 1), x_dim: np.arange(1.0, shape[-1] + 1)},
+                                  attrs={"units": "m/s"})})
+    delp = DataArray(rng.uniform(300, 1500, (6, 1, nz, n, n)), dims=["tile", "Time", "zaxis_1", "yaxis_2", "xaxis_1"])
+    length = DataArray(rng.uniform(0.5, 1, shape[:1] + shape[-2:]).astype(np.float32), dims=["tile", y_dim, x_dim])
+    regridded, masked = regrid_to_edge_weighted_pressure(ds, delp, length, toa, f, x_dim=x_dim, y_dim=y_dim, edge=edge, extrapolate=extrapolate)
+    want = edge_weighted_block_average(regridded, masked, f, x_dim=x_dim, y_dim=y_dim, edge=edge)
+    got = edge_weighted_pressure_means(ds, delp, length, toa, f, x_dim=x_dim, y_dim=y_dim, edge=edge, extrapolate=extrapolate)
+    assert_identical_including_dtype(got[name], want[name])
+    assert 0 < float((masked.values == 0).mean()) < 1  # (the mask did cut coarse levels below the fine surface)
+    lines = EdgeLines(delp, length, f, edge, x_dim, y_dim)
+    w_new = cr._compute_blending_weights_dgrid(delp, length, toa, f, edge, x_dim, y_dim, lines=lines)
+    # the reference's own sequence (coarsen_restarts.py:625-661) on the full edge thicknesses
+    delp_edge = cr.compute_edge_delp(delp, edge, x_dim=x_dim, y_dim=y_dim)
+    delp_edge_coarse = edge_weighted_block_average(delp_edge, length, f, x_dim=x_dim, y_dim=y_dim, edge=edge)
+    pfull = cr.pressure_at_midpoint_log(delp_edge_coarse, toa_pressure=toa, dim="zaxis_1")
+    ps = cr.surface_pressure_from_delp(delp_edge, p_toa=toa, vertical_dim="zaxis_1")
+    ps_c = cr.surface_pressure_from_delp(delp_edge_coarse, p_toa=toa, vertical_dim="zaxis_1")
+    pb = cr._scale(cr.block_edge_coarsen(ps, f, edge=edge, x_dim=x_dim, y_dim=y_dim, method="min"), cr.SIGMA_BLEND)
+    w_old = cr.compute_blending_weights(pb, ps_c, pfull)
+    np.testing.assert_array_equal(w_new.transpose(*w_old.dims).values, w_old.values)
+
+
 # ------------------------------------------------------------------------------------------------
 # fv3fit predictor
 # ------------------------------------------------------------------------------------------------
