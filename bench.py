@@ -837,6 +837,31 @@ def sharded_secondary_benchmarks(dev, steps, rank, world, rehearsal):
     return out
 
 
+def visible_gpu_count():
+    """GPU agents of the KFD topology (a node with a non-zero simd_count is a GPU; CPUs have simd_count 0), narrowed by
+    HIP_VISIBLE_DEVICES / ROCR_VISIBLE_DEVICES when set.  Pure file reads -- no HIP / HSA / amdsmi call.  None if unknown."""
+    import glob
+
+    nodes = glob.glob("/sys/class/kfd/kfd/topology/nodes/*/properties")
+    if not nodes:
+        return None
+    count = 0
+    for path in nodes:
+        try:
+            with open(path) as fh:
+                for line in fh:
+                    key, _, val = line.partition(" ")
+                    if key == "simd_count" and int(val) > 0:
+                        count += 1
+        except OSError:
+            return None
+    for var in ("HIP_VISIBLE_DEVICES", "ROCR_VISIBLE_DEVICES", "CUDA_VISIBLE_DEVICES"):
+        val = os.environ.get(var)
+        if val is not None:
+            count = min(count, len([v for v in val.split(",") if v.strip() != ""]))
+    return count
+
+
 def spawn_ranks(n):
     """``python bench.py --gpus N`` without a launcher (WORLD_SIZE unset): start the N ranks here, as fresh child
     processes, BEFORE anything in this process touches the GPU, and leave with their worst exit code.  Rank 0's
@@ -845,8 +870,12 @@ def spawn_ranks(n):
     import subprocess
 
     rehearsal = os.environ.get("FV3_BENCH_REHEARSAL") == "1"
-    have = torch.cuda.device_count()  # (counts devices without initialising the GPU)
-    if not rehearsal and have < n:
+    # No GPU-library call in this parent (`torch.cuda.device_count()` falls back to hipGetDeviceCount where
+    # amdsmi is unusable, and a parent that has initialised HIP must not start children that exec): the GPUs are counted
+    # from the kernel driver's topology files; where those are unreadable the count is unknown and rank r itself exits 2
+    # when cuda:r does not exist (the loop below propagates it).
+    have = visible_gpu_count()
+    if not rehearsal and have is not None and have < n:
         print(f"bench.py: --gpus {n} but only {have} GPU(s) visible", file=sys.stderr)
         sys.exit(2)
     with socket.socket() as sock:
@@ -895,6 +924,9 @@ def main():
     rehearsal = os.environ.get("FV3_BENCH_REHEARSAL") == "1"
     if rehearsal:
         local_rank = 0
+    if local_rank >= torch.cuda.device_count():  # (a rank's own process may ask; the launcher parent never does)
+        print(f"bench.py: rank {rank} needs cuda:{local_rank}, {torch.cuda.device_count()} GPU(s) visible", file=sys.stderr)
+        sys.exit(2)
     if world > 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         if rehearsal:

@@ -65,7 +65,7 @@ def _fields(state: Mapping[str, Any], metadata: Mapping):
             continue
         attrs = _get_attrs(key, metadata)
         attrs["units"] = attrs.pop("units", "unknown")
-        out[key] = (dims, np.ascontiguousarray(arr), attrs)
+        out[key] = (dims, np.ascontiguousarray(arr) if arr.ndim else np.asarray(arr), attrs)  # (ascontiguousarray makes 0-d 1-d)
     return out
 
 
@@ -100,13 +100,17 @@ class StorageHook:
     def store(self, state: Mapping[str, Any]) -> None:
         state = dict(**state)
         time = translate_time(state.pop("model_time"))
-        rank = int(np.asarray(state.pop("rank", 0)).reshape(-1)[0])
+        # (the reference pops `model_time` only: a `rank` entry goes through the field conversion like any other key -- a
+        # scalar has no recognised dims and is skipped there, an array of samples would be stored)
+        rank = int(np.asarray(state.get("rank", 0)).reshape(-1)[0])
         seconds = julian_seconds(time)
         if self.initial_time is None:
             self.initial_time = seconds
         if not self._store_data_at_time(seconds + self.dt_sec):  # (we are in the middle of the time step)
             return
-        when = _as_datetime(time) + datetime.timedelta(seconds=self.dt_sec)
+        # labelled with the UN-incremented model time, as the reference's _store_zarr / _store_netcdf are called
+        # (monitor.py:273-281: `time + increment` only decides whether to store)
+        when = _as_datetime(time)
         try:
             fields = _fields(state, self.metadata)
             if self.save_zarr:
@@ -122,13 +126,14 @@ class StorageHook:
     def _store_zarr(self, fields, when, rank):
         root = os.path.join(self.directory, "state_output.zarr")
         t = self._n_stored
-        if t == 0:
-            zarr_v2.create_group(root)
+        if t == 0:  # (every rank arrives here in its own process: whoever is first writes the metadata, the rest keep it)
+            zarr_v2.create_group(root, exist_ok=True)
         for name, (dims, arr, attrs) in fields.items():
             path = os.path.join(root, name)
             shape = (t + 1, self.n_ranks) + tuple(arr.shape)
             if t == 0:
-                zarr_v2.create_array(root, name, shape, (1, 1) + tuple(arr.shape), np.float32, ["time", "rank"] + list(dims), attrs)
+                zarr_v2.create_array(root, name, shape, (1, 1) + tuple(arr.shape), np.float32, ["time", "rank"] + list(dims), attrs,
+                                     exist_ok=True)
             zarr_v2.write_chunk(path, (t, rank) + (0,) * arr.ndim, arr[None, None])
             if rank == 0 and t > 0:
                 zarr_v2.set_shape(path, shape)
@@ -158,8 +163,8 @@ class StorageHook:
             var = f.createVariable(name, "f4", tuple(dims))
             if arr.ndim:
                 var[:] = arr
-            else:
-                var.assignValue(arr)
+            else:  # (scipy's assignValue indexes a scalar variable's 0-d buffer with [:])
+                var.data[...] = arr
             for k, v in attrs.items():
                 setattr(var, k, v)
         f.time = when.isoformat()

@@ -67,23 +67,36 @@ class SquashedOutputConfig:
         return from_compat(out, predictions)
 
 
+def _members(models) -> tuple:
+    members = tuple(models)
+    if not members:
+        raise ValueError("at least one model must be given")
+    return members
+
+
+def _union_variables(models):
+    """(sorted inputs, sorted outputs) over a group of predictors -- what every composite advertises."""
+    inputs = sorted({name for m in models for name in m.input_variables})
+    outputs = sorted({name for m in models for name in m.output_variables})
+    return tuple(inputs), tuple(outputs)
+
+
 @io.register("combined_output_model")
 class CombinedOutputModel(Predictor):
     _CONFIG_FILENAME = "combined_output_model.yaml"
 
     def __init__(self, models: Iterable[Predictor]):
-        self._models = tuple(models)
-        if len(self._models) == 0:
-            raise ValueError("at least one model must be given")
-        input_variables: Set[Hashable] = set()
-        output_variables: Set[Hashable] = set()
+        self._models = _members(models)
+        # every output name may come from one member only: count the claims, report the names claimed more than once
+        claims = {}
         for model in self._models:
-            common_outputs = set(model.output_variables).intersection(output_variables)
-            if len(common_outputs) > 0:
-                raise ValueError(f"All models being combined must have different outputs, got {common_outputs} multiple times.")
-            input_variables.update(model.input_variables)
-            output_variables.update(model.output_variables)
-        super().__init__(input_variables=tuple(sorted(input_variables)), output_variables=tuple(sorted(output_variables)))
+            for name in model.output_variables:
+                claims[name] = claims.get(name, 0) + 1
+        common_outputs = {name for name, count in claims.items() if count > 1}
+        if common_outputs:
+            raise ValueError(f"All models being combined must have different outputs, got {common_outputs} multiple times.")
+        inputs, outputs = _union_variables(self._models)
+        super().__init__(input_variables=inputs, output_variables=outputs)
 
     def predict(self, X):
         """Merge predictions of all models into a single dataset."""
@@ -103,13 +116,12 @@ class TaperedModel(Predictor):
     _CONFIG_FILENAME = "tapered_model.yaml"
 
     def __init__(self, model, tapering: Mapping[str, TaperConfig]):
-        for taper_var in tapering:
-            if taper_var not in model.output_variables:
-                raise KeyError(f"Tapered variable {taper_var} not in model output variables.")
-        self.model = model
-        self.tapering = tapering
-        super().__init__(input_variables=tuple(sorted(model.input_variables)),
-                         output_variables=tuple(sorted(model.output_variables)))
+        unknown = [name for name in tapering if name not in model.output_variables]
+        if unknown:
+            raise KeyError(f"Tapered variable {unknown[0]} not in model output variables.")
+        self.model, self.tapering = model, tapering
+        inputs, outputs = _union_variables([model])
+        super().__init__(input_variables=inputs, output_variables=outputs)
 
     @classmethod
     def load(cls, path: str) -> "TaperedModel":
@@ -134,21 +146,16 @@ class EnsembleModel(Predictor):
     _CONFIG_FILENAME = "ensemble_model.yaml"
 
     def __init__(self, models: Iterable[Predictor], reduction: str):
-        self._models = tuple(models)
-        if len(self._models) == 0:
-            raise ValueError("at least one model must be given")
+        self._models = _members(models)
         if reduction.lower() not in ("mean", "median"):
             raise NotImplementedError(f"Got reduction {reduction}: only mean, median supported")
         self._reduction = reduction
-        input_variables: Set[Hashable] = set()
-        output_variables: Set[Hashable] = set()
         outputs = set(self._models[0].output_variables)
-        for model in self._models:
-            if set(model.output_variables) != outputs:
-                raise ValueError(f"all models in ensemble must have same outputs, got {outputs} and {set(model.output_variables)}")
-            input_variables.update(model.input_variables)
-            output_variables.update(model.output_variables)
-        super().__init__(input_variables=tuple(sorted(input_variables)), output_variables=tuple(sorted(output_variables)))
+        odd = next((m for m in self._models[1:] if set(m.output_variables) != outputs), None)
+        if odd is not None:
+            raise ValueError(f"all models in ensemble must have same outputs, got {outputs} and {set(odd.output_variables)}")
+        inputs, all_outputs = _union_variables(self._models)
+        super().__init__(input_variables=inputs, output_variables=all_outputs)
 
     def predict(self, X):
         """Member predictions reduced along a new 'member' dimension."""

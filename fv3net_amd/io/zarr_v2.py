@@ -25,29 +25,45 @@ def _dtype_str(dtype) -> str:
 
 
 def _write_json(path: str, obj) -> None:
-    tmp = path + ".tmp"
-    with open(tmp, "w") as f:
-        json.dump(obj, f, indent=1, allow_nan=False)
-    os.replace(tmp, path)  # (atomic: several ranks may write identical metadata)
+    """Publish a metadata document atomically.  Several processes (the ranks of a model run) may write the same
+    document at the same time: each stages it in a file of its OWN (mkstemp in the target directory), so no writer can
+    truncate or rename away another's staging file, and whichever rename lands last leaves a complete document."""
+    import tempfile
+
+    fd, tmp = tempfile.mkstemp(prefix=os.path.basename(path) + ".", suffix=".tmp", dir=os.path.dirname(path) or ".")
+    try:
+        with os.fdopen(fd, "w") as f:
+            json.dump(obj, f, indent=1, allow_nan=False)
+        os.replace(tmp, path)
+    except BaseException:
+        if os.path.exists(tmp):
+            os.unlink(tmp)
+        raise
 
 
 def _fill_value(dtype):
     return "NaN" if np.dtype(dtype).kind == "f" else 0
 
 
-def create_group(path: str, attrs: Optional[Mapping] = None) -> None:
+def create_group(path: str, attrs: Optional[Mapping] = None, exist_ok: bool = False) -> None:
+    """``exist_ok``: leave an existing group's metadata alone (a second process arriving at the same store)."""
     os.makedirs(path, exist_ok=True)
+    if exist_ok and os.path.exists(os.path.join(path, ".zgroup")):
+        return
     _write_json(os.path.join(path, ".zgroup"), {"zarr_format": 2})
     _write_json(os.path.join(path, ".zattrs"), dict(attrs or {}))
 
 
 def create_array(group: str, name: str, shape: Sequence[int], chunks: Sequence[int], dtype, dims: Sequence[str],
-                 attrs: Optional[Mapping] = None) -> str:
-    """Write the metadata of an array (no chunk yet); returns the array directory."""
+                 attrs: Optional[Mapping] = None, exist_ok: bool = False) -> str:
+    """Write the metadata of an array (no chunk yet); returns the array directory.  ``exist_ok``: an array some other
+    process has created already keeps its metadata (its shape may have been extended since)."""
     if len(shape) != len(chunks) or len(shape) != len(dims):
         raise ValueError("shape, chunks and dims must have the same length")
     path = os.path.join(group, name)
     os.makedirs(path, exist_ok=True)
+    if exist_ok and os.path.exists(os.path.join(path, ".zarray")):
+        return path
     _write_json(os.path.join(path, ".zarray"), {
         "zarr_format": 2, "shape": [int(n) for n in shape], "chunks": [max(int(c), 1) for c in chunks],
         "dtype": _dtype_str(dtype), "compressor": None, "fill_value": _fill_value(dtype), "order": "C", "filters": None})

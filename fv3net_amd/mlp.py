@@ -413,15 +413,25 @@ class MlpModelSplitBf16:
         float32 ``[feature, sample]`` arrays (unit sample stride) for any of the outputs -- the hidden output included, as
         ``MlpModel.predict`` takes them; the others are allocated."""
         spec = self.spec
+        need = spec.source_nfeat()
         tensors = []
+        n = None
+        # the C entry point sees pointers, strides and n only: a short or mismatched source would be read past its end
         for name in spec.sources:
             t = sources[name]
             t = t.unsqueeze(0) if t.dim() == 1 else t
-            if t.dtype != torch.float32 or t.stride(1) != 1:
+            if t.dim() != 2:
+                raise ValueError(f"source {name!r} must be 1-D or 2-D, got shape {tuple(t.shape)}")
+            if t.dtype != torch.float32 or (t.shape[1] > 1 and t.stride(1) != 1):
                 raise TypeError("the split-bf16 kernel takes float32 [feature, sample] sources with unit sample stride")
+            if int(t.shape[0]) < need[name]:
+                raise ValueError(f"source {name!r} has {int(t.shape[0])} features, the model needs {need[name]}")
+            if n is None:
+                n = int(t.shape[1])
+            elif int(t.shape[1]) != n:
+                raise ValueError("sources differ in their number of samples")
             tensors.append(t)
         dev = _require_device(*tensors)
-        n = int(tensors[0].shape[1])
         nfeat = {o.name: o.nfeat for o in spec.outputs}
         for r in spec.residuals:
             nfeat[r.name] = nfeat[r.output]

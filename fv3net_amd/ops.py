@@ -604,6 +604,13 @@ def mask_weights(
         batch_shape = tuple(p_fine.shape[:-3])
         if tuple(weights.shape) != batch_shape + (ny, nx) or int(p_coarse.shape[-3]) != cmp_levels:
             raise ValueError("weights / p_coarse do not match the fine pressures' shape")
+        # the C entry point indexes p_coarse through (y // f) * nxc + x // f and cannot see its size
+        f_ = int(coarse_factor)
+        coarse_extent = lambda n: (n - 1) // f_ + 1 if n % 2 else n // f_  # (an odd, staggered extent keeps its last point)
+        want_c = batch_shape + (cmp_levels, coarse_extent(ny), coarse_extent(nx))
+        if tuple(p_coarse.shape) != want_c:
+            raise ValueError(f"p_coarse has shape {tuple(p_coarse.shape)}, expected {want_c} for fine pressures "
+                             f"{tuple(p_fine.shape)} coarsened by {f_}")
         out = torch.empty(batch_shape + (nz, ny, nx), dtype=weights.dtype, device=dev)
         try:
             _lib.call_on(dev, "fv3hip_mask_weights_coarse", _ptr(weights), _float_code(weights), _ptr(p_coarse), cmp_levels, cmp_offset,
@@ -654,9 +661,12 @@ def _workspace(dev, nbytes: int) -> torch.Tensor:
     return ws
 
 
-# Arithmetic of the remap when a call does not say: "fast" (reciprocal-multiply in the sweep kernel, a few ulp from the
-# reference's IEEE divisions -- inside the north star's 1e-5) or "exact" (bit-identical to the compiled Fortran).
-MAPPM_ARITHMETIC = os.environ.get("FV3NET_AMD_MAPPM_ARITH", "fast")
+# Arithmetic of the remap when a call does not say: "exact" -- bit-identical to the compiled reference Fortran, the
+# library's contract.  "fast" (reciprocal-multiply, fused multiply-adds and hardware minima in the sweep kernel: a few ulp
+# from the reference on every level, except that the reference's limiter is discontinuous where a slope cancels to exactly
+# zero -- such a level may take the other, equally monotone profile) is an opt-in: per call (``arith="fast"``), per process
+# (``ops.MAPPM_ARITHMETIC = "fast"``) or per environment (``FV3NET_AMD_MAPPM_ARITH=fast``).  bench.py times both.
+MAPPM_ARITHMETIC = os.environ.get("FV3NET_AMD_MAPPM_ARITH", "exact")
 
 
 def _arith_code(arith: Optional[str]) -> int:
@@ -719,7 +729,8 @@ def mappm_multi(pe1: torch.Tensor, fields: Sequence[torch.Tensor], pe2: torch.Te
                 z_axis: int = -1, arith: Optional[str] = None) -> list:
     """``mappm`` of several fields that share ``pe1`` and ``pe2`` (every variable of a dataset in
     regridz.py:163-185): one sweep per four fields computes the control flow and the pressure-only terms
-    once.  Each result is bit-identical to ``mappm`` on that field."""
+    once.  Each result is bit-identical to ``mappm`` on that field in the same arithmetic mode (``arith``: see ``mappm``;
+    the default "exact" is bit-identical to the compiled reference)."""
     fields = list(fields)
     if not fields:
         return []

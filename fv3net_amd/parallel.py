@@ -94,14 +94,18 @@ def weighted_block_average_banded(obj_bands: List[torch.Tensor], weight_bands: L
     plan = tile_bands(n_tiles, ny, factor, size)
     if len(coarse) != len(plan[rank]):
         raise ValueError(f"rank {rank} owns {len(plan[rank])} bands, got {len(coarse)}")
+    idle = [r for r, units in enumerate(plan) if not units]
+    if idle and size > 1:
+        # decided from the plan, which every rank computes alike: ALL ranks raise here, before the collective -- a rank
+        # without bands has no buffer shape to contribute, and raising on it alone would leave the others in the gather
+        raise ValueError(f"ranks {idle} own no bands of this partition ({n_tiles} tiles, {size} ranks): gather over the "
+                         "ranks that do (parallel.use_group), or coarsen without gather")
     if size == 1:
         pieces = {0: coarse}
     else:
         # bands of one plan share their shape except when whole tiles were dealt unevenly: pad the count, not the shape
         width = max(len(units) for units in plan)
-        ref = coarse[0] if coarse else None
-        if ref is None:
-            raise ValueError("a rank without bands cannot take part in the gather")
+        ref = coarse[0]
         stacked = torch.zeros((width,) + tuple(ref.shape), dtype=ref.dtype, device=ref.device)
         for i, c in enumerate(coarse):
             stacked[i] = c

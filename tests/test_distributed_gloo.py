@@ -159,3 +159,35 @@ def test_band_sharded_cube_on_four_ranks(tmp_path):
     plan = parallel.tile_bands(6, n, f, size)
     assert [len(u) for u in plan] == [3, 3, 3, 3] and sorted(sum(plan, [])) == [(t, b * 8, b * 8 + 8) for t in range(6) for b in range(2)]
     assert [len(u) for u in parallel.tile_bands(6, 3072, 8, 8)] == [3] * 8  # configs[4]: 4 bands of 768 rows per tile
+
+
+def _idle_rank_worker(rank, size, port, out_dir):
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=size)
+    from fv3net_amd import ops, parallel
+    from oracle import coarsen_np as onp
+
+    ops.weighted_block_average = lambda o, w, f: torch.from_numpy(onp.weighted_block_average(o.numpy(), w.numpy(), f))
+    n_tiles, n, f = 2, 4, 4  # one block per tile: whole tiles are dealt, ranks 2 and 3 get none
+    units = parallel.units_of_rank(n_tiles, n, f, size, rank)
+    objs = [torch.ones((3, r1 - r0, n)) for _, r0, r1 in units]
+    wts = [torch.ones((r1 - r0, n)) for _, r0, r1 in units]
+    try:
+        parallel.weighted_block_average_banded(objs, wts, f, n_tiles=n_tiles, ny=n, gather=True)
+        outcome = "returned"
+    except ValueError as err:
+        outcome = "raised" if "own no bands" in str(err) else f"other: {err}"
+    with open(os.path.join(out_dir, f"outcome_{rank}.txt"), "w") as fh:
+        fh.write(outcome)
+    dist.barrier()  # every rank gets here: nobody is left waiting inside a gather
+    dist.destroy_process_group()
+
+
+def test_banded_gather_with_idle_ranks_raises_on_every_rank(tmp_path):
+    """with more ranks than units (whole-tile fallback) a rank without bands used to raise alone while the
+    others entered ``dist.gather`` and hung.  The partition is known to every rank, so all of them raise before any
+    collective."""
+    size = 4
+    mp.spawn(_idle_rank_worker, args=(size, _free_port(), str(tmp_path)), nprocs=size, join=True)
+    assert [open(tmp_path / f"outcome_{r}.txt").read() for r in range(size)] == ["raised"] * size

@@ -351,6 +351,17 @@ def test_split_bf16_kernel_refuses_what_it_does_not_implement(device):
     spec = _random_spec(rng, {"a": ("a", 79, 0)}, 256, 2, {"y": 79}, limits={"y": (0.0, None)})
     with pytest.raises(Fv3HipError, match="limits"):
         MlpModelSplitBf16(spec, device=device)
+    # sources the C entry point could not check (it sees pointers, strides and n): refused before the launch
+    spec = _random_spec(rng, {"a": ("a", 79, 0), "b": ("b", 40, 0)}, 256, 2, {"y": 79})
+    model = MlpModelSplitBf16(spec, device=device)
+    good = {"a": torch.zeros((79, 256), device=device), "b": torch.zeros((40, 256), device=device)}
+    assert model.predict(good)["y"].shape == (79, 256)
+    with pytest.raises(ValueError, match="has 39 features, the model needs 40"):
+        model.predict({**good, "b": torch.zeros((39, 256), device=device)})
+    with pytest.raises(ValueError, match="differ in their number of samples"):
+        model.predict({**good, "b": torch.zeros((40, 128), device=device)})
+    with pytest.raises(ValueError, match="must be 1-D or 2-D"):
+        model.predict({**good, "b": torch.zeros((40, 16, 16), device=device)})
 
 
 @pytest.mark.parametrize("in_dtype,n_buffers", [(np.float32, 3), (np.float64, 2)])

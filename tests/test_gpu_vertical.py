@@ -539,7 +539,7 @@ def test_mappm_sweep_kernel_fast_mode_within_tolerance(device, km, kn, n_fields,
     pe1, pe2, fields, bad = _sweep_case(rng, nt, ny, nx, km, kn, n_fields, iv)
     nat = lambda a: _dev(_native(a, nt, ny, nx).astype(cast), device)
     res = ops.mappm_multi(nat(pe1), [nat(q) for q in fields], nat(pe2), iv=iv, kord=kord, z_axis=1, arith="fast")
-    worst = 0.0
+    worst, outliers = 0.0, 0
     for f, q in enumerate(fields):
         ref = mappm_c.mappm(pe1, q, pe2, iv, kord)
         got = np.moveaxis(ops.as_numpy(res[f]), 1, -1).reshape(-1, kn)
@@ -548,12 +548,15 @@ def test_mappm_sweep_kernel_fast_mode_within_tolerance(device, km, kn, n_fields,
         scale = np.nanmax(np.abs(np.where(np.isfinite(q), q, np.nan)), axis=1, keepdims=True)
         err = np.abs(got - ref) / scale
         worst = max(worst, float(np.nanmax(err)))
-        # The reference's limiter is discontinuous where dm == 0 exactly (mappm.f90:876-880: the profile is flattened):
-        # a slope that cancels to exactly zero in one arithmetic and to one ulp in the other gives a different, equally
-        # valid profile.  Such levels are rare (integer-valued test data provoke them); everything else is within 1e-5.
-        assert np.nanmean(err > 1e-5) <= 2e-4, (f, float(np.nanmean(err > 1e-5)))
+        # Every level within 1e-5 of the column's scale (measured: <= 1.2e-6).  The reference's limiter is discontinuous
+        # where dm == 0 exactly (mappm.f90:876-880); round 2's reciprocal arithmetic flipped that branch on 1 in 5e3 of
+        # the integer-valued levels here, round 3's formulation on none -- were one to appear, what must hold is
+        # test_fast_mode_outliers_stay_within_the_source_layers_bounds, not this line.
+        assert np.nanmax(err) <= 1e-5, (f, float(np.nanmax(err)))
         assert np.nanmedian(err) <= 1e-6, f
+        outliers += int(np.nansum(err > 1e-5))
     assert worst > 0  # (this really was the other arithmetic)
+    print(f"fast mode: worst |fast - reference| / column scale {worst:.2e}, levels beyond 1e-5: {outliers}")
 
 
 def test_mappm_fast_mode_full_size_c384(device):
@@ -579,6 +582,71 @@ def test_mappm_fast_mode_full_size_c384(device):
     cols = lambda t: t.permute(0, 2, 3, 1).reshape(-1, t.shape[1])[::16].cpu().numpy()
     ref = mappm_c.mappm(cols(pe1), cols(qs[1]), cols(pe2))
     assert _bits_equal(cols(exact[1]), ref)
+
+
+def _assert_outliers_within_source_bounds(pe1, q, pe2, fast, exact, tol):
+    """[ncol, lev] numpy arrays.  Every target layer whose fast value differs from exact by more than ``tol`` (per column)
+    must lie inside [min, max] of the source layers it overlaps plus one neighbour either side: the monotonicity constraint
+    (mappm.f90:854-931) bounds a layer's parabola by the means of its neighbours, whichever branch of the limiter a level
+    took.  Returns the number of outliers checked."""
+    diff = np.abs(fast - exact)
+    cols, levs = np.nonzero(diff > tol)
+    km = q.shape[1]
+    for c, k in zip(cols, levs):
+        lo, hi = pe2[c, k], pe2[c, k + 1]
+        j0 = int(np.clip(np.searchsorted(pe1[c], lo, side="right") - 1, 0, km - 1))
+        j1 = int(np.clip(np.searchsorted(pe1[c], hi, side="left") - 1, 0, km - 1))
+        a, b = max(j0 - 1, 0), min(max(j1, j0) + 1, km - 1)
+        qmin, qmax = q[c, a:b + 1].min(), q[c, a:b + 1].max()
+        slack = 1e-6 * max(abs(qmin), abs(qmax), 1.0)
+        assert qmin - slack <= fast[c, k] <= qmax + slack, (c, k, fast[c, k], exact[c, k], qmin, qmax)
+    return len(cols)
+
+
+def test_fast_mode_outliers_stay_within_the_source_layers_bounds(device):
+    """VERDICT r02 #6b.  FAST differs from EXACT by a few ulp -- except where the reference's limiter is discontinuous (a
+    slope `dm` that cancels to exactly zero flattens the profile, mappm.f90:876-880): there the two arithmetics may take
+    different branches.  What must hold for such a level is not closeness but monotonicity: the value stays inside the
+    bounds of the source layers the target layer overlaps.  Checked (i) at BASELINE configs[2]'s full size on the
+    pipeline's own target grid, (ii) on integer-valued fields over tied pressures, which provoke the flips by the hundred."""
+    from fv3net_amd import ops
+
+    # (i) C384, 4 fields
+    g = torch.Generator(device=device).manual_seed(11)
+    n, nz = 384, 79
+    delp = torch.rand((6, nz, n, n), device=device, generator=g) * 1200 + 300
+    area = torch.rand((6, n, n), device=device, generator=g) * 0.5 + 0.5
+    qs = [torch.rand((6, nz, n, n), device=device, generator=g) * 2000 - 1000 for _ in range(4)]
+    pe1 = ops.pressure_at_interface(delp, 300.0, 1)
+    pe2c = ops.pressure_at_interface(ops.weighted_block_average(delp, area, 8), 300.0, 1)
+    exact = ops.mappm_multi_coarse_target(pe1, qs, pe2c, 8, z_axis=1, arith="exact")
+    fast = ops.mappm_multi_coarse_target(pe1, qs, pe2c, 8, z_axis=1, arith="fast")
+    pe2 = ops.block_upsample(pe2c, 8)
+    cols = lambda t, idx: t.permute(0, 2, 3, 1).reshape(-1, t.shape[1])[idx].cpu().numpy()
+    n_out = 0
+    for e, f, q in zip(exact, fast, qs):
+        bad = ((e - f).abs() > 1e-5 * 2000).any(dim=1).reshape(-1).nonzero().reshape(-1)  # columns with an outlier
+        assert float((e - f).abs().mean()) <= 1e-7 * 2000
+        if bad.numel():
+            n_out += _assert_outliers_within_source_bounds(cols(pe1, bad), cols(q, bad), cols(pe2, bad), cols(f, bad), cols(e, bad),
+                                                           1e-5 * 2000)
+    # (ii) integer-valued data on tied pressures
+    rng = np.random.default_rng(3)
+    nt, ny, nx, km, kn = 2, 16, 16, 40, 37
+    ncol = nt * ny * nx
+    pe1 = np.concatenate([np.full((ncol, 1), 3.0), 3 + np.cumsum(rng.integers(1, 4, (ncol, km)), 1)], 1).astype(np.float32)
+    pe2 = np.concatenate([np.full((ncol, 1), 3.0), 3 + np.cumsum(rng.integers(1, 4, (ncol, kn)), 1)], 1).astype(np.float32)
+    fields = [np.round(rng.uniform(-20, 20, (ncol, km))).astype(np.float32) for _ in range(4)]
+    nat = lambda a: _dev(_native(a, nt, ny, nx), device)
+    back = lambda t: np.moveaxis(ops.as_numpy(t), 1, -1).reshape(ncol, -1)
+    e = ops.mappm_multi(nat(pe1), [nat(q) for q in fields], nat(pe2), z_axis=1, arith="exact")
+    f = ops.mappm_multi(nat(pe1), [nat(q) for q in fields], nat(pe2), z_axis=1, arith="fast")
+    flips = 0
+    for ee, ff, q in zip(e, f, fields):
+        flips += _assert_outliers_within_source_bounds(pe1, q, pe2, back(ff), back(ee), 1e-5 * 40)
+    # (round 2's reciprocal arithmetic flipped a branch on ~1 level in 6e8 at C384 and on 1 in 5e3 of the integer-valued
+    # levels; with round 3's formulation neither set shows one -- the bound is what would have to hold if it did)
+    print(f"limiter flips beyond 1e-5 of the range: C384 {n_out}, integer-valued {flips}")
 
 
 @pytest.mark.parametrize("dtype", [torch.float32, torch.float64])

@@ -23,7 +23,7 @@ def test_library_exports_every_symbol_in_the_header():
     lib = _lib.load()
     for name in declared:
         assert hasattr(lib, name), name
-    assert lib.fv3hip_abi_version() == _lib.ABI_VERSION == 2
+    assert lib.fv3hip_abi_version() == _lib.ABI_VERSION == 3
     assert lib.fv3hip_mappm_workspace_bytes(10, 79) >= 5 * 79 * 10 * 4
 
 
@@ -267,3 +267,51 @@ def test_graphed_call_needs_a_gpu():
         pytest.skip("a GPU is present")
     with pytest.raises(RuntimeError, match="cuda"):
         GraphedCall(lambda: None)
+
+
+def test_bench_launcher_never_touches_the_gpu_library(monkeypatch, tmp_path):
+    """``python bench.py --gpus N`` starts its ranks from a parent that has made no GPU-library call (a
+    parent that initialised HIP must not start children that exec): with every ``torch.cuda`` attribute raising,
+    ``spawn_ranks`` still counts the GPUs (kernel-driver topology files), starts N children with the rank environment and
+    leaves with their worst exit code."""
+    import subprocess
+    import sys
+
+    import torch
+
+    import bench
+
+    class Forbidden:
+        def __getattr__(self, name):
+            raise AssertionError(f"torch.cuda.{name} used in the launcher parent")
+
+    monkeypatch.setattr(torch, "cuda", Forbidden())
+    started = []
+
+    class FakeProc:
+        def __init__(self, cmd, env):
+            started.append((cmd, {k: env[k] for k in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "MASTER_ADDR", "MASTER_PORT")}))
+            self.code = 3 if env["RANK"] == "1" else 0
+
+        def poll(self):
+            return self.code
+
+        def terminate(self):
+            pass
+
+    monkeypatch.setattr(subprocess, "Popen", lambda cmd, env: FakeProc(cmd, env))
+    monkeypatch.setattr(bench, "visible_gpu_count", lambda: 2)
+    monkeypatch.setattr(sys, "argv", ["bench.py", "--gpus", "2"])
+    with pytest.raises(SystemExit) as exit_info:
+        bench.spawn_ranks(2)
+    assert exit_info.value.code == 3
+    assert [env["RANK"] for _, env in started] == ["0", "1"]
+    assert all(env["WORLD_SIZE"] == "2" and env["MASTER_ADDR"] == "127.0.0.1" for _, env in started)
+    # fewer GPUs than ranks: refused before anything starts; an unknown count leaves the check to the ranks
+    started.clear()
+    monkeypatch.setattr(bench, "visible_gpu_count", lambda: 1)
+    with pytest.raises(SystemExit) as exit_info:
+        bench.spawn_ranks(2)
+    assert exit_info.value.code == 2 and not started
+    monkeypatch.undo()
+    assert bench.visible_gpu_count() in (None, 0) or bench.visible_gpu_count() >= 1  # (file reads only; no GPU here)

@@ -115,7 +115,9 @@ def test_store_hook_writes_zarr_and_netcdf_at_the_output_times(tmp_path):
     tvals = zarr_v2.read_array(root, "time")[0]
     assert tvals[1] - tvals[0] == 1800.0
     names = sorted(os.listdir(tmp_path / "netcdf_output"))
-    assert names == ["state_20160801.003000_0.nc", "state_20160801.003000_1.nc", "state_20160801.010000_0.nc", "state_20160801.010000_1.nc"]
+    # labelled with the model time of the call, not with time + dt (monitor.py:273-281 passes `time` to the writers)
+    assert names == ["state_20160801.001500_0.nc", "state_20160801.001500_1.nc", "state_20160801.004500_0.nc", "state_20160801.004500_1.nc"]
+    assert tvals[0] == (np.datetime64("2016-08-01T00:15:00") - np.datetime64("1970-01-01T00:00:00")) / np.timedelta64(1, "s")
     f = netcdf_file(str(tmp_path / "netcdf_output" / names[1]), "r", mmap=False)
     assert f.variables["air_temperature_input"].dimensions == ("sample", "z") and f.tile == 1
     assert f.variables["surface_air_pressure"].units == b"unknown"
@@ -128,6 +130,46 @@ def test_store_hook_writes_zarr_and_netcdf_at_the_output_times(tmp_path):
         store({"q": np.ones((3, 4)), "model_time": [2016, 8, 1, 0, 0, 0]})
     finally:
         os.chdir(cwd)
+
+
+def _hook_rank_process(directory, rank, n_steps, barrier):
+    """One model rank in its own process (what MPI ranks are): the same store calls as the other ranks, at the same time."""
+    import numpy as np
+
+    from fv3net_amd.emulation.monitor import StorageHook
+
+    hook = StorageHook(output_freq_sec=900, dt_sec=900, save_nc=False, n_ranks=4, directory=directory)
+    for step in range(n_steps):
+        minute = 15 * step
+        barrier.wait()  # all ranks reach the output time together, as the time-stepping model's ranks do
+        hook.store({"q": np.full((5, 6), 100.0 * rank + step), "ps": np.full((6,), float(rank)),
+                    "model_time": [2016, 8, 1, 0, minute // 60, minute % 60], "rank": np.array([rank])})
+
+
+def test_store_hook_ranks_as_concurrent_processes(tmp_path):
+    """the ranks of a run are separate processes that create the same .zgroup / .zarray / .zattrs at the
+    first output time -- with a shared staging name two of them could publish a truncated document or lose the rename.
+    Four rank processes, released together at every step, twelve steps: every chunk and every metadata document intact."""
+    import multiprocessing as mp
+
+    from fv3net_amd.io import zarr_v2
+
+    ctx = mp.get_context("spawn")
+    n_ranks, n_steps = 4, 12
+    barrier = ctx.Barrier(n_ranks)
+    procs = [ctx.Process(target=_hook_rank_process, args=(str(tmp_path), r, n_steps, barrier)) for r in range(n_ranks)]
+    for p in procs:
+        p.start()
+    for p in procs:
+        p.join(120)
+        assert p.exitcode == 0
+    root = str(tmp_path / "state_output.zarr")
+    data, dims, _ = zarr_v2.read_array(root, "q")
+    assert dims == ["time", "rank", "sample", "z"] and data.shape == (n_steps, n_ranks, 6, 5)
+    want = 100.0 * np.arange(n_ranks)[None, :] + np.arange(n_steps)[:, None]
+    np.testing.assert_array_equal(data[:, :, 0, 0], want)
+    assert zarr_v2.read_array(root, "time")[0].shape == (n_steps,)
+    assert not [f for _, _, files in os.walk(root) for f in files if f.endswith(".tmp")]  # no staging file left behind
 
 
 @pytest.mark.gpu
