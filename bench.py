@@ -83,11 +83,19 @@ def zc_inputs_numpy(rng, n):
     return {k: v.astype(np.float32) for k, v in src.items()}
 
 
-def zc_spec(seed=0, residuals=True):
+def _per_level_output(OutputSpec, rng, name, nfeat, scale_fn):
+    scale = np.asarray(scale_fn(rng, nfeat), dtype=np.float32)
+    return OutputSpec(name, nfeat, scale=scale, center=(rng.normal(0, 1, nfeat) * scale).astype(np.float32))
+
+
+def zc_spec(seed=0, residuals=True, per_level_output_scale=None):
     """Random-init weights of the reference architecture; normalisation fitted on a sample the
     way MicrophysicsConfig does (center per feature, one std over all features).  ``residuals``: the
     production graph of dense.yaml, whose five difference outputs also leave as ``after = before +
-    difference`` (396 + 395 output rows); False: the 396 direct outputs only."""
+    difference`` (396 + 395 output rows); False: the 396 direct outputs only.
+    ``per_level_output_scale(rng, nfeat) -> [nfeat]``: per-feature output standard deviations (StdDevMethod.per_feature,
+    normalization.py:105-114) instead of one per variable -- the parity tests let them span > 4 decades over the levels;
+    the arithmetic and the kernel instantiation are the same (scale and centre are folded into the output weights)."""
     from fv3net_amd.mlp import InputSpec, MlpSpec, OutputSpec, ResidualSpec
 
     def fit_mean_per_feature(data):  # MeanMethod.per_feature (emulation/layers/normalization.py:117-128)
@@ -117,6 +125,7 @@ def zc_spec(seed=0, residuals=True):
         hidden_kernels=[glorot(k, w), glorot(w, w)],
         hidden_biases=[rng.normal(0, 0.01, w).astype(np.float32) for _ in range(2)],
         outputs=[OutputSpec(n_, nf, scale=np.float32(rng.uniform(0.5, 2)), center=rng.normal(0, 1, nf).astype(np.float32))
+                 if per_level_output_scale is None else _per_level_output(OutputSpec, rng, n_, nf, per_level_output_scale)
                  for n_, nf in OUTPUTS.items()],
         out_kernel=glorot(w, f),
         out_bias=rng.normal(0, 0.01, f).astype(np.float32),
