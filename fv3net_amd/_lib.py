@@ -175,6 +175,7 @@ SIGNATURES = {
          POINTER(c_void_p), c_int, POINTER(c_int64), POINTER(c_int64), c_void_p],
     ),
     "fv3hip_mlp_flops_per_sample": (c_int64, [c_void_p]),
+    "fv3hip_mlp_set_small_limit": (c_int, [c_void_p, c_int64]),
     "fv3hip_mlp_last_variant": (c_char_p, [c_void_p]),
     "fv3hip_mlp3_create": (c_int, [POINTER(MlpDesc), POINTER(c_void_p)]),
     "fv3hip_mlp3_destroy": (c_int, [c_void_p]),

@@ -1085,6 +1085,208 @@ __global__ __launch_bounds__(kThreads, 1) void mlp_fused_kernel(const MlpLaunch 
 #endif
 }
 
+// ---------------------------------------------------------------------------------------------
+// Small sample counts: one model rank's columns (2 304 at C48 on 6 ranks) are 18 tiles of the kernel above -- 18 of 256 CUs,
+// and a wave spends a whole tile's matrix time (~390 K cycles for the Zhao-Carr graph) on its 32 columns whatever the
+// count.  mlp_small_kernel gives 32 samples to a WORKGROUP instead and splits the layers' output features over its
+// waves (32-feature tiles dealt round-robin): four times as many CUs work on a call, and a call lasts a quarter of a tile.
+// The price is an exchange of every layer's activations through LDS (one barrier per layer) and weights read straight from
+// L2 in operand layout (nothing to share between waves, so no LDS staging) -- throughput per CU is no better than the big
+// kernel's, so the host picks this kernel only while the big one would leave CUs idle (fv3hip_mlp_predict).
+// Same graph, same float32 MFMA arithmetic (v_mfma_f32_32x32x2_f32, bias as the initial accumulator, one rounding per
+// folded weight), the contraction in plain feature order; the general per-value epilogue (any strides and dtypes, limits,
+// masks, residual and hidden outputs).  Checked against the same float64 oracle at the same per-level tolerance
+// (tests/test_gpu_mlp.py::test_small_sample_kernel_*).
+// ---------------------------------------------------------------------------------------------
+struct SmallLaunch {
+    const float *w1;   // [n_ktab][Wp]   layer 1, rows in table order (log inputs first), 1 / std folded in
+    const float *wh;   // [n_hidden - 1][Wp][Wp]
+    const float *wo;   // [Wp][Fp]       output scale folded in
+    const float *bh;   // [n_hidden][Wp]
+    const float *bo;   // [Fp]           output scale and centre folded in
+    const KEntry *ktab;
+    const OEntry *otab;
+    int n_ktab, Wp, HT, n_hidden, Fp, n_otiles, n_hout_tiles, out64, has_limits, hout_slot;
+    int64_t n_samples;
+    const void *src[kMaxSources];
+    int64_t src_fs[kMaxSources];
+    int64_t src_ss[kMaxSources];
+    void *out[kMaxOutputs];
+    int64_t out_fs[kMaxOutputs];
+    int64_t out_ss[kMaxOutputs];
+};
+
+constexpr int kSmallWaves = 8;     // 512 threads: two waves per SIMD hide each other's operand loads
+constexpr int kSmallChunk = 128;   // input features staged per step (2 x 16 KB of LDS)
+
+template <bool SRC64>
+__global__ __launch_bounds__(kSmallWaves * 64) void mlp_small_kernel(const SmallLaunch p)
+{
+    using Raw = typename std::conditional<SRC64, double, float>::type;
+    constexpr int NW = kSmallWaves, NT = NW * 64, KCH = kSmallChunk, PER = KCH * 32 / NT;
+    constexpr int MAXT = (8 + NW - 1) / NW;  // hidden tiles a wave may own (HT <= 8)
+    extern __shared__ float small_lds[];
+    float *xs = small_lds;               // [2][KCH][32]
+    float *hA = xs + 2 * KCH * 32;       // [Wp][32]
+    float *hB = hA + p.Wp * 32;          // [Wp][32]
+    const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63, half = lane >> 5, col = lane & 31;
+    const int64_t n0 = (int64_t)blockIdx.x * 32;
+    const int Wp = p.Wp, HT = p.HT;
+    const int n_chunks = (p.n_ktab + KCH - 1) / KCH;
+
+    // ---- input staging: raw loads now, transform + centre when the rows are parked in LDS ----
+    Raw xr[PER];
+    auto issue = [&](int c) {
+#pragma unroll
+        for (int j = 0; j < PER; ++j) {
+            const int idx = tid + j * NT, kk = idx >> 5, n = idx & 31, k = c * KCH + kk;
+            xr[j] = (Raw)1;
+            if (k < p.n_ktab) {
+                const KEntry e = p.ktab[k];
+                int64_t ns = n0 + n;
+                if (ns >= p.n_samples) ns = p.n_samples - 1;  // (a ragged last tile reads its last sample again)
+                if (e.src >= 0) xr[j] = static_cast<const Raw *>(p.src[e.src])[(int64_t)e.feat * p.src_fs[e.src] + ns * p.src_ss[e.src]];
+            }
+        }
+    };
+    auto commit = [&](int c, int buf) {
+#pragma unroll
+        for (int j = 0; j < PER; ++j) {
+            const int idx = tid + j * NT, kk = idx >> 5, n = idx & 31, k = c * KCH + kk;
+            float v = 0.f;
+            if (k < p.n_ktab) {
+                const KEntry e = p.ktab[k];
+                if (e.src >= 0) {
+                    v = (float)xr[j];
+                    if (e.transform == FV3HIP_TRANSFORM_LOG) v = logf(v < e.eps ? e.eps : v);
+                    v = v - e.center;  // (1 / std lives in the layer-1 weights)
+                }
+            }
+            xs[(buf * KCH + kk) * 32 + n] = v;
+        }
+    };
+    f32x16 acc[MAXT];
+    auto init_bias = [&](const float *b) {
+#pragma unroll
+        for (int ti = 0; ti < MAXT; ++ti) {
+            const int t = wave + ti * NW;
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[ti][r] = (t < HT) ? b[32 * t + rho(r) + 4 * half] : 0.f;
+        }
+    };
+    // one block of k-pairs against this wave's tiles: B[k][sample] from LDS, A[feature][k] from the plain weight rows
+    auto contract = [&](const float *bsrc, const float *wrow0, int n_pairs, int ldw) {
+        constexpr int U = 8;  // operand loads run U pairs ahead of their MFMAs
+        for (int p0 = 0; p0 < n_pairs; p0 += U) {
+            float a[MAXT][U], b[U];
+#pragma unroll
+            for (int u = 0; u < U; ++u) {
+                const int k = 2 * (p0 + u) + half;
+                b[u] = bsrc[k * 32 + col];
+#pragma unroll
+                for (int ti = 0; ti < MAXT; ++ti) {
+                    const int t = wave + ti * NW;
+                    a[ti][u] = (t < HT) ? wrow0[(int64_t)k * ldw + 32 * t + col] : 0.f;
+                }
+            }
+#pragma unroll
+            for (int u = 0; u < U; ++u)
+#pragma unroll
+                for (int ti = 0; ti < MAXT; ++ti)
+                    if (wave + ti * NW < HT) acc[ti] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[ti][u], b[u], acc[ti], 0, 0, 0);
+        }
+    };
+    // ReLU, park the activations for the next layer (and hand them out when the model returns its last hidden layer)
+    auto finish_hidden = [&](float *dst, bool last) {
+#pragma unroll
+        for (int ti = 0; ti < MAXT; ++ti) {
+            const int t = wave + ti * NW;
+            if (t >= HT) continue;
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int f = 32 * t + rho(r) + 4 * half;
+                const float h = acc[ti][r] < 0.f ? 0.f : acc[ti][r];  // (a NaN stays a NaN, as in the big kernel and in Keras' relu)
+                dst[f * 32 + col] = h;
+                if (last && p.n_hout_tiles) {
+                    const OEntry e = p.otab[f];
+                    if (e.out_feat >= 0 && n0 + col < p.n_samples) {
+                        const int slot = e.out_feat >> 20, q = e.out_feat & 0xFFFFF;
+                        const int64_t off = (int64_t)q * p.out_fs[slot] + (n0 + col) * p.out_ss[slot];
+                        if (p.out64) static_cast<double *>(p.out[slot])[off] = (double)h;
+                        else static_cast<float *>(p.out[slot])[off] = h;
+                    }
+                }
+            }
+        }
+    };
+
+    // ---- layer 1 ----
+    issue(0);
+    init_bias(p.bh);
+    commit(0, 0);
+    __syncthreads();
+    for (int c = 0; c < n_chunks; ++c) {
+        if (c + 1 < n_chunks) issue(c + 1);
+        const int kn = (p.n_ktab - c * KCH < KCH) ? p.n_ktab - c * KCH : KCH;  // (n_ktab is a multiple of 32)
+        contract(xs + (c & 1) * KCH * 32, p.w1 + (int64_t)c * KCH * Wp, kn / 2, Wp);
+        if (c + 1 < n_chunks) commit(c + 1, (c + 1) & 1);
+        __syncthreads();
+    }
+    float *hin = hA, *hout = hB;
+    finish_hidden(hin, p.n_hidden == 1);
+    __syncthreads();
+    // ---- hidden layers ----
+    for (int l = 1; l < p.n_hidden; ++l) {
+        init_bias(p.bh + (int64_t)l * Wp);
+        contract(hin, p.wh + (int64_t)(l - 1) * Wp * Wp, Wp / 2, Wp);
+        finish_hidden(hout, l == p.n_hidden - 1);
+        __syncthreads();
+        float *tmp = hin; hin = hout; hout = tmp;
+    }
+    // ---- output layer: 32-feature tiles dealt over the waves; per-value epilogue ----
+    for (int t = wave; t < p.n_otiles; t += NW) {
+        f32x16 y;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) y[r] = p.bo[32 * t + rho(r) + 4 * half];
+        constexpr int U = 8;
+        for (int p0 = 0; p0 < Wp / 2; p0 += U) {
+            float a[U], b[U];
+#pragma unroll
+            for (int u = 0; u < U; ++u) {
+                const int k = 2 * (p0 + u) + half;
+                b[u] = hin[k * 32 + col];
+                a[u] = p.wo[(int64_t)k * p.Fp + 32 * t + col];
+            }
+#pragma unroll
+            for (int u = 0; u < U; ++u) y = __builtin_amdgcn_mfma_f32_32x32x2f32(a[u], b[u], y, 0, 0, 0);
+        }
+        if (n0 + col >= p.n_samples) continue;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            const int f = 32 * t + rho(r) + 4 * half;
+            const OEntry e = p.otab[32 * p.n_hout_tiles + f];
+            if (e.out_feat < 0) continue;
+            float x = y[r];  // (the physical value: scale and centre live in the output weights and bias)
+            if (p.has_limits) {
+                if (x < e.lo) x = e.lo;
+                if (x >= e.hi) x = e.hi;
+                x = x * e.mask;
+            }
+            const int slot = e.out_feat >> 20, q = e.out_feat & 0xFFFFF;
+            const int64_t off = (int64_t)q * p.out_fs[slot] + (n0 + col) * p.out_ss[slot];
+            if (p.out64) static_cast<double *>(p.out[slot])[off] = (double)x;
+            else static_cast<float *>(p.out[slot])[off] = x;
+            if (e.res >= 0) {  // residual output: after = before + value (transforms.py:54-58)
+                const int rslot = e.res >> 8, rs = e.res & 0xFF;
+                const float before = (float)static_cast<const Raw *>(p.src[rs])[(int64_t)q * p.src_fs[rs] + (n0 + col) * p.src_ss[rs]];
+                const int64_t roff = (int64_t)q * p.out_fs[rslot] + (n0 + col) * p.out_ss[rslot];
+                if (p.out64) static_cast<double *>(p.out[rslot])[roff] = (double)(before + x);
+                else static_cast<float *>(p.out[rslot])[roff] = before + x;
+            }
+        }
+    }
+}
+
 }  // namespace
 }  // namespace fv3hip
 
@@ -1106,6 +1308,10 @@ struct fv3hip_mlp {
     void *d_sink = nullptr;
     size_t sink_bytes = 0;
     void *d_w = nullptr, *d_ktab = nullptr, *d_otab = nullptr, *d_bias = nullptr;
+    // plain (operand-layout) copies of the weights for mlp_small_kernel
+    void *d_w1 = nullptr, *d_wh = nullptr, *d_wo = nullptr, *d_bh = nullptr, *d_bo = nullptr;
+    int Wp = 0, Fp = 0;
+    int64_t small_limit = -1;  // fv3hip_mlp_set_small_limit: -1 = default rule, 0 = never, n = calls of at most n samples
     int n_cu = 256;
     size_t lds_bytes = 0;
     char last_variant[160] = {0};  // what the last fv3hip_mlp_predict launched (fv3hip_mlp_last_variant)
@@ -1370,7 +1576,31 @@ extern "C" int fv3hip_mlp_create(const fv3hip_mlp_desc_t *d, fv3hip_mlp_t *out)
                                 d->out_kernel[(size_t)k * F + f] * (d->out_scale ? d->out_scale[f] : 1.f);
                     }
 
+    // ---- plain copies for mlp_small_kernel: the same folded values, rows in table order ----
+    const int Wp = HT * 32, Fp = (nt_out > 0 ? nt_out : 1) * 32;
+    m->Wp = Wp;
+    m->Fp = Fp;
+    std::vector<float> w1((size_t)m->n_ktab * Wp, 0.f), wh((size_t)(d->n_hidden > 1 ? d->n_hidden - 1 : 1) * Wp * Wp, 0.f),
+        wo((size_t)Wp * Fp, 0.f), bh((size_t)d->n_hidden * Wp, 0.f), bo((size_t)Fp, 0.f);
+    for (size_t k = 0; k < perm.size(); ++k)
+        if (perm[k] >= 0)
+            for (int f = 0; f < width; ++f) w1[k * Wp + f] = d->hidden_kernels[0][(size_t)perm[k] * width + f] * ktab[k].scale;
+    for (int l = 1; l < d->n_hidden; ++l)
+        for (int k = 0; k < width; ++k)
+            for (int f = 0; f < width; ++f) wh[((size_t)(l - 1) * Wp + k) * Wp + f] = d->hidden_kernels[l][(size_t)k * width + f];
+    for (int l = 0; l < d->n_hidden; ++l)
+        for (int f = 0; f < width; ++f) bh[(size_t)l * Wp + f] = d->hidden_biases[l][f];
+    for (int k = 0; k < width; ++k)
+        for (int f = 0; f < F; ++f) wo[(size_t)k * Fp + f] = d->out_kernel[(size_t)k * F + f] * (d->out_scale ? d->out_scale[f] : 1.f);
+    for (int f = 0; f < F; ++f)
+        bo[f] = (float)((double)d->out_bias[f] * (d->out_scale ? d->out_scale[f] : 1.f) + (d->out_center ? d->out_center[f] : 0.f));
+
     int rc;
+    if ((rc = upload(w1, &m->d_w1)) || (rc = upload(wh, &m->d_wh)) || (rc = upload(wo, &m->d_wo)) || (rc = upload(bh, &m->d_bh)) ||
+        (rc = upload(bo, &m->d_bo))) {
+        fv3hip_mlp_destroy(m);
+        return rc;
+    }
     FV3HIP_REQUIRE(w.size() * sizeof(float) < (1ull << 31), "model too large: the packed weight stream exceeds 2 GiB");
     m->w_bytes = (unsigned int)(w.size() * sizeof(float));
     if ((rc = upload(w, &m->d_w)) || (rc = upload(ktab, &m->d_ktab)) || (rc = upload(otab, &m->d_otab)) ||
@@ -1404,11 +1634,20 @@ extern "C" int fv3hip_mlp_destroy(fv3hip_mlp_t m)
     if (m->d_ktab) hipFree(m->d_ktab);
     if (m->d_otab) hipFree(m->d_otab);
     if (m->d_bias) hipFree(m->d_bias);
+    for (void *q : {m->d_w1, m->d_wh, m->d_wo, m->d_bh, m->d_bo})
+        if (q) hipFree(q);
     delete m;
     return FV3HIP_OK;
 }
 
 extern "C" int64_t fv3hip_mlp_flops_per_sample(fv3hip_mlp_t m) { return m ? m->flops : 0; }
+
+extern "C" int fv3hip_mlp_set_small_limit(fv3hip_mlp_t m, int64_t max_samples)
+{
+    FV3HIP_REQUIRE(m, "null model handle");
+    m->small_limit = max_samples < 0 ? -1 : max_samples;
+    return FV3HIP_OK;
+}
 
 extern "C" const char *fv3hip_mlp_last_variant(fv3hip_mlp_t m) { return m ? m->last_variant : ""; }
 
@@ -1455,6 +1694,56 @@ extern "C" int fv3hip_mlp_predict(fv3hip_mlp_t m, const void *const *sources, co
         lp.out[j] = outputs[j];
         lp.out_fs[j] = out_feat_stride[j];
         lp.out_ss[j] = out_sample_stride[j];
+    }
+    // ---- few samples: the feature-split kernel while the big one would leave CUs without a tile (see mlp_small_kernel) ----
+    {
+        static const int64_t small_max = [] {
+            const char *e = getenv("FV3HIP_MLP_SMALL_MAX_SAMPLES");  // 0 disables; default: three waves of 32-sample tiles over the CUs
+            return e ? (int64_t)atoll(e) : (int64_t)-1;
+        }();
+        const int64_t limit = m->small_limit >= 0 ? m->small_limit : small_max >= 0 ? small_max : (int64_t)3 * 32 * m->n_cu;
+        const size_t lds_small = (size_t)(2 * kSmallChunk * 32 + 2 * m->Wp * 32) * sizeof(float);
+        if (n_samples <= limit && m->n_otiles + m->n_hout_tiles > 0 && lds_small <= 160 * 1024) {
+            SmallLaunch sp;
+            memset(&sp, 0, sizeof(sp));
+            sp.w1 = static_cast<const float *>(m->d_w1);
+            sp.wh = static_cast<const float *>(m->d_wh);
+            sp.wo = static_cast<const float *>(m->d_wo);
+            sp.bh = static_cast<const float *>(m->d_bh);
+            sp.bo = static_cast<const float *>(m->d_bo);
+            sp.ktab = static_cast<const KEntry *>(m->d_ktab);
+            sp.otab = static_cast<const OEntry *>(m->d_otab);
+            sp.n_ktab = m->n_ktab;
+            sp.Wp = m->Wp;
+            sp.HT = m->HT;
+            sp.n_hidden = m->n_hidden;
+            sp.Fp = m->Fp;
+            sp.n_otiles = m->n_otiles;
+            sp.n_hout_tiles = m->n_hout_tiles;
+            sp.out64 = (out_dtype == FV3HIP_F64);
+            sp.has_limits = m->has_limits;
+            sp.n_samples = n_samples;
+            memcpy(sp.src, lp.src, sizeof(sp.src));
+            memcpy(sp.src_fs, lp.src_fs, sizeof(sp.src_fs));
+            memcpy(sp.src_ss, lp.src_ss, sizeof(sp.src_ss));
+            memcpy(sp.out, lp.out, sizeof(sp.out));
+            memcpy(sp.out_fs, lp.out_fs, sizeof(sp.out_fs));
+            memcpy(sp.out_ss, lp.out_ss, sizeof(sp.out_ss));
+            const int grid_s = (int)ceil_div(n_samples, (int64_t)32);
+            hipStream_t st_s = as_stream(stream);
+            snprintf(m->last_variant, sizeof(m->last_variant), "mlp_small_kernel<%s> (32-sample workgroups, features split over %d waves)",
+                     src64 ? "true" : "false", kSmallWaves);
+            if (src64) {
+                auto kern = mlp_small_kernel<true>;
+                FV3HIP_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_small));
+                hipLaunchKernelGGL(kern, dim3(grid_s), dim3(kSmallWaves * 64), lds_small, st_s, sp);
+            } else {
+                auto kern = mlp_small_kernel<false>;
+                FV3HIP_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_small));
+                hipLaunchKernelGGL(kern, dim3(grid_s), dim3(kSmallWaves * 64), lds_small, st_s, sp);
+            }
+            return check_launch("mlp_small_kernel");
+        }
     }
     lp.w = static_cast<const f32x4 *>(m->d_w);
     lp.w_bytes = m->w_bytes;

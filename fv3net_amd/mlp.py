@@ -199,10 +199,18 @@ def _iptr(a: np.ndarray):
     return a.ctypes.data_as(ctypes.POINTER(ctypes.c_int))
 
 
+# Default of ``MlpModel(small_limit=...)`` for models built without saying (the emulators build theirs internally): None =
+# the library's rule.  Tests set it to 0 / a large number to pin one kernel or the other.
+DEFAULT_SMALL_LIMIT: Optional[int] = None
+
+
 class MlpModel:
     """Device handle of a fused MLP (``fv3hip_mlp_t``)."""
 
-    def __init__(self, spec: MlpSpec, device="cuda"):
+    def __init__(self, spec: MlpSpec, device="cuda", small_limit: Optional[int] = None):
+        """``small_limit``: calls of at most that many samples run on the feature-split kernel for small sample counts
+        (``fv3hip_mlp_set_small_limit``); None = the library's rule (while the 128-sample tiles would leave CUs idle),
+        0 = never."""
         spec.validate()
         self.spec = spec
         self.device = torch.device(device)
@@ -212,6 +220,13 @@ class MlpModel:
             _require_device(torch.empty(1, device=self.device))
             self._handle = self._create(spec)
         self.flops_per_sample = int(_lib.load().fv3hip_mlp_flops_per_sample(self._handle))
+        if small_limit is None:
+            small_limit = DEFAULT_SMALL_LIMIT
+        if small_limit is not None:
+            self.set_small_limit(small_limit)
+
+    def set_small_limit(self, max_samples: Optional[int]) -> None:
+        _lib.call("fv3hip_mlp_set_small_limit", self._handle, -1 if max_samples is None else int(max_samples))
 
     @staticmethod
     def _create(spec: MlpSpec, entry_point: str = "fv3hip_mlp_create"):

@@ -18,6 +18,16 @@ from tolerances import assert_close_per_level
 pytestmark = pytest.mark.gpu
 
 
+@pytest.fixture(autouse=True, params=["tiles-of-128", "feature-split"])
+def _mlp_kernel(request, monkeypatch):
+    """Every emulator test on both MLP kernels: the 128-sample-tile kernel and the feature-split kernel for small sample
+    counts (which a model rank's column counts select by default)."""
+    from fv3net_amd import mlp
+
+    monkeypatch.setattr(mlp, "DEFAULT_SMALL_LIMIT", 0 if request.param == "tiles-of-128" else 1 << 40)
+    return request.param
+
+
 def _dev(st):
     return {k: torch.from_numpy(v).cuda() for k, v in st.items()}
 

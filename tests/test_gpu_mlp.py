@@ -57,21 +57,28 @@ def _check(spec, sources_sf, device, layout, src_dtype=np.float32, out_dtype=tor
     """sources_sf: name -> [sample, feature] numpy arrays."""
     from fv3net_amd.mlp import MlpModel
 
-    model = MlpModel(spec, device=device)
     dev_src = {}
     for k, v in sources_sf.items():
         a = v.astype(src_dtype)
         a = a if layout == "sample_feature" else np.ascontiguousarray(a.T)
         dev_src[k] = torch.from_numpy(np.ascontiguousarray(a)).to(device)
-    out = model.predict(dev_src, layout=layout, out_dtype=out_dtype)
     truth = mlp_np.forward(spec, {k: v.astype(src_dtype) for k, v in sources_sf.items()}, dtype=np.float64)
     cpu32 = mlp_np.forward(spec, {k: v.astype(src_dtype) for k, v in sources_sf.items()}, dtype=np.float32)
-    assert set(out) == set(truth)
-    for name in truth:
-        got = out[name].cpu().numpy()
-        got = got if layout == "sample_feature" else got.T
-        assert got.shape == truth[name].shape, (name, got.shape, truth[name].shape)
-        assert_close_per_level(got, truth[name], cpu32[name], name)
+    # both kernels on every case: the 128-sample-tile kernel (small_limit=0) and the feature-split kernel for small sample
+    # counts (any count goes to it here); the results returned are the big kernel's
+    results = {}
+    for which, limit in (("mlp_fused_kernel", 0), ("mlp_small_kernel", 1 << 40)):
+        model = MlpModel(spec, device=device, small_limit=limit)
+        out = model.predict(dev_src, layout=layout, out_dtype=out_dtype)
+        assert model.last_variant.startswith(which), model.last_variant
+        assert set(out) == set(truth)
+        for name in truth:
+            got = out[name].cpu().numpy()
+            got = got if layout == "sample_feature" else got.T
+            assert got.shape == truth[name].shape, (name, got.shape, truth[name].shape)
+            assert_close_per_level(got, truth[name], cpu32[name], f"{name} ({which})")
+        results[which] = out
+    out = results["mlp_fused_kernel"]
     return out, truth
 
 
@@ -148,6 +155,40 @@ def test_limits_masks_and_clipped_inputs(device):
     assert (q2 == -0.5).any() and (q2 == 0.75).any()
 
 
+def test_small_sample_kernel_column_results_do_not_depend_on_the_call(device):
+    """The feature-split kernel for small sample counts (what a model rank's 2 304 columns select): a column's result is
+    the same bit for bit whatever else is in the call -- 2 304 columns at once, the same columns in calls of 1 000 and
+    1 304 or one by 37, in another order -- so a run does not depend on its domain decomposition while every rank stays on
+    this kernel.  Against the 128-sample-tile kernel the results agree to rounding (both are checked against the float64
+    oracle at the same tolerance), not bit for bit: `small_limit` pins one kernel where that matters."""
+    import bench
+    from fv3net_amd.mlp import MlpModel
+
+    spec = bench.zc_spec(0, per_level_output_scale=decades)
+    n = 2304
+    src = bench.zc_inputs_numpy(np.random.default_rng(21), n)
+    dev = {k: torch.from_numpy(np.ascontiguousarray(v.T.astype(np.float64))).to(device) for k, v in src.items()}  # as the hook gets them
+    model = MlpModel(spec, device=device)
+    full = model.predict(dev)
+    assert model.last_variant.startswith("mlp_small_kernel<true>"), model.last_variant
+    truth = mlp_np.forward(spec, src, dtype=np.float64)
+    cpu32 = mlp_np.forward(spec, src, dtype=np.float32)
+    for name, t in truth.items():
+        assert_close_per_level(full[name].cpu().numpy().T, t, cpu32[name], name)
+    for lo, hi in ((0, 1000), (1000, 2304), (37, 74)):
+        part = model.predict({k: v[:, lo:hi].contiguous() for k, v in dev.items()})
+        for name in truth:
+            assert torch.equal(part[name], full[name][:, lo:hi]), (name, lo, hi)
+    perm = torch.randperm(n, device=device, generator=torch.Generator(device=device).manual_seed(3))
+    shuffled = model.predict({k: v[:, perm].contiguous() for k, v in dev.items()})
+    for name in truth:
+        assert torch.equal(shuffled[name], full[name][:, perm]), name
+    # the other kernel on the same columns: the same values to rounding
+    big = MlpModel(spec, device=device, small_limit=0).predict(dev)
+    for name, t in truth.items():
+        assert_close_per_level(big[name].cpu().numpy().T, full[name].cpu().numpy().T, None, f"{name}: small against big", rel=2e-6)
+
+
 def test_nan_input_propagates_only_to_its_sample(device):
     rng = np.random.default_rng(6)
     n = 300
@@ -195,7 +236,7 @@ def test_full_size_c384_properties(device):
     from fv3net_amd.mlp import MlpModel
 
     spec = _random_spec(rng, {"a": ("a", 79, 0), "b": ("b", 79, 0)}, 64, 2, {"y": 79, "z": 1})
-    model = MlpModel(spec, device=device)
+    model = MlpModel(spec, device=device, small_limit=0)  # (one kernel for both calls: bit-identity holds within a kernel)
     n = 6 * 384 * 384
     g = torch.Generator(device=device).manual_seed(0)
     a = torch.randn((79, n), device=device, generator=g)
@@ -223,7 +264,7 @@ def test_timed_kernel_against_oracle(device, n, residuals):
     # (output standard deviations per level, falling by 4.5 decades from the surface up: the gate below is per level)
     spec = bench.zc_spec(0, residuals=residuals, per_level_output_scale=decades)
     src = bench.zc_inputs_numpy(np.random.default_rng(11), n)
-    model = MlpModel(spec, device=device)
+    model = MlpModel(spec, device=device, small_limit=0)  # (the kernel of the full-size call, whatever n is here)
     dev_src = {k: torch.from_numpy(np.ascontiguousarray(v.T)).to(device) for k, v in src.items()}
     out = model.predict(dev_src)
     assert model.last_variant == ("mlp_fused_kernel<8,false,true,false,false,false> epilogue="
@@ -254,7 +295,7 @@ def test_timed_kernel_float64_sources_take_general_epilogue(device):
 
     spec = bench.zc_spec(0)
     src = bench.zc_inputs_numpy(np.random.default_rng(12), 4096)
-    model = MlpModel(spec, device=device)
+    model = MlpModel(spec, device=device, small_limit=0)
     out = model.predict({k: torch.from_numpy(np.ascontiguousarray(v.T.astype(np.float64))).to(device) for k, v in src.items()})
     assert model.last_variant.startswith("mlp_fused_kernel<8,true,true,false,false,false>"), model.last_variant
     truth = mlp_np.forward(spec, src, dtype=np.float64)
@@ -312,6 +353,55 @@ def test_split_bf16_kernel_other_architectures(device, n_hidden, out_feats, n, p
     for name, t in truth.items():
         got = out[name].cpu().numpy().T
         assert_close_per_level(got, t, cpu32[name], name, slack32=2e-7)
+
+
+def test_split_bf16_kernel_adversarial_inputs(device):
+    """the domain of the split-bf16 arithmetic, pinned.  x = hi + mid + lo in bf16 (8 mantissa bits each, the
+    float32 exponent range) is exact while lo stays a normal bf16 number, |x| >~ 2^-102; of the nine partial products six are
+    kept, the dropped ones are <= 2^-25 |x w| -- under one float32 rounding per product.  Checked against the float64 oracle
+    per (variable, level) and against the fp32 kernel sample for sample:
+      * features whose magnitudes span 2^-60 .. 2^60 with standard deviations (folded into the weights) to match;
+      * log inputs at and below their floor (0, 1e-12, exactly eps);
+      * NaN in a sample -> NaN in every output of that sample, in both kernels, nowhere else;
+      * +-Inf in a sample: the fp32 kernel yields Inf or NaN by IEEE rules; the split kernel yields NaN or Inf (Inf - hi is
+        NaN in the mid piece) -- non-finite either way, never a finite number; other samples untouched."""
+    from fv3net_amd.mlp import InputSpec, MlpModel, MlpModelSplitBf16, MlpSpec, OutputSpec
+
+    rng = np.random.default_rng(21)
+    nf, n, w = 79, 1024, 256
+    expo = rng.integers(-60, 61, nf)
+    mag = (2.0 ** expo).astype(np.float32)
+    x = (rng.normal(0, 1, (n, nf)) * mag).astype(np.float32)
+    q = np.where(rng.random((n, nf)) < 0.3, 0.0, 10.0 ** rng.uniform(-13, -3, (n, nf))).astype(np.float32)
+    q[:8, :] = 1e-10  # exactly the floor
+    q[8:16, :] = 1e-12
+    inputs = [InputSpec("x", nf, center=(rng.normal(0, 0.1, nf) * mag).astype(np.float32), scale=mag),
+              InputSpec("q", nf, transform="log", eps=1e-10, center=np.full(nf, -15.0, np.float32), scale=np.float32(4.0))]
+    glorot = lambda a, b: rng.uniform(-1, 1, (a, b)).astype(np.float32) * np.float32(np.sqrt(6.0 / (a + b)))
+    spec = MlpSpec(inputs=inputs, hidden_kernels=[glorot(2 * nf, w), glorot(w, w)],
+                   hidden_biases=[rng.normal(0, 0.01, w).astype(np.float32) for _ in range(2)],
+                   outputs=[OutputSpec("y", nf, scale=decades(rng, nf), center=(rng.normal(0, 1, nf) * decades(rng, nf)).astype(np.float32))],
+                   out_kernel=glorot(w, nf), out_bias=rng.normal(0, 0.01, nf).astype(np.float32))
+    split, fp32 = MlpModelSplitBf16(spec, device=device), MlpModel(spec, device=device)
+    dev = lambda a: torch.from_numpy(np.ascontiguousarray(a.T)).to(device)
+    src = {"x": x, "q": q}
+    truth = mlp_np.forward(spec, src, dtype=np.float64)["y"]
+    cpu32 = mlp_np.forward(spec, src, dtype=np.float32)["y"]
+    got_s = split.predict({k: dev(v) for k, v in src.items()})["y"].cpu().numpy().T
+    got_f = fp32.predict({k: dev(v) for k, v in src.items()})["y"].cpu().numpy().T
+    assert_close_per_level(got_f, truth, cpu32, "y (fp32 kernel)")
+    assert_close_per_level(got_s, truth, cpu32, "y (split-bf16 kernel)", slack32=2e-7)
+    # non-finite inputs
+    bad = x.copy()
+    bad[100, 5], bad[200, 40], bad[300, 7], bad[301, 70] = np.nan, np.inf, -np.inf, np.inf
+    out_s = split.predict({"x": dev(bad), "q": dev(q)})["y"].cpu().numpy().T
+    out_f = fp32.predict({"x": dev(bad), "q": dev(q)})["y"].cpu().numpy().T
+    touched = np.zeros(n, bool)
+    touched[[100, 200, 300, 301]] = True
+    np.testing.assert_array_equal(out_s[~touched], got_s[~touched])  # other samples: bit for bit what they were
+    np.testing.assert_array_equal(out_f[~touched], got_f[~touched])
+    assert np.isnan(out_s[100]).all() and np.isnan(out_f[100]).all()
+    assert not np.isfinite(out_f[[200, 300, 301]]).any() and not np.isfinite(out_s[[200, 300, 301]]).any()
 
 
 def test_split_bf16_kernel_rows_of_256_mib(device):
