@@ -649,15 +649,9 @@ def streaming_benchmark(dev, n_snapshots=24):
     return out
 
 
-def dense_local_benchmark(dev, steps):
-    """The reference's production gscond emulator (projects/microphysics/configs/models/gscond.yaml: "dense-local",
-    12 inputs at a point -> 2 x 256 -> 2 outputs, temperature-conditional un-scaling + Difference outputs) over one
-    C384 snapshot: 79 x 884 736 points.  MFMA-bound like the headline kernel, plus two HBM-bound passes."""
-    from fv3net_amd.local_mlp import ConditionalScale, LocalInput, LocalMlpModel, LocalMlpSpec, LocalOutput
-
-    rng = np.random.default_rng(0)
-    ncol, width = 6 * 384 * 384, 256
-    g = torch.Generator(device=dev).manual_seed(2)
+def emulator_state(dev, ncol, seed=2, dtype=torch.float32):
+    """[79, ncol] state arrays of the gscond / precpd emulators' inputs (device)."""
+    g = torch.Generator(device=dev).manual_seed(seed)
     u = lambda lo, hi, shape=(NZ, ncol): torch.rand(shape, device=dev, generator=g) * (hi - lo) + lo
     qv = torch.pow(10.0, u(-8, -2))
     t = u(180, 310)
@@ -668,8 +662,21 @@ def dense_local_benchmark(dev, steps):
         "specific_humidity_after_last_gscond": qv * u(0.9, 1.1), "air_pressure": u(300, 101000),
         "surface_air_pressure": u(95000, 103000, (ncol,)), "surface_air_pressure_after_last_gscond": u(95000, 103000, (ncol,)),
     }
-    raw = [(n, n, "none", 0.0) for n in st] + [(k, v[0], "log", v[1]) for k, v in LOG_FIELDS.items()]
-    inputs = [LocalInput(name, source, tr, eps, center=rng.normal(0, 1, NZ).astype(np.float32) if st[source].dim() == 2 else
+    return {k: v.to(dtype) for k, v in st.items()}
+
+
+def emulator_specs(width=256):
+    """(gscond "dense-local" regressor spec, precpd "rnn-v1-shared-weights" spec, number of inputs): the reference's
+    production architectures (projects/microphysics/configs/models/{gscond,precpd}.yaml) with random-init weights."""
+    from fv3net_amd.local_mlp import ConditionalScale, LocalInput, LocalMlpSpec, LocalOutput, RnnLayer, RnnSpec
+
+    rng = np.random.default_rng(0)
+    two_d = {"surface_air_pressure", "surface_air_pressure_after_last_gscond"}
+    names = ["air_temperature_input", "specific_humidity_input", "cloud_water_mixing_ratio_input",
+             "pressure_thickness_of_atmospheric_layer", "air_temperature_after_last_gscond", "specific_humidity_after_last_gscond",
+             "air_pressure", "surface_air_pressure", "surface_air_pressure_after_last_gscond"]
+    raw = [(n, n, "none", 0.0) for n in names] + [(k, v[0], "log", v[1]) for k, v in LOG_FIELDS.items()]
+    inputs = [LocalInput(name, source, tr, eps, center=rng.normal(0, 1, NZ).astype(np.float32) if source not in two_d else
                          np.float32(rng.normal()), scale=np.float32(rng.uniform(0.5, 2))) for name, source, tr, eps in sorted(raw)]
     k = len(inputs)
     edges = np.linspace(180, 310, 51)[:-1].astype(np.float32)
@@ -685,6 +692,31 @@ def dense_local_benchmark(dev, steps):
                         (rng.normal(0, 1, (width, width)) / np.sqrt(width)).astype(np.float32)],
         hidden_biases=[rng.normal(0, 0.1, width).astype(np.float32) for _ in range(2)], outputs=outs,
         out_kernel=(rng.normal(0, 1, (width, 2)) / np.sqrt(width)).astype(np.float32), out_bias=rng.normal(0, 0.1, 2).astype(np.float32))
+    layers, fan = [], k
+    for _ in range(2):
+        layers.append(RnnLayer((rng.normal(0, 1, (fan, width)) / np.sqrt(fan)).astype(np.float32),
+                               (rng.normal(0, 0.6, (width, width)) / np.sqrt(width)).astype(np.float32),
+                               rng.normal(0, 0.1, width).astype(np.float32)))
+        fan = width
+    routs = [LocalOutput("total_precipitation", scale=np.float32(1e-3), center=np.float32(1e-4), single_level=True)] + [
+        LocalOutput(f"{v}_precpd_difference", scale=rng.uniform(0.5, 2, NZ).astype(np.float32), center=rng.normal(0, 0.1, NZ).astype(np.float32),
+                    after=f"{src}_after_precpd", before=f"{src}_input", value_limit=lim)
+        for v, src, lim in (("cloud", "cloud_water_mixing_ratio", (None, 0.0)), ("temperature", "air_temperature", (None, 0.0)),
+                            ("humidity", "specific_humidity", (0.0, None)))]
+    rspec = RnnSpec(inputs=inputs, layers=layers, outputs=routs,
+                    out_kernel=(rng.normal(0, 1, (width, 4)) / np.sqrt(width)).astype(np.float32), out_bias=rng.normal(0, 0.1, 4).astype(np.float32))
+    return spec, rspec, k
+
+
+def dense_local_benchmark(dev, steps):
+    """The reference's production gscond emulator (projects/microphysics/configs/models/gscond.yaml: "dense-local",
+    12 inputs at a point -> 2 x 256 -> 2 outputs, temperature-conditional un-scaling + Difference outputs) over one
+    C384 snapshot: 79 x 884 736 points.  MFMA-bound like the headline kernel, plus two HBM-bound passes."""
+    from fv3net_amd.local_mlp import LocalMlpModel
+
+    ncol, width = 6 * 384 * 384, 256
+    st = emulator_state(dev, ncol)
+    spec, rspec, k = emulator_specs(width)
     model = LocalMlpModel(spec, device=dev)
     fn = lambda: model.predict(st)
     fn()
@@ -717,21 +749,8 @@ def dense_local_benchmark(dev, steps):
         out.append({"kernel": "dense-local emulator on mlp3_kernel<1>", "error": f"{type(err).__name__}: {err}"})
     # the production precpd emulator (configs/models/precpd.yaml: "rnn-v1-shared-weights", 2 stacked SimpleRNN(256) over the
     # 79 levels, 4 outputs): 79 x 2 launches of the fused kernel, the states ping-ponging in HBM
-    from fv3net_amd.local_mlp import RnnLayer, RnnModel, RnnSpec
+    from fv3net_amd.local_mlp import RnnModel
 
-    layers, fan = [], k
-    for _ in range(2):
-        layers.append(RnnLayer((rng.normal(0, 1, (fan, width)) / np.sqrt(fan)).astype(np.float32),
-                               (rng.normal(0, 0.6, (width, width)) / np.sqrt(width)).astype(np.float32),
-                               rng.normal(0, 0.1, width).astype(np.float32)))
-        fan = width
-    routs = [LocalOutput("total_precipitation", scale=np.float32(1e-3), center=np.float32(1e-4), single_level=True)] + [
-        LocalOutput(f"{v}_precpd_difference", scale=rng.uniform(0.5, 2, NZ).astype(np.float32), center=rng.normal(0, 0.1, NZ).astype(np.float32),
-                    after=f"{src}_after_precpd", before=f"{src}_input", value_limit=lim)
-        for v, src, lim in (("cloud", "cloud_water_mixing_ratio", (None, 0.0)), ("temperature", "air_temperature", (None, 0.0)),
-                            ("humidity", "specific_humidity", (0.0, None)))]
-    rspec = RnnSpec(inputs=inputs, layers=layers, outputs=routs,
-                    out_kernel=(rng.normal(0, 1, (width, 4)) / np.sqrt(width)).astype(np.float32), out_bias=rng.normal(0, 0.1, 4).astype(np.float32))
     rmodel = RnnModel(rspec, device=dev)
     fn = lambda: rmodel.predict(st)
     fn()
@@ -763,6 +782,88 @@ def dense_local_benchmark(dev, steps):
         del rmodel
     except Exception as err:  # noqa: BLE001
         out.append({"kernel": "RNN emulator on mlp3_kernel<1> cells", "error": f"{type(err).__name__}: {err}"})
+    return out
+
+
+def rank_latency_benchmark(dev, column_counts=(2304, 9216), reps=20):
+    """The shape of the prognostic loop (north_star: drops into prognostic_c48_run): ONE model rank's columns per call --
+    2 304 (a 48 x 48 subdomain at C48 on 6 ranks) and 9 216 -- not a C384 snapshot.  Per emulator and column count the wall
+    time of a call with both MLP kernels: the feature-split kernel for small sample counts (the library's choice here) and
+    the 128-sample-tile kernel pinned (`small_limit=0`; what rounds 1-2 ran), plus the number of library launches per call.
+      * MicrophysicsHook.microphysics(state) as the Fortran model calls it: float64 [79, ncol] numpy arrays in, state
+        updated in place (upload, Zhao-Carr dense network, squash / range / level masks, download);
+      * the same emulator on device-resident float64 arrays (no PCIe: the network + masks alone);
+      * the gscond dense-local regressor and the precpd RNN (2 x SimpleRNN(256) over 79 levels, HIP-graph replay) on
+        device-resident float32 state."""
+    from fv3net_amd import _lib, mlp
+    from fv3net_amd.emulation import HipEmulator, MicrophysicsHook
+    from fv3net_amd.emulation.config import ModelConfig
+    from fv3net_amd.local_mlp import LocalMlpModel, RnnModel
+    from fv3net_amd.mlp import ResidualSpec
+
+    out = []
+    zc = zc_spec(0)
+    zc.residuals = [
+        ResidualSpec("air_temperature_after_precpd", "air_temperature_input", "temperature_precpd_difference"),
+        ResidualSpec("specific_humidity_after_precpd", "specific_humidity_input", "humidity_precpd_difference"),
+        ResidualSpec("cloud_water_mixing_ratio_after_precpd", "cloud_water_mixing_ratio_input", "cloud_precpd_difference"),
+    ]
+    cfg = ModelConfig.from_dict({"cloud_squash": 1e-8, "ranges": {"total_precipitation": {"min": 0.0}},
+                                 "mask_emulator_levels": {"air_temperature_after_precpd": {"start": 74, "fill_value": "air_temperature_input"}}})
+    gspec, rspec, _ = emulator_specs(256)
+
+    def wall(fn):
+        for _ in range(3):
+            fn()
+        torch.cuda.synchronize(dev)
+        t0 = time.perf_counter()
+        for _ in range(reps):
+            fn()
+        torch.cuda.synchronize(dev)
+        return (time.perf_counter() - t0) / reps * 1e3
+
+    def launches(fn):
+        count, real = [0], _lib.call_on
+
+        def counting(*a, **k):
+            count[0] += 1
+            return real(*a, **k)
+
+        _lib.call_on = counting
+        try:
+            fn()
+        finally:
+            _lib.call_on = real
+        return count[0]
+
+    for ncol in column_counts:
+        host = {k: np.ascontiguousarray(v.T.astype(np.float64)) for k, v in zc_inputs_numpy(np.random.default_rng(5), ncol).items()}
+        host["model_time"], host["rank"] = [2016, 8, 1, 0, 15, 0], 0
+        dev64t = {k: torch.from_numpy(v).to(dev).t() for k, v in host.items() if isinstance(v, np.ndarray)}  # [sample, feature] views, as the hook hands them to the model
+        st32 = emulator_state(dev, ncol, seed=7)
+        entry = {"kernel": "one model rank's columns per call (MicrophysicsHook / emulators)", "workload": f"{ncol} columns x 79 levels", "calls": {}}
+        for label, limit in (("feature-split kernel (default)", None), ("128-sample tiles pinned", 0)):
+            mlp.DEFAULT_SMALL_LIMIT = limit
+            try:
+                hook = MicrophysicsHook(model=HipEmulator(zc), mask=cfg._build_mask())
+                rnn = RnnModel(rspec, device=dev, use_graph=True)
+                loc = LocalMlpModel(gspec, device=dev)
+                emu = hook.model
+                res = {
+                    "hook_wall_ms (float64 numpy state in, updated in place)": wall(lambda: hook.microphysics(dict(host))),
+                    "zhao_carr_dense_device_resident_ms": wall(lambda: emu(dev64t)),
+                    "gscond_dense_local_device_resident_ms": wall(lambda: loc.predict(st32)),
+                    "precpd_rnn_device_resident_ms (HIP-graph replay)": wall(lambda: rnn.predict(st32)),
+                    "library_launches": {"hook": launches(lambda: hook.microphysics(dict(host))), "dense_local": launches(lambda: loc.predict(st32))},
+                }
+                entry["calls"][label] = res
+                del hook, rnn, loc
+            except Exception as err:  # noqa: BLE001
+                entry["calls"][label] = {"error": f"{type(err).__name__}: {err}"}
+            finally:
+                mlp.DEFAULT_SMALL_LIMIT = None
+        out.append(entry)
+    torch.cuda.empty_cache()
     return out
 
 

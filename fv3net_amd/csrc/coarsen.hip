@@ -834,6 +834,11 @@ __global__ void ew_kernel(int op, const T *__restrict__ a, const T *__restrict__
             case FV3HIP_EW_WHERE_S: v = (y != (T)0) ? x : s; break;            // a.where(mask b, other=s)
             case FV3HIP_EW_ADD: v = x + y; break;
             case FV3HIP_EW_ADD_S: v = x + s; break;
+            case FV3HIP_EW_SUB: v = x - y; break;
+            case FV3HIP_EW_LOG_FLOOR_S: v = log(x < s ? s : x); break;         // tf.math.log(tf.maximum(a, s)); a NaN stays a NaN 
+            case FV3HIP_EW_EXP: v = exp(x); break;
+            case FV3HIP_EW_RELU_THRESHOLD_S: v = (x > s) ? x : (T)0; break;    // tf.keras.activations.relu(a, threshold=s)
+            case FV3HIP_EW_BELOW_S: v = (x < s) ? x : (T)0; break;             // tf.cast(a < s, a.dtype) * a
             case FV3HIP_EW_MUL_S: v = s * x; break;                            // scalar * a           // blend(weights a, pressure-level b, model-level c)
             default: v = x;
         }
@@ -1159,13 +1164,13 @@ extern "C" int fv3hip_ew(int op, const void *a, const void *b, const void *c, do
                          int64_t inner, int64_t b_rep, int64_t c_rep, void *out, void *stream)
 {
     FV3HIP_REQUIRE(dtype == FV3HIP_F32 || dtype == FV3HIP_F64, "dtype must be F32 or F64");
-    FV3HIP_REQUIRE(op >= FV3HIP_EW_MUL && op <= FV3HIP_EW_ADD_S, "unknown elementwise op %d", op);
+    FV3HIP_REQUIRE(op >= FV3HIP_EW_MUL && op <= FV3HIP_EW_BELOW_S, "unknown elementwise op %d", op);
     FV3HIP_REQUIRE(n >= 0 && inner >= 1 && b_rep >= 1 && c_rep >= 1, "bad extents");
     if (n == 0) return FV3HIP_OK;
     FV3HIP_REQUIRE(a && out, "null pointer");
     const bool needs_b = op == FV3HIP_EW_MUL || op == FV3HIP_EW_ISCLOSE || op == FV3HIP_EW_WHERE_NAN ||
                          op == FV3HIP_EW_SELECT || op == FV3HIP_EW_SELECT_S || op == FV3HIP_EW_AND || op == FV3HIP_EW_BLEND ||
-                         op == FV3HIP_EW_WHERE_S || op == FV3HIP_EW_ADD;
+                         op == FV3HIP_EW_WHERE_S || op == FV3HIP_EW_ADD || op == FV3HIP_EW_SUB;
     FV3HIP_REQUIRE(!needs_b || b, "this op needs operand b");
     FV3HIP_REQUIRE((op != FV3HIP_EW_SELECT && op != FV3HIP_EW_BLEND) || c, "this op needs operand c");
     FV3HIP_REQUIRE(n % inner == 0, "n must be a multiple of inner");

@@ -1129,11 +1129,14 @@ __global__ __launch_bounds__(kSmallWaves * 64) void mlp_small_kernel(const Small
     float *xs = small_lds;               // [2][KCH][32]
     float *hA = xs + 2 * KCH * 32;       // [Wp][32]
     float *hB = hA + p.Wp * 32;          // [Wp][32]
+    KEntry *kt = reinterpret_cast<KEntry *>(hB + p.Wp * 32);  // [n_ktab]: the input table, so that a row's address does not cost a round trip
     const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63, half = lane >> 5, col = lane & 31;
     const int64_t n0 = (int64_t)blockIdx.x * 32;
     const int Wp = p.Wp, HT = p.HT;
     const int n_chunks = (p.n_ktab + KCH - 1) / KCH;
 
+    for (int i = tid; i < p.n_ktab; i += NT) kt[i] = p.ktab[i];
+    __syncthreads();
     // ---- input staging: raw loads now, transform + centre when the rows are parked in LDS ----
     Raw xr[PER];
     auto issue = [&](int c) {
@@ -1142,7 +1145,7 @@ __global__ __launch_bounds__(kSmallWaves * 64) void mlp_small_kernel(const Small
             const int idx = tid + j * NT, kk = idx >> 5, n = idx & 31, k = c * KCH + kk;
             xr[j] = (Raw)1;
             if (k < p.n_ktab) {
-                const KEntry e = p.ktab[k];
+                const KEntry e = kt[k];
                 int64_t ns = n0 + n;
                 if (ns >= p.n_samples) ns = p.n_samples - 1;  // (a ragged last tile reads its last sample again)
                 if (e.src >= 0) xr[j] = static_cast<const Raw *>(p.src[e.src])[(int64_t)e.feat * p.src_fs[e.src] + ns * p.src_ss[e.src]];
@@ -1155,7 +1158,7 @@ __global__ __launch_bounds__(kSmallWaves * 64) void mlp_small_kernel(const Small
             const int idx = tid + j * NT, kk = idx >> 5, n = idx & 31, k = c * KCH + kk;
             float v = 0.f;
             if (k < p.n_ktab) {
-                const KEntry e = p.ktab[k];
+                const KEntry e = kt[k];
                 if (e.src >= 0) {
                     v = (float)xr[j];
                     if (e.transform == FV3HIP_TRANSFORM_LOG) v = logf(v < e.eps ? e.eps : v);
@@ -1174,26 +1177,56 @@ __global__ __launch_bounds__(kSmallWaves * 64) void mlp_small_kernel(const Small
             for (int r = 0; r < 16; ++r) acc[ti][r] = (t < HT) ? b[32 * t + rho(r) + 4 * half] : 0.f;
         }
     };
-    // one block of k-pairs against this wave's tiles: B[k][sample] from LDS, A[feature][k] from the plain weight rows
-    auto contract = [&](const float *bsrc, const float *wrow0, int n_pairs, int ldw) {
-        constexpr int U = 8;  // operand loads run U pairs ahead of their MFMAs
-        for (int p0 = 0; p0 < n_pairs; p0 += U) {
-            float a[MAXT][U], b[U];
+    // A block of k-pairs against this wave's tiles: B[k][sample] from LDS, A[feature][k] from the plain weight rows in L2.
+    // The operand loads of batch i + 1 (U k-pairs) are in flight while the MFMAs of batch i issue: two register sets, the
+    // loop body written out for both (a rotation by moves would wait for the loads just issued).  Without it every batch
+    // paid an L2 round trip (~1 us) in front of its 8 MFMAs (~0.2 us): the first version of this kernel ran at a fifth of
+    // its matrix time.
+    // (every load is unconditional -- indices past the end are clamped, a wave without a tile reads the last tile's rows
+    // and skips the MFMAs -- so that the counted wait in front of a batch's MFMAs is `vmcnt(loads of the next batch)`:
+    // with the loads inside branches the compiler waited for everything, the next batch included)
+    constexpr int U = 8;
+    // Addresses are a wave-uniform part (scalar registers) plus a per-lane 32-bit offset that never changes: with 64-bit
+    // per-lane address arithmetic the compiler computed each address IN the register a previous load was still writing
+    // and had to wait for that load first -- the requests of a batch were serialised behind the batch before.
+    const int wave_u = __builtin_amdgcn_readfirstlane(wave);
+    int tcl[MAXT];  // this wave's tiles, clamped (uniform)
 #pragma unroll
-            for (int u = 0; u < U; ++u) {
-                const int k = 2 * (p0 + u) + half;
-                b[u] = bsrc[k * 32 + col];
+    for (int ti = 0; ti < MAXT; ++ti) tcl[ti] = (wave_u + ti * NW < HT) ? wave_u + ti * NW : HT - 1;
+    // (weights through raw buffer loads: descriptor + a loop-invariant per-lane offset + a scalar row offset -- no address
+    // arithmetic on the vector unit, and the destination registers are nobody's address temporaries)
+    auto load_ops = [&](float (&a)[MAXT][U], float (&b)[U], const float *bsrc, const __amdgpu_buffer_rsrc_t wr, int p0, int n_pairs, int ldw) {
+        const int lane_w = (half * ldw + col) * 4;   // bytes, per lane, loop-invariant
+        const int lane_b = half * 32 + col;
 #pragma unroll
-                for (int ti = 0; ti < MAXT; ++ti) {
-                    const int t = wave + ti * NW;
-                    a[ti][u] = (t < HT) ? wrow0[(int64_t)k * ldw + 32 * t + col] : 0.f;
-                }
-            }
+        for (int u = 0; u < U; ++u) {
+            const int pr = (p0 + u < n_pairs) ? p0 + u : n_pairs - 1;  // uniform
+            b[u] = (bsrc + 64 * pr)[lane_b];
 #pragma unroll
-            for (int u = 0; u < U; ++u)
+            for (int ti = 0; ti < MAXT; ++ti)
+                a[ti][u] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(wr, lane_w, (2 * pr * ldw + 32 * tcl[ti]) * 4, 0));
+        }
+    };
+    auto mfma_ops = [&](const float (&a)[MAXT][U], const float (&b)[U]) {
 #pragma unroll
-                for (int ti = 0; ti < MAXT; ++ti)
-                    if (wave + ti * NW < HT) acc[ti] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[ti][u], b[u], acc[ti], 0, 0, 0);
+        for (int u = 0; u < U; ++u)
+#pragma unroll
+            for (int ti = 0; ti < MAXT; ++ti)
+                if (wave_u + ti * NW < HT) acc[ti] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[ti][u], b[u], acc[ti], 0, 0, 0);
+    };
+    auto contract = [&](const float *bsrc, const float *wbase, int n_rows, int n_pairs, int ldw) {  // n_pairs: a multiple of 2 U
+        const __amdgpu_buffer_rsrc_t wrow0 = __builtin_amdgcn_make_buffer_rsrc(const_cast<float *>(wbase), 0, n_rows * ldw * 4, 0x00020000);
+        float a0[MAXT][U], b0[U], a1[MAXT][U], b1[U];
+        load_ops(a0, b0, bsrc, wrow0, 0, n_pairs, ldw);
+        for (int p0 = 0; p0 < n_pairs; p0 += 2 * U) {
+            load_ops(a1, b1, bsrc, wrow0, p0 + U, n_pairs, ldw);
+            __builtin_amdgcn_sched_barrier(0);  // (requests of the next batch stay in front of this batch's MFMAs)
+            mfma_ops(a0, b0);
+            __builtin_amdgcn_sched_barrier(0);
+            load_ops(a0, b0, bsrc, wrow0, p0 + 2 * U, n_pairs, ldw);
+            __builtin_amdgcn_sched_barrier(0);
+            mfma_ops(a1, b1);
+            __builtin_amdgcn_sched_barrier(0);
         }
     };
     // ReLU, park the activations for the next layer (and hand them out when the model returns its last hidden layer)
@@ -1228,7 +1261,7 @@ __global__ __launch_bounds__(kSmallWaves * 64) void mlp_small_kernel(const Small
     for (int c = 0; c < n_chunks; ++c) {
         if (c + 1 < n_chunks) issue(c + 1);
         const int kn = (p.n_ktab - c * KCH < KCH) ? p.n_ktab - c * KCH : KCH;  // (n_ktab is a multiple of 32)
-        contract(xs + (c & 1) * KCH * 32, p.w1 + (int64_t)c * KCH * Wp, kn / 2, Wp);
+        contract(xs + (c & 1) * KCH * 32, p.w1 + (int64_t)c * KCH * Wp, kn, kn / 2, Wp);
         if (c + 1 < n_chunks) commit(c + 1, (c + 1) & 1);
         __syncthreads();
     }
@@ -1238,7 +1271,7 @@ __global__ __launch_bounds__(kSmallWaves * 64) void mlp_small_kernel(const Small
     // ---- hidden layers ----
     for (int l = 1; l < p.n_hidden; ++l) {
         init_bias(p.bh + (int64_t)l * Wp);
-        contract(hin, p.wh + (int64_t)(l - 1) * Wp * Wp, Wp / 2, Wp);
+        contract(hin, p.wh + (int64_t)(l - 1) * Wp * Wp, Wp, Wp / 2, Wp);
         finish_hidden(hout, l == p.n_hidden - 1);
         __syncthreads();
         float *tmp = hin; hin = hout; hout = tmp;
@@ -1248,17 +1281,35 @@ __global__ __launch_bounds__(kSmallWaves * 64) void mlp_small_kernel(const Small
         f32x16 y;
 #pragma unroll
         for (int r = 0; r < 16; ++r) y[r] = p.bo[32 * t + rho(r) + 4 * half];
-        constexpr int U = 8;
-        for (int p0 = 0; p0 < Wp / 2; p0 += U) {
-            float a[U], b[U];
+        const int n_pairs_o = Wp / 2;
+        const int t_u = __builtin_amdgcn_readfirstlane(t);
+        const __amdgpu_buffer_rsrc_t wo_rsrc = __builtin_amdgcn_make_buffer_rsrc(const_cast<float *>(p.wo), 0, Wp * p.Fp * 4, 0x00020000);
+        const int lane_wo = (half * p.Fp + col) * 4, lane_bo = half * 32 + col;
+        auto load_o = [&](float (&a)[U], float (&b)[U], int p0) {
 #pragma unroll
             for (int u = 0; u < U; ++u) {
-                const int k = 2 * (p0 + u) + half;
-                b[u] = hin[k * 32 + col];
-                a[u] = p.wo[(int64_t)k * p.Fp + 32 * t + col];
+                const int pr = (p0 + u < n_pairs_o) ? p0 + u : n_pairs_o - 1;
+                b[u] = (hin + 64 * pr)[lane_bo];
+                a[u] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(wo_rsrc, lane_wo, (2 * pr * p.Fp + 32 * t_u) * 4, 0));
             }
+        };
+        auto mfma_o = [&](const float (&a)[U], const float (&b)[U]) {
 #pragma unroll
             for (int u = 0; u < U; ++u) y = __builtin_amdgcn_mfma_f32_32x32x2f32(a[u], b[u], y, 0, 0, 0);
+        };
+        {
+            float a0[U], b0[U], a1[U], b1[U];
+            load_o(a0, b0, 0);
+            for (int p0 = 0; p0 < n_pairs_o; p0 += 2 * U) {
+                load_o(a1, b1, p0 + U);
+                __builtin_amdgcn_sched_barrier(0);  // (requests of the next batch stay in front of this batch's MFMAs)
+                mfma_o(a0, b0);
+                __builtin_amdgcn_sched_barrier(0);
+                load_o(a0, b0, p0 + 2 * U);
+                __builtin_amdgcn_sched_barrier(0);
+                mfma_o(a1, b1);
+                __builtin_amdgcn_sched_barrier(0);
+            }
         }
         if (n0 + col >= p.n_samples) continue;
 #pragma unroll
@@ -1702,7 +1753,7 @@ extern "C" int fv3hip_mlp_predict(fv3hip_mlp_t m, const void *const *sources, co
             return e ? (int64_t)atoll(e) : (int64_t)-1;
         }();
         const int64_t limit = m->small_limit >= 0 ? m->small_limit : small_max >= 0 ? small_max : (int64_t)3 * 32 * m->n_cu;
-        const size_t lds_small = (size_t)(2 * kSmallChunk * 32 + 2 * m->Wp * 32) * sizeof(float);
+        const size_t lds_small = (size_t)(2 * kSmallChunk * 32 + 2 * m->Wp * 32) * sizeof(float) + (size_t)m->n_ktab * sizeof(KEntry);
         if (n_samples <= limit && m->n_otiles + m->n_hout_tiles > 0 && lds_small <= 160 * 1024) {
             SmallLaunch sp;
             memset(&sp, 0, sizeof(sp));

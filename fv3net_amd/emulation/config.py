@@ -8,7 +8,7 @@ section (the zarr / netCDF monitor) is accepted with a warning and its hook does
 import dataclasses
 import logging
 import os
-from typing import Dict, Iterable, Mapping, Optional
+from typing import Dict, Iterable, List, Mapping, Optional
 
 import yaml
 
@@ -20,7 +20,7 @@ from .schedule import IntervalSchedule, TimeMask
 
 logger = logging.getLogger("emulation")
 
-_UNIMPLEMENTED = ("tensor_transform",)
+_UNIMPLEMENTED = ()
 _FLAGS = (
     "gscond_cloud_conservative", "mask_gscond_identical_cloud", "mask_gscond_zero_cloud", "enforce_conservative",
     "enforce_conservative_phase_dependent", "mask_gscond_zero_cloud_classifier", "mask_gscond_no_tend_classifier",
@@ -68,6 +68,7 @@ class ModelConfig:
     enforce_strict_precpd_conservative: bool = False
     simple_precip_conservative: bool = False
     batch_size: int = 512
+    tensor_transform: List[object] = dataclasses.field(default_factory=list)  # emulation.transforms objects (config.py:120)
 
     def __post_init__(self):
         if self.enforce_conservative and self.enforce_conservative_phase_dependent:
@@ -91,6 +92,9 @@ class ModelConfig:
         kwargs["mask_emulator_levels"] = {k: LevelSlice(**v) for k, v in (d.get("mask_emulator_levels") or {}).items()}
         if d.get("online_schedule"):
             kwargs["online_schedule"] = IntervalSchedule.from_dict(d["online_schedule"])
+        from .transforms import transform_from_dict
+
+        kwargs["tensor_transform"] = [transform_from_dict(e) for e in (d.get("tensor_transform") or [])]
         return ModelConfig(path=d.get("path"), classifier_path=d.get("classifier_path"), batch_size=int(d.get("batch_size", 512)), **kwargs)
 
     def build(self) -> MicrophysicsHook:
@@ -101,6 +105,11 @@ class ModelConfig:
         else:
             def model(x):
                 return x
+        if self.tensor_transform:  # config.py:145-161: forward on the inputs, the model, backward on everything
+            from .models import transform_model
+            from .transforms import ComposedTransform
+
+            model = transform_model(model, ComposedTransform(self.tensor_transform))
         return MicrophysicsHook(model=model, mask=self._build_mask())
 
     def _build_mask(self) -> Mask:

@@ -57,6 +57,9 @@ class MicrophysicsHook:
             dev_state = {name: on_device(v) if _is_field(name, v) else v for name, v in state.items()}
             inputs = {name: v.t() if v.dim() == 2 else v for name, v in dev_state.items() if hasattr(v, "dim")}
             predictions = self.model(inputs)
+            # (a model wrapped in tensor transforms returns its inputs along with its outputs, models.py:56-65: an entry that
+            # IS the input array has nothing to write back)
+            predictions = {name: t for name, t in predictions.items() if t is not inputs.get(name)}
             # numpy's .T: reverse all axes ([sample, z, class] logits -> [class, z, sample])
             model_outputs = {name: t.permute(*reversed(range(t.dim()))) for name, t in predictions.items()}
             model_outputs.update(self.mask(dev_state, model_outputs))
@@ -65,6 +68,7 @@ class MicrophysicsHook:
             return
         inputs = {name: state[name].T for name in state if hasattr(state[name], "T")}
         predictions = self.model(inputs)
+        predictions = {name: t for name, t in predictions.items() if t is not inputs.get(name)}
         # transpose back to FV3 conventions
         model_outputs = {name: np.asarray(tensor).T for name, tensor in predictions.items()}
         model_outputs.update(self.mask(state, model_outputs))

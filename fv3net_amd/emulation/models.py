@@ -274,4 +274,6 @@ def transform_model(model, transform):
         x_transformed.update(model(x_transformed))
         return transform.backward(x_transformed)
 
+    # (the hook keeps the state on the device around a device-resident model; the transforms work on device tensors too)
+    combined.device_resident = getattr(model, "device_resident", False)
     return combined

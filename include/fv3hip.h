@@ -187,6 +187,12 @@ int fv3hip_block_upsample(const void *in, int elem_size, int64_t n_outer, int ny
 #define FV3HIP_EW_WHERE_S 13   /* a.where(mask b, other=scalar)                       */
 #define FV3HIP_EW_ADD 14       /* a + b                                               */
 #define FV3HIP_EW_ADD_S 15     /* a + scalar                                          */
+/* the emulators' tensor transforms (fv3fit/emulation/transforms/transforms.py:17-158; ABI v3) */
+#define FV3HIP_EW_SUB 16               /* a - b                                (Difference.forward)               */
+#define FV3HIP_EW_LOG_FLOOR_S 17       /* log(max(a, scalar))                  (LogTransform.forward)             */
+#define FV3HIP_EW_EXP 18               /* exp(a)                               (LogTransform.backward)            */
+#define FV3HIP_EW_RELU_THRESHOLD_S 19  /* a where a > scalar else 0            (LimitValueTransform, lower bound) */
+#define FV3HIP_EW_BELOW_S 20           /* a where a < scalar else 0            (LimitValueTransform, upper bound) */
 int fv3hip_ew(int op, const void *a, const void *b, const void *c, double scalar, int dtype,
               int64_t n, int64_t inner, int64_t b_rep, int64_t c_rep, void *out, void *stream);
 

@@ -635,6 +635,48 @@ def test_microphysics_hook_keeps_masks_on_the_device(tmp_path):
     assert state["air_temperature_after_precpd"].dtype == np.float64 and np.all(state["total_precipitation"] >= 0)
 
 
+def test_hook_with_config_level_tensor_transforms(tmp_path):
+    """``zhao_carr_emulation.model.tensor_transform`` (config.py:120,145-161) around a device-resident emulator: the transforms
+    run on the device tensors (fv3hip_ew launches) -- a log-transformed copy of an input the network reads, a Difference
+    whose ``after`` the hook hands back, a value limit -- and the state the Fortran model gets equals the oracle network
+    with the numpy transforms around it."""
+    from fv3net_amd.emulation import HipEmulator
+    from fv3net_amd.emulation.config import ModelConfig
+    from fv3net_amd.emulation.transforms import ComposedTransform
+    from fv3net_amd.mlp import InputSpec, MlpSpec, OutputSpec
+
+    rng = np.random.default_rng(4)
+    nz, n, w = 19, 300, 64
+    spec = MlpSpec(
+        inputs=[InputSpec("T_in", nz, center=np.full(nz, 250.0, np.float32), scale=np.float32(30.0)),
+                InputSpec("log_q", nz, center=np.full(nz, -10.0, np.float32), scale=np.float32(4.0))],
+        hidden_kernels=[(rng.normal(0, 1, (2 * nz, w)) / np.sqrt(2 * nz)).astype(np.float32)], hidden_biases=[rng.normal(0, 0.1, w).astype(np.float32)],
+        outputs=[OutputSpec("dT", nz, scale=np.float32(2.0), center=np.zeros(nz, np.float32)),
+                 OutputSpec("precip", 1, scale=np.float32(1.0), center=np.zeros(1, np.float32))],
+        out_kernel=(rng.normal(0, 1, (w, nz + 1)) / np.sqrt(w)).astype(np.float32), out_bias=rng.normal(0, 0.1, nz + 1).astype(np.float32))
+    HipEmulator(spec).dump(str(tmp_path / "emu"))
+    transforms = [{"source": "q", "transform": {"epsilon": 1e-9}, "to": "log_q"},
+                  {"to": "dT", "before": "T_in", "after": "T_out"},
+                  {"source": "precip", "transform": {"lower": 0.0}}]
+    cfg = ModelConfig.from_dict({"path": str(tmp_path / "emu"), "tensor_transform": transforms})
+    hook = cfg.build()
+    state = {"T_in": rng.uniform(200, 300, (nz, n)), "q": np.where(rng.random((nz, n)) < 0.3, 0.0, 10.0 ** rng.uniform(-8, -2, (nz, n))),
+             "model_time": [2016, 8, 1, 0, 0, 0], "rank": 0}
+    fortran = {k: (v.copy() if isinstance(v, np.ndarray) else v) for k, v in state.items()}
+    assert hook.microphysics(state) is None
+    # the oracle: numpy transforms (the host flavour of the same classes, pinned by tests/test_host_transforms.py) + oracle network
+    x = {"T_in": fortran["T_in"].T, "q": fortran["q"].T}
+    xt = ComposedTransform(cfg.tensor_transform).forward(x)
+    pred = mlp_np.forward(spec, {"T_in": xt["T_in"], "log_q": xt["log_q"]}, dtype=np.float64)
+    want = ComposedTransform(cfg.tensor_transform).backward({**xt, **pred})
+    for name in ("dT", "T_out", "precip", "log_q"):
+        got, ref = state[name], np.asarray(want[name]).T
+        assert got.shape == ref.shape, (name, got.shape, ref.shape)
+        np.testing.assert_allclose(got, ref, rtol=1e-5, atol=1e-5 * np.max(np.abs(ref)), err_msg=name)
+    assert (state["precip"] >= 0).all() and (state["precip"] == 0).any() and (state["precip"] > 0).any()
+    np.testing.assert_array_equal(state["T_in"], fortran["T_in"])  # inputs are not touched
+
+
 def test_calls_work_when_another_device_is_current():
     """The library launches and allocates on the CURRENT device (include/fv3hip.h, DEVICE RULE): the Python layer makes the
     tensors' device current around every call and restores the caller's; fv3hip_init does not switch devices.  Needs two
