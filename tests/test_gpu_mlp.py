@@ -186,7 +186,7 @@ def test_small_sample_kernel_column_results_do_not_depend_on_the_call(device):
     # the other kernel on the same columns: the same values to rounding
     big = MlpModel(spec, device=device, small_limit=0).predict(dev)
     for name, t in truth.items():
-        assert_close_per_level(big[name].cpu().numpy().T, full[name].cpu().numpy().T, None, f"{name}: small against big", rel=2e-6)
+        assert_close_per_level(big[name].cpu().numpy().T, full[name].cpu().numpy().T, None, f"{name}: small against big", rel=1e-5)
 
 
 def test_nan_input_propagates_only_to_its_sample(device):

@@ -165,7 +165,10 @@ def test_emulation_config(tmp_path):
     gscond, micro, store = get_hooks(str(tmp_path / "missing.yml"))
     state = {"a": np.zeros(3)}
     assert micro(state) is None and gscond(state) is None and store(state) is None and list(state) == ["a"]
-    with pytest.raises(NotImplementedError, match="tensor_transform"):
+    # transforms that build from nothing are accepted (tests/test_host_transforms.py); one that has to be fitted is not
+    with pytest.raises(NotImplementedError, match="ConditionallyScaled"):
+        EmulationConfig.from_dict({"model": {"path": "x", "tensor_transform": [{"to": "a", "source": "b", "condition_on": "T", "bins": 10}]}})
+    with pytest.raises(ValueError, match="unknown tensor transform"):
         EmulationConfig.from_dict({"model": {"path": "x", "tensor_transform": [{"to": "a", "source": "b"}]}})
     assert EmulationConfig.from_dict({"model": {"path": "x", "classifier_path": "y"}}).model.classifier_path == "y"
     cfg = EmulationConfig.from_dict({"model": {"path": "x", "cloud_squash": 1e-6, "enforce_conservative": True,
