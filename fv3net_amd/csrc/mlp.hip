@@ -1108,6 +1108,7 @@ struct SmallLaunch {
     const OEntry *otab;
     int n_ktab, Wp, HT, n_hidden, Fp, n_otiles, n_hout_tiles, out64, has_limits, hout_slot;
     int64_t n_samples;
+    unsigned long long *stamps;  // diagnostic builds only (-DSMALL_STAMPS): [workgroup][wave][8] cycle stamps
     const void *src[kMaxSources];
     int64_t src_fs[kMaxSources];
     int64_t src_ss[kMaxSources];
@@ -1119,24 +1120,142 @@ struct SmallLaunch {
 constexpr int kSmallWaves = 8;     // 512 threads: two waves per SIMD hide each other's operand loads
 constexpr int kSmallChunk = 128;   // input features staged per step (2 x 16 KB of LDS)
 
+#ifdef SMALL_STAMPS
+#define SM_STAMP(i) if (lane == 0 && p.stamps) p.stamps[((int64_t)blockIdx.x * kSmallWaves + wave) * 8 + (i)] = __builtin_readcyclecounter()
+#else
+#define SM_STAMP(i) ((void)0)
+#endif
+
 template <bool SRC64>
 __global__ __launch_bounds__(kSmallWaves * 64) void mlp_small_kernel(const SmallLaunch p)
 {
     using Raw = typename std::conditional<SRC64, double, float>::type;
     constexpr int NW = kSmallWaves, NT = NW * 64, KCH = kSmallChunk, PER = KCH * 32 / NT;
     constexpr int MAXT = (8 + NW - 1) / NW;  // hidden tiles a wave may own (HT <= 8)
+    constexpr int U = 8;                     // k-pairs per operand batch
+    struct XRow {  // one network input of this call: where its row starts and what is done to it (32 bytes, LDS)
+        int64_t row;      // byte address of (feature, sample 0); 0 = padding
+        unsigned int ss;  // bytes between samples
+        float center, eps;
+        int is_log;
+        int pad0, pad1;
+    };
     extern __shared__ float small_lds[];
     float *xs = small_lds;               // [2][KCH][32]
     float *hA = xs + 2 * KCH * 32;       // [Wp][32]
     float *hB = hA + p.Wp * 32;          // [Wp][32]
-    KEntry *kt = reinterpret_cast<KEntry *>(hB + p.Wp * 32);  // [n_ktab]: the input table, so that a row's address does not cost a round trip
+    XRow *kt = reinterpret_cast<XRow *>(hB + p.Wp * 32);  // [n_ktab]
+    // the call's source / output arrays, so that a per-feature slot number is an LDS lookup (indexing the kernel arguments
+    // with a per-lane index costs a dependent memory round trip per value: the first version spent 4 K cycles per chunk
+    // just ISSUING its input loads, and 13 K storing the hidden outputs)
+    int64_t *otab_base = reinterpret_cast<int64_t *>(kt + p.n_ktab);  // [3][kMaxOutputs]: base, feature stride, sample stride (bytes)
+    int64_t *stab_base = otab_base + 3 * kMaxOutputs;                  // [3][kMaxSources]
     const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63, half = lane >> 5, col = lane & 31;
+    const int wave_u = __builtin_amdgcn_readfirstlane(wave);
     const int64_t n0 = (int64_t)blockIdx.x * 32;
     const int Wp = p.Wp, HT = p.HT;
     const int n_chunks = (p.n_ktab + KCH - 1) / KCH;
+    constexpr int64_t ESZ = SRC64 ? 8 : 4;
+    const int64_t osz = p.out64 ? 8 : 4;
 
-    for (int i = tid; i < p.n_ktab; i += NT) kt[i] = p.ktab[i];
+    // ---- the weight stream ----
+    // A call of this kernel is a chain of dependent phases (table, inputs, layer by layer, epilogue); at 32 samples per
+    // workgroup each phase is a few microseconds, so every memory round trip that sits BETWEEN phases shows (the first
+    // version paid ~10 of them, 3x its matrix time).  The weights therefore form ONE stream over layer 1 and the hidden
+    // layers -- segment 0 = w1 [n_ktab][Wp], segment l = wh[l-1] [Wp][Wp], all read as rows of k-pairs for this wave's
+    // tiles -- requested one batch (U k-pairs) ahead of the MFMAs that consume it, ACROSS chunk, barrier and layer
+    // boundaries: while a phase ends, the next phase's first operands are already on their way.  Every request is an
+    // unconditional raw buffer load (descriptor + loop-invariant lane offset + scalar row offset): no vector address
+    // arithmetic, exact counted waits.
+    int tcl[MAXT];  // this wave's tiles, clamped (uniform)
+#pragma unroll
+    for (int ti = 0; ti < MAXT; ++ti) tcl[ti] = (wave_u + ti * NW < HT) ? wave_u + ti * NW : HT - 1;
+    const int lane_w = (half * Wp + col) * 4, lane_b = half * 32 + col;
+    int a_seg = 0, a_pair = 0;  // the next batch to request (uniform)
+    const int last_seg = p.n_hidden - 1;
+    auto request_a = [&](float (&a)[MAXT][U]) {
+        const float *base = (a_seg == 0) ? p.w1 : p.wh + (int64_t)(a_seg - 1) * Wp * Wp;
+        const int seg_pairs = (a_seg == 0) ? p.n_ktab / 2 : Wp / 2;
+        const __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc(const_cast<float *>(base), 0, seg_pairs * 2 * Wp * 4, 0x00020000);
+#pragma unroll
+        for (int u = 0; u < U; ++u)
+#pragma unroll
+            for (int ti = 0; ti < MAXT; ++ti)
+                a[ti][u] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rs, lane_w, (2 * (a_pair + u) * Wp + 32 * tcl[ti]) * 4, 0));
+        a_pair += U;  // (segments are whole numbers of batches: n_ktab / 2 and Wp / 2 are multiples of 2 U)
+        if (a_pair >= seg_pairs && a_seg < last_seg) {
+            a_pair = 0;
+            ++a_seg;
+        } else if (a_pair >= seg_pairs) {
+            a_pair = seg_pairs - U;  // past the end of the stream: the last batch again (never consumed)
+        }
+    };
+    auto load_b = [&](float (&b)[U], const float *bsrc, int p0, int n_pairs) {
+#pragma unroll
+        for (int u = 0; u < U; ++u) {
+            const int pr = (p0 + u < n_pairs) ? p0 + u : n_pairs - 1;
+            b[u] = (bsrc + 64 * pr)[lane_b];
+        }
+    };
+    f32x16 acc[MAXT];
+    auto mfma_ops = [&](const float (&a)[MAXT][U], const float (&b)[U]) {
+#pragma unroll
+        for (int u = 0; u < U; ++u)
+#pragma unroll
+            for (int ti = 0; ti < MAXT; ++ti)
+                if (wave_u + ti * NW < HT) acc[ti] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[ti][u], b[u], acc[ti], 0, 0, 0);
+    };
+    float a0[MAXT][U], a1[MAXT][U], b0[U], b1[U];
+    // n_pairs (a multiple of 2 U) k-pairs of the stream against B[k][sample] in LDS; on entry a0 holds the first batch
+    auto contract = [&](const float *bsrc, int n_pairs) {
+        load_b(b0, bsrc, 0, n_pairs);
+        for (int p0 = 0; p0 < n_pairs; p0 += 2 * U) {
+            request_a(a1);
+            load_b(b1, bsrc, p0 + U, n_pairs);
+            __builtin_amdgcn_sched_barrier(0);  // (the requests stay in front of this batch's MFMAs)
+            mfma_ops(a0, b0);
+            __builtin_amdgcn_sched_barrier(0);
+            request_a(a0);
+            load_b(b0, bsrc, p0 + 2 * U, n_pairs);
+            __builtin_amdgcn_sched_barrier(0);
+            mfma_ops(a1, b1);
+            __builtin_amdgcn_sched_barrier(0);
+        }
+    };
+    SM_STAMP(0);
+    request_a(a0);  // the first weights are on their way before anything else
+
+    for (int i = tid; i < p.n_ktab; i += NT) {
+        const KEntry e = p.ktab[i];
+        XRow x;
+        x.row = e.src < 0 ? 0 : reinterpret_cast<int64_t>(p.src[e.src]) + (int64_t)e.feat * p.src_fs[e.src] * ESZ;
+        x.ss = e.src < 0 ? 0u : (unsigned int)(p.src_ss[e.src] * ESZ);
+        x.center = e.center;
+        x.eps = e.eps;
+        x.is_log = (e.transform == FV3HIP_TRANSFORM_LOG) ? 1 : 0;
+        x.pad0 = x.pad1 = 0;
+        kt[i] = x;
+    }
+    if (tid < kMaxOutputs) {
+        otab_base[tid] = reinterpret_cast<int64_t>(p.out[tid]);
+        otab_base[kMaxOutputs + tid] = p.out_fs[tid] * osz;
+        otab_base[2 * kMaxOutputs + tid] = p.out_ss[tid] * osz;
+    }
+    if (tid < kMaxSources) {
+        stab_base[tid] = reinterpret_cast<int64_t>(p.src[tid]);
+        stab_base[kMaxSources + tid] = p.src_fs[tid] * ESZ;
+        stab_base[2 * kMaxSources + tid] = p.src_ss[tid] * ESZ;
+    }
+    // the output slots of the hidden activations (hidden-output models): read now, used after the last hidden layer
+    int hout_feat[MAXT][16];
+    if (p.n_hout_tiles) {
+#pragma unroll
+        for (int ti = 0; ti < MAXT; ++ti)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) hout_feat[ti][r] = p.otab[32 * tcl[ti] + rho(r) + 4 * half].out_feat;
+    }
     __syncthreads();
+    SM_STAMP(1);
     // ---- input staging: raw loads now, transform + centre when the rows are parked in LDS ----
     Raw xr[PER];
     auto issue = [&](int c) {
@@ -1145,10 +1264,10 @@ __global__ __launch_bounds__(kSmallWaves * 64) void mlp_small_kernel(const Small
             const int idx = tid + j * NT, kk = idx >> 5, n = idx & 31, k = c * KCH + kk;
             xr[j] = (Raw)1;
             if (k < p.n_ktab) {
-                const KEntry e = kt[k];
+                const XRow e = kt[k];
                 int64_t ns = n0 + n;
                 if (ns >= p.n_samples) ns = p.n_samples - 1;  // (a ragged last tile reads its last sample again)
-                if (e.src >= 0) xr[j] = static_cast<const Raw *>(p.src[e.src])[(int64_t)e.feat * p.src_fs[e.src] + ns * p.src_ss[e.src]];
+                if (e.row != 0) xr[j] = *reinterpret_cast<const Raw *>(e.row + ns * e.ss);
             }
         }
     };
@@ -1158,82 +1277,27 @@ __global__ __launch_bounds__(kSmallWaves * 64) void mlp_small_kernel(const Small
             const int idx = tid + j * NT, kk = idx >> 5, n = idx & 31, k = c * KCH + kk;
             float v = 0.f;
             if (k < p.n_ktab) {
-                const KEntry e = kt[k];
-                if (e.src >= 0) {
+                const XRow e = kt[k];
+                if (e.row != 0) {
                     v = (float)xr[j];
-                    if (e.transform == FV3HIP_TRANSFORM_LOG) v = logf(v < e.eps ? e.eps : v);
+                    if (e.is_log) v = logf(v < e.eps ? e.eps : v);
                     v = v - e.center;  // (1 / std lives in the layer-1 weights)
                 }
             }
             xs[(buf * KCH + kk) * 32 + n] = v;
         }
     };
-    f32x16 acc[MAXT];
     auto init_bias = [&](const float *b) {
 #pragma unroll
-        for (int ti = 0; ti < MAXT; ++ti) {
-            const int t = wave + ti * NW;
+        for (int ti = 0; ti < MAXT; ++ti)
 #pragma unroll
-            for (int r = 0; r < 16; ++r) acc[ti][r] = (t < HT) ? b[32 * t + rho(r) + 4 * half] : 0.f;
-        }
-    };
-    // A block of k-pairs against this wave's tiles: B[k][sample] from LDS, A[feature][k] from the plain weight rows in L2.
-    // The operand loads of batch i + 1 (U k-pairs) are in flight while the MFMAs of batch i issue: two register sets, the
-    // loop body written out for both (a rotation by moves would wait for the loads just issued).  Without it every batch
-    // paid an L2 round trip (~1 us) in front of its 8 MFMAs (~0.2 us): the first version of this kernel ran at a fifth of
-    // its matrix time.
-    // (every load is unconditional -- indices past the end are clamped, a wave without a tile reads the last tile's rows
-    // and skips the MFMAs -- so that the counted wait in front of a batch's MFMAs is `vmcnt(loads of the next batch)`:
-    // with the loads inside branches the compiler waited for everything, the next batch included)
-    constexpr int U = 8;
-    // Addresses are a wave-uniform part (scalar registers) plus a per-lane 32-bit offset that never changes: with 64-bit
-    // per-lane address arithmetic the compiler computed each address IN the register a previous load was still writing
-    // and had to wait for that load first -- the requests of a batch were serialised behind the batch before.
-    const int wave_u = __builtin_amdgcn_readfirstlane(wave);
-    int tcl[MAXT];  // this wave's tiles, clamped (uniform)
-#pragma unroll
-    for (int ti = 0; ti < MAXT; ++ti) tcl[ti] = (wave_u + ti * NW < HT) ? wave_u + ti * NW : HT - 1;
-    // (weights through raw buffer loads: descriptor + a loop-invariant per-lane offset + a scalar row offset -- no address
-    // arithmetic on the vector unit, and the destination registers are nobody's address temporaries)
-    auto load_ops = [&](float (&a)[MAXT][U], float (&b)[U], const float *bsrc, const __amdgpu_buffer_rsrc_t wr, int p0, int n_pairs, int ldw) {
-        const int lane_w = (half * ldw + col) * 4;   // bytes, per lane, loop-invariant
-        const int lane_b = half * 32 + col;
-#pragma unroll
-        for (int u = 0; u < U; ++u) {
-            const int pr = (p0 + u < n_pairs) ? p0 + u : n_pairs - 1;  // uniform
-            b[u] = (bsrc + 64 * pr)[lane_b];
-#pragma unroll
-            for (int ti = 0; ti < MAXT; ++ti)
-                a[ti][u] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(wr, lane_w, (2 * pr * ldw + 32 * tcl[ti]) * 4, 0));
-        }
-    };
-    auto mfma_ops = [&](const float (&a)[MAXT][U], const float (&b)[U]) {
-#pragma unroll
-        for (int u = 0; u < U; ++u)
-#pragma unroll
-            for (int ti = 0; ti < MAXT; ++ti)
-                if (wave_u + ti * NW < HT) acc[ti] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[ti][u], b[u], acc[ti], 0, 0, 0);
-    };
-    auto contract = [&](const float *bsrc, const float *wbase, int n_rows, int n_pairs, int ldw) {  // n_pairs: a multiple of 2 U
-        const __amdgpu_buffer_rsrc_t wrow0 = __builtin_amdgcn_make_buffer_rsrc(const_cast<float *>(wbase), 0, n_rows * ldw * 4, 0x00020000);
-        float a0[MAXT][U], b0[U], a1[MAXT][U], b1[U];
-        load_ops(a0, b0, bsrc, wrow0, 0, n_pairs, ldw);
-        for (int p0 = 0; p0 < n_pairs; p0 += 2 * U) {
-            load_ops(a1, b1, bsrc, wrow0, p0 + U, n_pairs, ldw);
-            __builtin_amdgcn_sched_barrier(0);  // (requests of the next batch stay in front of this batch's MFMAs)
-            mfma_ops(a0, b0);
-            __builtin_amdgcn_sched_barrier(0);
-            load_ops(a0, b0, bsrc, wrow0, p0 + 2 * U, n_pairs, ldw);
-            __builtin_amdgcn_sched_barrier(0);
-            mfma_ops(a1, b1);
-            __builtin_amdgcn_sched_barrier(0);
-        }
+            for (int r = 0; r < 16; ++r) acc[ti][r] = b[32 * tcl[ti] + rho(r) + 4 * half];
     };
     // ReLU, park the activations for the next layer (and hand them out when the model returns its last hidden layer)
     auto finish_hidden = [&](float *dst, bool last) {
 #pragma unroll
         for (int ti = 0; ti < MAXT; ++ti) {
-            const int t = wave + ti * NW;
+            const int t = wave_u + ti * NW;
             if (t >= HT) continue;
 #pragma unroll
             for (int r = 0; r < 16; ++r) {
@@ -1241,12 +1305,12 @@ __global__ __launch_bounds__(kSmallWaves * 64) void mlp_small_kernel(const Small
                 const float h = acc[ti][r] < 0.f ? 0.f : acc[ti][r];  // (a NaN stays a NaN, as in the big kernel and in Keras' relu)
                 dst[f * 32 + col] = h;
                 if (last && p.n_hout_tiles) {
-                    const OEntry e = p.otab[f];
-                    if (e.out_feat >= 0 && n0 + col < p.n_samples) {
-                        const int slot = e.out_feat >> 20, q = e.out_feat & 0xFFFFF;
-                        const int64_t off = (int64_t)q * p.out_fs[slot] + (n0 + col) * p.out_ss[slot];
-                        if (p.out64) static_cast<double *>(p.out[slot])[off] = (double)h;
-                        else static_cast<float *>(p.out[slot])[off] = h;
+                    const int of = hout_feat[ti][r];
+                    if (of >= 0 && n0 + col < p.n_samples) {
+                        const int slot = of >> 20, q = of & 0xFFFFF;
+                        const int64_t addr = otab_base[slot] + q * otab_base[kMaxOutputs + slot] + (n0 + col) * otab_base[2 * kMaxOutputs + slot];
+                        if (p.out64) *reinterpret_cast<double *>(addr) = (double)h;
+                        else *reinterpret_cast<float *>(addr) = h;
                     }
                 }
             }
@@ -1258,84 +1322,91 @@ __global__ __launch_bounds__(kSmallWaves * 64) void mlp_small_kernel(const Small
     init_bias(p.bh);
     commit(0, 0);
     __syncthreads();
+    SM_STAMP(2);
     for (int c = 0; c < n_chunks; ++c) {
         if (c + 1 < n_chunks) issue(c + 1);
         const int kn = (p.n_ktab - c * KCH < KCH) ? p.n_ktab - c * KCH : KCH;  // (n_ktab is a multiple of 32)
-        contract(xs + (c & 1) * KCH * 32, p.w1 + (int64_t)c * KCH * Wp, kn, kn / 2, Wp);
+        contract(xs + (c & 1) * KCH * 32, kn / 2);
         if (c + 1 < n_chunks) commit(c + 1, (c + 1) & 1);
         __syncthreads();
     }
+    SM_STAMP(3);
     float *hin = hA, *hout = hB;
     finish_hidden(hin, p.n_hidden == 1);
     __syncthreads();
+    SM_STAMP(4);
     // ---- hidden layers ----
     for (int l = 1; l < p.n_hidden; ++l) {
         init_bias(p.bh + (int64_t)l * Wp);
-        contract(hin, p.wh + (int64_t)(l - 1) * Wp * Wp, Wp, Wp / 2, Wp);
+        contract(hin, Wp / 2);
         finish_hidden(hout, l == p.n_hidden - 1);
         __syncthreads();
         float *tmp = hin; hin = hout; hout = tmp;
     }
     // ---- output layer: 32-feature tiles dealt over the waves; per-value epilogue ----
-    for (int t = wave; t < p.n_otiles; t += NW) {
+    const __amdgpu_buffer_rsrc_t wo_rsrc = __builtin_amdgcn_make_buffer_rsrc(const_cast<float *>(p.wo), 0, Wp * p.Fp * 4, 0x00020000);
+    const int lane_wo = (half * p.Fp + col) * 4;
+    const int n_pairs_o = Wp / 2;
+    for (int t = wave_u; t < p.n_otiles; t += NW) {
         f32x16 y;
-#pragma unroll
-        for (int r = 0; r < 16; ++r) y[r] = p.bo[32 * t + rho(r) + 4 * half];
-        const int n_pairs_o = Wp / 2;
-        const int t_u = __builtin_amdgcn_readfirstlane(t);
-        const __amdgpu_buffer_rsrc_t wo_rsrc = __builtin_amdgcn_make_buffer_rsrc(const_cast<float *>(p.wo), 0, Wp * p.Fp * 4, 0x00020000);
-        const int lane_wo = (half * p.Fp + col) * 4, lane_bo = half * 32 + col;
+        float c0[U], c1[U];
         auto load_o = [&](float (&a)[U], float (&b)[U], int p0) {
 #pragma unroll
             for (int u = 0; u < U; ++u) {
                 const int pr = (p0 + u < n_pairs_o) ? p0 + u : n_pairs_o - 1;
-                b[u] = (hin + 64 * pr)[lane_bo];
-                a[u] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(wo_rsrc, lane_wo, (2 * pr * p.Fp + 32 * t_u) * 4, 0));
+                b[u] = (hin + 64 * pr)[lane_b];
+                a[u] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(wo_rsrc, lane_wo, (2 * pr * p.Fp + 32 * t) * 4, 0));
             }
         };
         auto mfma_o = [&](const float (&a)[U], const float (&b)[U]) {
 #pragma unroll
             for (int u = 0; u < U; ++u) y = __builtin_amdgcn_mfma_f32_32x32x2f32(a[u], b[u], y, 0, 0, 0);
         };
-        {
-            float a0[U], b0[U], a1[U], b1[U];
-            load_o(a0, b0, 0);
-            for (int p0 = 0; p0 < n_pairs_o; p0 += 2 * U) {
-                load_o(a1, b1, p0 + U);
-                __builtin_amdgcn_sched_barrier(0);  // (requests of the next batch stay in front of this batch's MFMAs)
-                mfma_o(a0, b0);
-                __builtin_amdgcn_sched_barrier(0);
-                load_o(a0, b0, p0 + 2 * U);
-                __builtin_amdgcn_sched_barrier(0);
-                mfma_o(a1, b1);
-                __builtin_amdgcn_sched_barrier(0);
-            }
+        load_o(c0, b0, 0);
+        // this tile's table entries and biases travel under its MFMAs
+        int of_[16], res_[16];
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            const int f = 32 * t + rho(r) + 4 * half;
+            y[r] = p.bo[f];
+            of_[r] = p.otab[32 * p.n_hout_tiles + f].out_feat;
+            res_[r] = p.otab[32 * p.n_hout_tiles + f].res;
+        }
+        for (int p0 = 0; p0 < n_pairs_o; p0 += 2 * U) {
+            load_o(c1, b1, p0 + U);
+            __builtin_amdgcn_sched_barrier(0);
+            mfma_o(c0, b0);
+            __builtin_amdgcn_sched_barrier(0);
+            load_o(c0, b0, p0 + 2 * U);
+            __builtin_amdgcn_sched_barrier(0);
+            mfma_o(c1, b1);
+            __builtin_amdgcn_sched_barrier(0);
         }
         if (n0 + col >= p.n_samples) continue;
 #pragma unroll
         for (int r = 0; r < 16; ++r) {
-            const int f = 32 * t + rho(r) + 4 * half;
-            const OEntry e = p.otab[32 * p.n_hout_tiles + f];
-            if (e.out_feat < 0) continue;
+            if (of_[r] < 0) continue;
             float x = y[r];  // (the physical value: scale and centre live in the output weights and bias)
             if (p.has_limits) {
+                const OEntry e = p.otab[32 * p.n_hout_tiles + 32 * t + rho(r) + 4 * half];
                 if (x < e.lo) x = e.lo;
                 if (x >= e.hi) x = e.hi;
                 x = x * e.mask;
             }
-            const int slot = e.out_feat >> 20, q = e.out_feat & 0xFFFFF;
-            const int64_t off = (int64_t)q * p.out_fs[slot] + (n0 + col) * p.out_ss[slot];
-            if (p.out64) static_cast<double *>(p.out[slot])[off] = (double)x;
-            else static_cast<float *>(p.out[slot])[off] = x;
-            if (e.res >= 0) {  // residual output: after = before + value (transforms.py:54-58)
-                const int rslot = e.res >> 8, rs = e.res & 0xFF;
-                const float before = (float)static_cast<const Raw *>(p.src[rs])[(int64_t)q * p.src_fs[rs] + (n0 + col) * p.src_ss[rs]];
-                const int64_t roff = (int64_t)q * p.out_fs[rslot] + (n0 + col) * p.out_ss[rslot];
-                if (p.out64) static_cast<double *>(p.out[rslot])[roff] = (double)(before + x);
-                else static_cast<float *>(p.out[rslot])[roff] = before + x;
+            const int slot = of_[r] >> 20, q = of_[r] & 0xFFFFF;
+            const int64_t addr = otab_base[slot] + q * otab_base[kMaxOutputs + slot] + (n0 + col) * otab_base[2 * kMaxOutputs + slot];
+            if (p.out64) *reinterpret_cast<double *>(addr) = (double)x;
+            else *reinterpret_cast<float *>(addr) = x;
+            if (res_[r] >= 0) {  // residual output: after = before + value (transforms.py:54-58)
+                const int rslot = res_[r] >> 8, rs = res_[r] & 0xFF;
+                const float before = (float)*reinterpret_cast<const Raw *>(stab_base[rs] + q * stab_base[kMaxSources + rs] + (n0 + col) * stab_base[2 * kMaxSources + rs]);
+                const int64_t raddr = otab_base[rslot] + q * otab_base[kMaxOutputs + rslot] + (n0 + col) * otab_base[2 * kMaxOutputs + rslot];
+                if (p.out64) *reinterpret_cast<double *>(raddr) = (double)(before + x);
+                else *reinterpret_cast<float *>(raddr) = before + x;
             }
         }
     }
+    SM_STAMP(5);
 }
 
 }  // namespace
@@ -1672,6 +1743,10 @@ extern "C" int fv3hip_mlp_create(const fv3hip_mlp_desc_t *d, fv3hip_mlp_t *out)
     return FV3HIP_OK;
 }
 
+#ifdef SMALL_STAMPS
+static unsigned long long *g_small_stamps = nullptr;
+extern "C" void fv3hip_diag_set_small_stamps(void *p) { g_small_stamps = static_cast<unsigned long long *>(p); }
+#endif
 #ifdef MLP_STAMPS
 static unsigned long long *g_mlp_stamps = nullptr;
 extern "C" void fv3hip_diag_set_mlp_stamps(void *p) { g_mlp_stamps = static_cast<unsigned long long *>(p); }
@@ -1753,7 +1828,8 @@ extern "C" int fv3hip_mlp_predict(fv3hip_mlp_t m, const void *const *sources, co
             return e ? (int64_t)atoll(e) : (int64_t)-1;
         }();
         const int64_t limit = m->small_limit >= 0 ? m->small_limit : small_max >= 0 ? small_max : (int64_t)3 * 32 * m->n_cu;
-        const size_t lds_small = (size_t)(2 * kSmallChunk * 32 + 2 * m->Wp * 32) * sizeof(float) + (size_t)m->n_ktab * sizeof(KEntry);
+        const size_t lds_small = (size_t)(2 * kSmallChunk * 32 + 2 * m->Wp * 32) * sizeof(float) + (size_t)m->n_ktab * 32 +
+                                 (size_t)3 * (kMaxOutputs + kMaxSources) * sizeof(int64_t);
         if (n_samples <= limit && m->n_otiles + m->n_hout_tiles > 0 && lds_small <= 160 * 1024) {
             SmallLaunch sp;
             memset(&sp, 0, sizeof(sp));
@@ -1774,6 +1850,9 @@ extern "C" int fv3hip_mlp_predict(fv3hip_mlp_t m, const void *const *sources, co
             sp.out64 = (out_dtype == FV3HIP_F64);
             sp.has_limits = m->has_limits;
             sp.n_samples = n_samples;
+#ifdef SMALL_STAMPS
+            sp.stamps = g_small_stamps;
+#endif
             memcpy(sp.src, lp.src, sizeof(sp.src));
             memcpy(sp.src_fs, lp.src_fs, sizeof(sp.src_fs));
             memcpy(sp.src_ss, lp.src_ss, sizeof(sp.src_ss));

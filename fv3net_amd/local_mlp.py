@@ -465,41 +465,42 @@ class RnnModel(_PointModel):
                  torch.empty((m.spec.width, ncol), dtype=torch.float32, device=dev)] for m in self._cells]
 
     def _sweep(self, x: torch.Tensor, y: torch.Tensor, states, nz: int, pipelined: bool = False) -> None:
-        """The recurrence, from the model top (last index) to the surface.  ``pipelined``: one HIP stream per layer, so
-        that layer n+1 of level z runs beside layer n of level z-1 (for column counts that leave most CUs idle).  The
-        hazards are the state ping-pong buffers: layer n+1 reads at step t what layer n wrote at step t, and layer n
-        overwrites at step t+1 the buffer layer n+1 read at step t-1."""
+        """The recurrence, from the model top (last index) to the surface.  ``pipelined`` (column counts that leave most
+        CUs idle): a wavefront over (layer, level) -- at tick t layer n works on step t - n, all layers of a tick side by
+        side on a stream each, joined before the next tick.  Fork / join by ``wait_stream`` only, which a HIP-graph capture
+        records as parallel branches (per-step events across three streams crashed the runtime's capture_end).  Hazards: the
+        state ping-pong buffers -- layer n reads at step s what layer n - 1 wrote at step s (the tick before: joined), and the
+        layers of one tick touch different halves of every pair (layer n - 1 writes [cur(s)] while layer n reads [nxt(s)])."""
         depth = len(self._cells)
-        if pipelined and depth > 1:
-            dev = x.device
-            main = torch.cuda.current_stream(dev)
-            if not hasattr(self, "_streams"):
-                self._streams = [torch.cuda.Stream(dev) for _ in range(depth)]
-            done = [[torch.cuda.Event() for _ in range(nz)] for _ in range(depth)]
-            for s in self._streams:
-                s.wait_stream(main)
-        for step, z in enumerate(range(nz - 1, -1, -1)):
+
+        def cell(n: int, step: int):
+            z = nz - 1 - step
             cur, nxt = step & 1, (step & 1) ^ 1
-            below = x[:, z]
-            for n, m in enumerate(self._cells):
-                outs = {"h": states[n][nxt]}
-                if n == depth - 1:
-                    outs["y"] = y[:, z]
-                if pipelined and depth > 1:
-                    st = self._streams[n]
-                    with torch.cuda.stream(st):
-                        if n > 0:
-                            st.wait_event(done[n - 1][step])
-                        if n + 1 < depth and step >= 2:
-                            st.wait_event(done[n + 1][step - 2])
-                        m.predict({"in": below, "rec": states[n][cur]}, out=outs)
-                        done[n][step].record(st)
-                else:
-                    m.predict({"in": below, "rec": states[n][cur]}, out=outs)
-                below = states[n][nxt]
-        if pipelined and depth > 1:
-            for s in self._streams:
-                main.wait_stream(s)
+            below = x[:, z] if n == 0 else states[n - 1][nxt]
+            outs = {"h": states[n][nxt]}
+            if n == depth - 1:
+                outs["y"] = y[:, z]
+            self._cells[n].predict({"in": below, "rec": states[n][cur]}, out=outs)
+
+        if not (pipelined and depth > 1):
+            for step in range(nz):
+                for n in range(depth):
+                    cell(n, step)
+            return
+        dev = x.device
+        main = torch.cuda.current_stream(dev)
+        if not hasattr(self, "_streams"):
+            self._streams = [torch.cuda.Stream(dev) for _ in range(depth - 1)]
+        for tick in range(nz + depth - 1):
+            active = [(n, tick - n) for n in range(depth) if 0 <= tick - n < nz]
+            side = active[1:]
+            for (n, step), st in zip(side, self._streams):
+                st.wait_stream(main)
+                with torch.cuda.stream(st):
+                    cell(n, step)
+            cell(*active[0])
+            for _, st in zip(side, self._streams):
+                main.wait_stream(st)
 
     def _sweep_graphed(self, arrs, nz: int, ncol: int, dev):
         """Pack into the graph's static input buffer, replay the captured sweep, hand back its static output buffer
@@ -512,13 +513,16 @@ class RnnModel(_PointModel):
             y = torch.empty((self.spec.n_channels, nz, ncol), dtype=torch.float32, device=dev)
             states = self._new_states(ncol, dev)
             self._pack_into(arrs, nz, ncol, dev, x)
-            self._sweep(x, y, states, nz)  # eager warm-up: the kernels' one-time allocations happen here
+            # (column counts that leave most CUs idle: the layers on a stream each, layer n + 1 of level z beside layer n of
+            # level z - 1; the capture records the side streams' work as parallel branches of the graph)
+            pipelined = ncol < 128 * self._inner_cus()
+            self._sweep(x, y, states, nz, pipelined=pipelined)  # eager warm-up: the kernels' one-time allocations happen here
             torch.cuda.synchronize(dev)
             graph = torch.cuda.CUDAGraph()
             with torch.cuda.graph(graph):
                 for st in states:
                     st[0].zero_()
-                self._sweep(x, y, states, nz)
+                self._sweep(x, y, states, nz, pipelined=pipelined)
             entry = self._graphs[key] = (graph, x, y, states)
         graph, x, y, _ = entry
         self._pack_into(arrs, nz, ncol, dev, x)
