@@ -1120,6 +1120,13 @@ struct SmallLaunch {
 constexpr int kSmallWaves = 8;     // 512 threads: two waves per SIMD hide each other's operand loads
 constexpr int kSmallChunk = 128;   // input features staged per step (2 x 16 KB of LDS)
 
+// (uniform index: a scalar read of the kernel arguments) what: 0 base address, 1 feature stride, 2 sample stride, in bytes
+__device__ __forceinline__ int64_t otab_base_early(const SmallLaunch &p, int slot, int what)
+{
+    const int64_t osz = p.out64 ? 8 : 4;
+    return what == 0 ? reinterpret_cast<int64_t>(p.out[slot]) : what == 1 ? p.out_fs[slot] * osz : p.out_ss[slot] * osz;
+}
+
 #ifdef SMALL_STAMPS
 #define SM_STAMP(i) if (lane == 0 && p.stamps) p.stamps[((int64_t)blockIdx.x * kSmallWaves + wave) * 8 + (i)] = __builtin_readcyclecounter()
 #else
@@ -1293,7 +1300,15 @@ __global__ __launch_bounds__(kSmallWaves * 64) void mlp_small_kernel(const Small
 #pragma unroll
             for (int r = 0; r < 16; ++r) acc[ti][r] = b[32 * tcl[ti] + rho(r) + 4 * half];
     };
-    // ReLU, park the activations for the next layer (and hand them out when the model returns its last hidden layer)
+    // ReLU, park the activations for the next layer.  When the model returns its last hidden layer (recurrent cells) the
+    // rows leave AFTER the barrier, from LDS, 16 bytes per lane (hidden_rows_out) where the output is float32, sample-contiguous
+    // and 16-byte aligned and the tile is whole -- four row pieces per thread instead of sixteen 4-byte stores per lane.
+    const int hslot = p.n_hout_tiles ? (p.otab[0].out_feat >> 20) : 0;  // (uniform: every hidden feature goes to one slot)
+    bool hout_rows = false;
+    if (p.n_hout_tiles) {
+        const int64_t hb = otab_base_early(p, hslot, 0), hfs = otab_base_early(p, hslot, 1), hss = otab_base_early(p, hslot, 2);
+        hout_rows = !p.out64 && hss == 4 && (hb % 16 == 0) && (hfs % 16 == 0) && (n0 % 4 == 0) && n0 + 32 <= p.n_samples;
+    }
     auto finish_hidden = [&](float *dst, bool last) {
 #pragma unroll
         for (int ti = 0; ti < MAXT; ++ti) {
@@ -1304,7 +1319,7 @@ __global__ __launch_bounds__(kSmallWaves * 64) void mlp_small_kernel(const Small
                 const int f = 32 * t + rho(r) + 4 * half;
                 const float h = acc[ti][r] < 0.f ? 0.f : acc[ti][r];  // (a NaN stays a NaN, as in the big kernel and in Keras' relu)
                 dst[f * 32 + col] = h;
-                if (last && p.n_hout_tiles) {
+                if (last && p.n_hout_tiles && !hout_rows) {
                     const int of = hout_feat[ti][r];
                     if (of >= 0 && n0 + col < p.n_samples) {
                         const int slot = of >> 20, q = of & 0xFFFFF;
@@ -1314,6 +1329,16 @@ __global__ __launch_bounds__(kSmallWaves * 64) void mlp_small_kernel(const Small
                     }
                 }
             }
+        }
+    };
+    auto hidden_rows_out = [&](const float *srcl) {  // after the barrier that follows finish_hidden(last = true)
+        if (!(p.n_hout_tiles && hout_rows)) return;
+        const int width = 32 * p.n_hout_tiles;
+        for (int i = tid; i < width * 8; i += NT) {
+            const int f = i >> 3, quad = i & 7;
+            if (p.otab[f].out_feat < 0) continue;  // (padding rows of the last tile)
+            const f32x4 v = *reinterpret_cast<const f32x4 *>(srcl + f * 32 + 4 * quad);
+            *reinterpret_cast<f32x4 *>(otab_base[hslot] + f * otab_base[kMaxOutputs + hslot] + (n0 + 4 * quad) * 4) = v;
         }
     };
 
@@ -1334,6 +1359,7 @@ __global__ __launch_bounds__(kSmallWaves * 64) void mlp_small_kernel(const Small
     float *hin = hA, *hout = hB;
     finish_hidden(hin, p.n_hidden == 1);
     __syncthreads();
+    if (p.n_hidden == 1) hidden_rows_out(hin);
     SM_STAMP(4);
     // ---- hidden layers ----
     for (int l = 1; l < p.n_hidden; ++l) {
@@ -1341,19 +1367,25 @@ __global__ __launch_bounds__(kSmallWaves * 64) void mlp_small_kernel(const Small
         contract(hin, Wp / 2);
         finish_hidden(hout, l == p.n_hidden - 1);
         __syncthreads();
+        if (l == p.n_hidden - 1) hidden_rows_out(hout);
         float *tmp = hin; hin = hout; hout = tmp;
     }
     // ---- output layer: 32-feature tiles dealt over the waves; per-value epilogue ----
     const __amdgpu_buffer_rsrc_t wo_rsrc = __builtin_amdgcn_make_buffer_rsrc(const_cast<float *>(p.wo), 0, Wp * p.Fp * 4, 0x00020000);
     const int lane_wo = (half * p.Fp + col) * 4;
     const int n_pairs_o = Wp / 2;
-    for (int t = wave_u; t < p.n_otiles; t += NW) {
+    // One output tile only (recurrent cells' 4 outputs, the dense-local models' 2): the contraction index is split over
+    // the waves instead -- every wave a slice of the k-pairs, the partial tiles summed through LDS -- or seven waves would
+    // watch one work through the whole contraction (a fifth of a cell launch).
+    const bool ksplit = p.n_otiles == 1 && n_pairs_o % (NW * U) == 0;
+    const int pairs_lo = ksplit ? wave_u * (n_pairs_o / NW) : 0, pairs_hi = ksplit ? pairs_lo + n_pairs_o / NW : n_pairs_o;
+    for (int t = ksplit ? 0 : wave_u; t < p.n_otiles; t += NW) {
         f32x16 y;
         float c0[U], c1[U];
         auto load_o = [&](float (&a)[U], float (&b)[U], int p0) {
 #pragma unroll
             for (int u = 0; u < U; ++u) {
-                const int pr = (p0 + u < n_pairs_o) ? p0 + u : n_pairs_o - 1;
+                const int pr = (p0 + u < pairs_hi) ? p0 + u : pairs_hi - 1;
                 b[u] = (hin + 64 * pr)[lane_b];
                 a[u] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(wo_rsrc, lane_wo, (2 * pr * p.Fp + 32 * t) * 4, 0));
             }
@@ -1362,25 +1394,35 @@ __global__ __launch_bounds__(kSmallWaves * 64) void mlp_small_kernel(const Small
 #pragma unroll
             for (int u = 0; u < U; ++u) y = __builtin_amdgcn_mfma_f32_32x32x2f32(a[u], b[u], y, 0, 0, 0);
         };
-        load_o(c0, b0, 0);
+        load_o(c0, b0, pairs_lo);
         // this tile's table entries and biases travel under its MFMAs
         int of_[16], res_[16];
 #pragma unroll
         for (int r = 0; r < 16; ++r) {
             const int f = 32 * t + rho(r) + 4 * half;
-            y[r] = p.bo[f];
+            y[r] = (ksplit && wave_u != 0) ? 0.f : p.bo[f];
             of_[r] = p.otab[32 * p.n_hout_tiles + f].out_feat;
             res_[r] = p.otab[32 * p.n_hout_tiles + f].res;
         }
-        for (int p0 = 0; p0 < n_pairs_o; p0 += 2 * U) {
+        for (int p0 = pairs_lo; p0 < pairs_hi; p0 += 2 * U) {
             load_o(c1, b1, p0 + U);
             __builtin_amdgcn_sched_barrier(0);
             mfma_o(c0, b0);
             __builtin_amdgcn_sched_barrier(0);
             load_o(c0, b0, p0 + 2 * U);
             __builtin_amdgcn_sched_barrier(0);
-            mfma_o(c1, b1);
+            if (p0 + U < pairs_hi) mfma_o(c1, b1);
             __builtin_amdgcn_sched_barrier(0);
+        }
+        if (ksplit) {  // partial tiles -> LDS (the input staging buffers are free by now), summed by wave 0 in wave order
+            float *part = xs + wave_u * 1024;
+#pragma unroll
+            for (int r = 0; r < 16; ++r) part[r * 64 + lane] = y[r];
+            __syncthreads();
+            if (wave_u != 0) break;
+#pragma unroll
+            for (int r = 0; r < 16; ++r)
+                for (int w = 1; w < NW; ++w) y[r] += xs[w * 1024 + r * 64 + lane];
         }
         if (n0 + col >= p.n_samples) continue;
 #pragma unroll

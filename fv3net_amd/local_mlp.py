@@ -405,7 +405,7 @@ class RnnModel(_PointModel):
     convolutions, whose rows go straight into the level's slice of the output array.  79 levels x depth launches
     per call, each with ``ncol`` samples; the states ping-pong between two buffers per layer."""
 
-    def __init__(self, spec: RnnSpec, device="cuda", use_graph: bool = False, arithmetic: Optional[str] = None):
+    def __init__(self, spec: RnnSpec, device="cuda", use_graph: Optional[bool] = None, arithmetic: Optional[str] = None):
         """``arithmetic``: as for ``LocalMlpModel`` ("fp32" / opt-in "split-bf16"; default from FV3NET_AMD_EMULATOR_ARITHMETIC)."""
         super().__init__(spec, device)
         self.arithmetic = arithmetic or os.environ.get("FV3NET_AMD_EMULATOR_ARITHMETIC", "fp32")
@@ -413,9 +413,11 @@ class RnnModel(_PointModel):
             raise ValueError(f"arithmetic must be 'fp32' or 'split-bf16', got {self.arithmetic!r}")
         cell_cls = MlpModelSplitBf16 if self.arithmetic == "split-bf16" else MlpModel
         # ``use_graph``: capture the level sweep (nz x depth launches) once per (nz, ncol) into a HIP graph on static
-        # buffers and replay it.  Bit-identical, but measured to gain nothing (9.90 vs 9.93 ms at the 2 304 columns of a
-        # C48 rank): a step there is bound by the ~60 us one 128-sample tile needs on each of the 18 CUs it occupies,
-        # not by launch overhead -- hence off by default.
+        # buffers and replay it (bit-identical).  None = where it pays: the column counts of one model rank, whose launches
+        # are ~20-40 us each on the feature-split kernel -- 158 of them cost more host time than device time when launched
+        # one by one (3.9 ms replayed against 5.3 ms eager at 2 304 columns) -- and not for snapshot-sized calls, where a
+        # launch lasts milliseconds.  (Round 2 measured no gain at all: a step was then bound by the ~60 us one 128-sample
+        # tile needs on each of the 18 CUs it occupied.)
         self._use_graph = use_graph
         self._graphs: Dict[Tuple[int, int], tuple] = {}
         self._cells: List[MlpModel] = []
@@ -437,7 +439,8 @@ class RnnModel(_PointModel):
         spec = self.spec
         arrs, nz, ncol, dev = self._gather(sources)
         c = spec.n_channels
-        if self._use_graph:
+        use_graph = self._use_graph if self._use_graph is not None else (self.arithmetic == "fp32" and ncol < 128 * self._inner_cus())
+        if use_graph:
             x, y = self._sweep_graphed(arrs, nz, ncol, dev)
         else:
             x = self._pack(arrs, nz, ncol, dev).view(len(spec.inputs), nz, ncol)
