@@ -168,7 +168,7 @@ def zc_inputs_device(dev, n, seed):
     }
 
 
-PMC_TRAFFIC_FILES = ("r02_pmc_traffic.json", "r01_pmc_traffic.json")
+PMC_TRAFFIC_FILES = ("r03_pmc_traffic.json", "r02_pmc_traffic.json", "r01_pmc_traffic.json")
 
 
 def pmc_traffic(kernel_key):

@@ -1866,10 +1866,12 @@ extern "C" int fv3hip_mlp_predict(fv3hip_mlp_t m, const void *const *sources, co
     // ---- few samples: the feature-split kernel while the big one would leave CUs without a tile (see mlp_small_kernel) ----
     {
         static const int64_t small_max = [] {
-            const char *e = getenv("FV3HIP_MLP_SMALL_MAX_SAMPLES");  // 0 disables; default: three waves of 32-sample tiles over the CUs
+            const char *e = getenv("FV3HIP_MLP_SMALL_MAX_SAMPLES");  // 0 disables; default: one round of 32-sample workgroups over the CUs
             return e ? (int64_t)atoll(e) : (int64_t)-1;
         }();
-        const int64_t limit = m->small_limit >= 0 ? m->small_limit : small_max >= 0 ? small_max : (int64_t)3 * 32 * m->n_cu;
+        // (measured, profiles/r03_bench.json: a 32-sample workgroup takes 0.5-0.7 of the time of a 128-sample tile of the
+        // big kernel, so a second round of workgroups -- 9 216 columns on 256 CUs -- already loses to the big kernel's one)
+        const int64_t limit = m->small_limit >= 0 ? m->small_limit : small_max >= 0 ? small_max : (int64_t)32 * m->n_cu;
         const size_t lds_small = (size_t)(2 * kSmallChunk * 32 + 2 * m->Wp * 32) * sizeof(float) + (size_t)m->n_ktab * 32 +
                                  (size_t)3 * (kMaxOutputs + kMaxSources) * sizeof(int64_t);
         if (n_samples <= limit && m->n_otiles + m->n_hout_tiles > 0 && lds_small <= 160 * 1024) {

@@ -411,8 +411,8 @@ int fv3hip_mlp_predict(fv3hip_mlp_t model, const void *const *sources, const int
 int64_t fv3hip_mlp_flops_per_sample(fv3hip_mlp_t model);
 /* Calls of at most max_samples samples go to the feature-split kernel for small sample counts (mlp_small_kernel: 32 samples
  * per workgroup, a layer's output features split over its waves -- four times the CUs of the 128-sample tiles, a quarter
- * of their latency; same graph and arithmetic class, contraction in plain feature order).  -1 (default): while the big
- * kernel would leave CUs idle (3 x 32 x CUs samples; FV3HIP_MLP_SMALL_MAX_SAMPLES overrides per process); 0: never.
+ * of their latency; same graph and arithmetic class, contraction in plain feature order).  -1 (default): while one round of
+ * such workgroups covers the call (32 x CUs samples; FV3HIP_MLP_SMALL_MAX_SAMPLES overrides per process); 0: never.
  * Results of the two kernels agree to float32 rounding, not bit for bit: pin the limit where runs on different domain
  * decompositions must reproduce each other exactly (ABI v3). */
 int fv3hip_mlp_set_small_limit(fv3hip_mlp_t model, int64_t max_samples);
