@@ -24,6 +24,8 @@
 //     tests; BASELINE.json north_star asks for 1e-5, and the reference itself is not bit-reproducible across platforms,
 //     external/vcm/tests/test_coarsen_restarts.py:119-123).
 // Columns with NaN or non-monotone pressures go on the worklist and are redone by mappm_fallback_kernel, as before.
+#include <type_traits>
+
 #include "common.h"
 #include "remap.h"
 
@@ -133,7 +135,12 @@ __device__ __forceinline__ float ld(const char *base, unsigned int boff)
 
 // Dynamic LDS of a wave: [target interfaces: kRing rows x 64 lanes, or (TGT) the whole (kn + 1) x 8 table][result ring]
 extern __shared__ float sweep_lds[];
-constexpr int kSweepRing = 16, kSweepOut = 8;
+constexpr int kSweepRing = 16;
+// Result rows held per field (see the result ring below).  8 everywhere but in the instantiation the float64 restart pipelines
+// launch in the fast arithmetic: on BASELINE configs[2]'s iid data (lanes up to 16 rows apart) 12 rows cut its partial
+// stores enough to win 11 % (1.16 -> 1.04 ms) although a wave then holds 14.5 KB of LDS; every other instantiation lost
+// (occupancy, or the modulo by 12), 16 rows lost everywhere.
+template <typename Tin, int NF, bool FAST> constexpr int sweep_out_rows() { return (sizeof(Tin) == 8 && NF == 4 && FAST) ? 12 : 8; }
 
 template <typename Tin, int NV, int W, bool FAST, bool TGT>
 __global__ __launch_bounds__(64) void mappm_sweep_kernel(const SweepArgs a)
@@ -199,11 +206,13 @@ __global__ __launch_bounds__(64) void mappm_sweep_kernel(const SweepArgs a)
     // (z, x, y, w), q(kk-1..kk+1) and dc(kk-1).  The pressure-only terms are formed once for all fields; d4c and its
     // reciprocal are next level's d4b.
     float d4b = d0 + dp1;  // d4(2) = dp(1) + dp(2): becomes d4(kk) of the first reconstructed level below
-    auto level = [&](float z, float x, float y, float w, float d4b_, const Den<FAST> r4b, const V *qa, const V *qb,
-                     const V *qc, const V *dca, V *dcb, V *alb, float &d4c_out, Den<FAST> &r4c_out) {
+    // (`fast_c`: the arithmetic of this call -- the loop's own mode, or exact for the prologue, see there)
+    auto level = [&](auto fast_c, float z, float x, float y, float w, float d4b_, const auto r4b, const V *qa, const V *qb,
+                     const V *qc, const V *dca, V *dcb, V *alb, float &d4c_out, auto &r4c_out) {
+        constexpr bool FASTL = decltype(fast_c)::value;
         const float d4a = z + x, d4c = y + w;
-        const Den<FAST> r4c(d4c);
-        if constexpr (FAST) {
+        const Den<FASTL> r4c(d4c);
+        if constexpr (FASTL) {
             // everything that multiplies a field difference is folded into pressure-only factors first:
             //   df2 = k1 (qc - qb) + k2 (qb - qa),   al = qa + c1f h + m2 dc(k-1) - m1 dc(k),   c1f = (qb - qa) xr
             const float yr = y * __builtin_amdgcn_rcpf(d4b_ + w);
@@ -228,10 +237,10 @@ __global__ __launch_bounds__(64) void mappm_sweep_kernel(const SweepArgs a)
         } else {
         const float c1 = r4c.under(x + 0.5f * y);          // (dp(k-1) + 0.5 dp(k)) / d4(k+1)
         const float c2 = r4b.under(w + 0.5f * y);          // (dp(k+1) + 0.5 dp(k)) / d4(k)
-        const Den<FAST> r3p(d4b_ + w);                     // d4(k) + dp(k+1)
-        const float a1 = Den<FAST>(d4b_ + x).under(d4a);   // d4(k-1) / (d4(k) + dp(k-1))
-        const float a2 = Den<FAST>(d4b_ + y).under(d4c);   // d4(k+1) / (d4(k) + dp(k))
-        const float g = Den<FAST>(d4a + d4c).under(2.f);   // 2 / (d4(k-1) + d4(k+1))
+        const Den<FASTL> r3p(d4b_ + w);                     // d4(k) + dp(k+1)
+        const float a1 = Den<FASTL>(d4b_ + x).under(d4a);   // d4(k-1) / (d4(k) + dp(k-1))
+        const float a2 = Den<FASTL>(d4b_ + y).under(d4c);   // d4(k+1) / (d4(k) + dp(k))
+        const float g = Den<FASTL>(d4a + d4c).under(2.f);   // 2 / (d4(k-1) + d4(k+1))
         const float a12 = a1 - a2, xa1 = x * a1;
 #pragma unroll
         for (int v = 0; v < NV; ++v) {
@@ -247,15 +256,19 @@ __global__ __launch_bounds__(64) void mappm_sweep_kernel(const SweepArgs a)
     };
 
     // ---- prologue: dc(2), dc(3), al(3), then the top boundary (mappm.f90:689-725) ----
+    // Once per column, and in EXACT arithmetic in both modes: the top boundary clamps al(2) between q(1) and q(2), and a
+    // clamp that lands exactly on q(1) makes dm(1) = 0 -- the limiter's discontinuous branch.  Left to the fast arithmetic,
+    // an ulp decided it differently from the reference on one level in 3e8 (found at C384 with a third of configs[2]'s
+    // spread: 24.7 on values of +-1000, inside the source layers' bounds, but avoidable here for a few divisions per column).
     V al0[NV], al1[NV], al2[NV], dc0[NV], dc1[NV], dc2[NV], ar_km[NV];
     float d4c = dp1 + dp2;  // d4(3)
-    Den<FAST> r4c(d4c);
+    Den<false> r4c(d4c);
     {
         // dc(2): the dc part of a level with (x, y, w) = (dp(1), dp(2), dp(3)); its al is not used
-        const Den<FAST> r4b(d4b);
+        const Den<false> r4b(d4b);
         const float c1 = r4c.under(d0 + 0.5f * dp1);
         const float c2 = r4b.under(dp2 + 0.5f * dp1);
-        const Den<FAST> r3p(d4b + dp2);
+        const Den<false> r3p(d4b + dp2);
 #pragma unroll
         for (int v = 0; v < NV; ++v) {
             const V df2 = r3p.under(dp1 * (c1 * (qp2[v] - qp1[v]) + c2 * (qp1[v] - q0[v])));
@@ -265,11 +278,11 @@ __global__ __launch_bounds__(64) void mappm_sweep_kernel(const SweepArgs a)
     {
         V dc_3[NV], al_3[NV];
         float d4n;
-        Den<FAST> r4n(1.f);
-        level(d0, dp1, dp2, dp3, d4c, r4c, qp1, qp2, qp3, dc1, dc_3, al_3, d4n, r4n);  // kk = 3 (recomputed by the loop's L = 1)
+        Den<false> r4n(1.f);
+        level(std::false_type{}, d0, dp1, dp2, dp3, d4c, r4c, qp1, qp2, qp3, dc1, dc_3, al_3, d4n, r4n);  // kk = 3 (recomputed by the loop's L = 1)
         const float d1 = d0, d2 = dp1;
-        const Den<FAST> r12(d1 + d2);
-        const Den<FAST> rcub(d2 * (2.f * d2 * d2 + d1 * (d2 + 3.f * d1)));
+        const Den<false> r12(d1 + d2);
+        const Den<false> rcub(d2 * (2.f * d2 * d2 + d1 * (d2 + 3.f * d1)));
         const float poly = d2 * (5.f * d1 + d2) - 3.f * d1 * d1, d2p = d2 + 3.f * d1, d1sq = d1 * d1;
 #pragma unroll
         for (int v = 0; v < NV; ++v) {
@@ -298,9 +311,9 @@ __global__ __launch_bounds__(64) void mappm_sweep_kernel(const SweepArgs a)
             ar_km[v] = zero;
         }
     }
-    // the loop's first level is kk = 3: its d4(kk) = d4(3), already in (d4c, r4c)
+    // the loop's first level is kk = 3: its d4(kk) = d4(3)
     d4b = d4c;
-    Den<FAST> r4b = r4c;
+    Den<FAST> r4b(d4b);
 
     // ---- per-lane target cursor ----
     // A lane consumes the target interfaces at its own pace.  Loading pe2(k+1) where it is needed would put a memory
@@ -376,8 +389,11 @@ __global__ __launch_bounds__(64) void mappm_sweep_kernel(const SweepArgs a)
     float dpsum = 0.f;
 #pragma unroll
     for (int v = 0; v < NV; ++v) qsum[v] = v_splat(q0[v], 0.f);
+    constexpr int kOut = sweep_out_rows<Tin, NF, FAST>();  // rows of the result ring (below)
+    int oslot = 0, fslot = 0;  // ring slot of this lane's row k - 1 / of the wave's row rf, counted along (kOut need not be a power of two)
     auto advance = [&]() {
         ++k;
+        oslot = (oslot + 1 == kOut) ? 0 : oslot + 1;
         if (!(p2k1 >= p2k)) bad = true;  // also catches NaN
         p2k = p2k1;
         p2k1 = PE2(k <= kn ? k : kn);
@@ -394,14 +410,13 @@ __global__ __launch_bounds__(64) void mappm_sweep_kernel(const SweepArgs a)
     // that runs kOut rows ahead of the slowest one writes its own oldest row out first.  Ill-formed lanes count as past
     // every row; whatever the flush writes for them is overwritten by the fallback pass.  (kOut = 16 and 32 were slower:
     // the ring's LDS footprint costs occupancy.)
-    constexpr int kOut = kSweepOut;
     float *oring = sweep_lds + (TGT ? (kn + 1) * 8 : kRing * 64) + lane;
     int rf = 0;  // uniform: rows [0, rf) are in memory for every lane
     int rl = 0;  // per lane (>= rf where it matters)
     V out_v[NV];
     auto OUT = [&](int v, V x) { out_v[v] = x; };
     auto out_end = [&]() {  // after the OUTs of target k (before advance())
-        const int r = k - 1, slot = r & (kOut - 1);
+        const int r = k - 1, slot = oslot;
         if (r - kOut >= (rl > rf ? rl : rf)) {  // the slot still holds this lane's row r - kOut: write it out now
 #pragma unroll
             for (int f = 0; f < NF; ++f)
@@ -420,9 +435,10 @@ __global__ __launch_bounds__(64) void mappm_sweep_kernel(const SweepArgs a)
 #pragma unroll
                 for (int f = 0; f < NF; ++f)
                     *reinterpret_cast<float *>(q2_b[f] + (size_t)rf * row_out + (unsigned int)lane * 4u) =
-                        oring[(f * kOut + (rf & (kOut - 1))) * 64];
+                        oring[(f * kOut + fslot) * 64];
             }
             ++rf;
+            fslot = (fslot + 1 == kOut) ? 0 : fslot + 1;
         }
     };
     if (!(p2k1 >= p2k)) bad = true;
@@ -568,7 +584,7 @@ __global__ __launch_bounds__(64) void mappm_sweep_kernel(const SweepArgs a)
         if (kk <= km1) {
             float d4n;
             Den<FAST> r4n(1.f);
-            level(d0, dp1, dp2, dp3, d4b, r4b, qp1, qp2, qp3, dc1, dc2, al2, d4n, r4n);
+            level(std::integral_constant<bool, FAST>{}, d0, dp1, dp2, dp3, d4b, r4b, qp1, qp2, qp3, dc1, dc2, al2, d4n, r4n);
             d4b = d4n;
             r4b = r4n;
         } else if (kk == km) {
@@ -658,8 +674,9 @@ __global__ __launch_bounds__(64) void mappm_sweep_kernel(const SweepArgs a)
 template <typename Tin, int NV, int W>
 void launch_sweep2(const SweepArgs &a, int64_t n_waves, bool fast, bool tgt, hipStream_t st)
 {
-    const size_t lds = (size_t)((tgt ? (a.kn + 1) * 8 : kSweepRing * 64) + NV * W * kSweepOut * 64) * sizeof(float);
-#define SWEEP_(F, T) hipLaunchKernelGGL((mappm_sweep_kernel<Tin, NV, W, F, T>), dim3((unsigned)n_waves), dim3(64), lds, st, a)
+#define SWEEP_(F, T)                                                                                                                \
+    hipLaunchKernelGGL((mappm_sweep_kernel<Tin, NV, W, F, T>), dim3((unsigned)n_waves), dim3(64),                                   \
+                       (size_t)((tgt ? (a.kn + 1) * 8 : kSweepRing * 64) + NV * W * sweep_out_rows<Tin, NV * W, F>() * 64) * sizeof(float), st, a)
     if (fast) {
         if (tgt) SWEEP_(true, true); else SWEEP_(true, false);
     } else {
