@@ -128,6 +128,12 @@ SIGNATURES = {
                                            c_int64, c_void_p, c_void_p]),
     "fv3hip_level_scale": (c_int, [c_void_p, c_int, c_void_p, c_int64, c_int, c_int64, c_void_p, c_void_p]),
     "fv3hip_member_reduce": (c_int, [c_void_p, c_int, c_int, c_int, c_int64, c_void_p, c_void_p]),
+    "fv3hip_tendency_to_flux": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_int64, c_int, c_int64, c_int, c_int,
+                                        c_void_p, c_void_p, c_void_p]),
+    "fv3hip_flux_to_tendency": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_int64, c_int, c_int64, c_void_p, c_void_p]),
+    "fv3hip_minmax_score": (c_int, [c_void_p, c_int, c_int64, c_int64, c_int, c_void_p, c_void_p, c_int64, c_int, c_int, c_void_p,
+                                    c_void_p, c_void_p, c_void_p]),
+    "fv3hip_ocsvm_score": (c_int, [c_void_p, c_int, c_int64, c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_double, c_void_p, c_void_p]),
     "fv3hip_local_pack": (c_int, [c_void_p, c_int, c_int, c_int, c_double, c_void_p, c_void_p, c_int, c_int64, c_void_p, c_void_p]),
     "fv3hip_local_unpack": (c_int, [c_void_p, c_int64, c_void_p, c_void_p, c_void_p, c_int, c_void_p, c_void_p, c_void_p, c_int,
                                     c_double, c_void_p, c_int, c_int, c_double, c_double, c_double, c_double, c_int, c_int64,

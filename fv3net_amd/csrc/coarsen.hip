@@ -839,6 +839,12 @@ __global__ void ew_kernel(int op, const T *__restrict__ a, const T *__restrict__
             case FV3HIP_EW_EXP: v = exp(x); break;
             case FV3HIP_EW_RELU_THRESHOLD_S: v = (x > s) ? x : (T)0; break;    // tf.keras.activations.relu(a, threshold=s)
             case FV3HIP_EW_BELOW_S: v = (x < s) ? x : (T)0; break;             // tf.cast(a < s, a.dtype) * a
+            case FV3HIP_EW_DIV_S: v = x / s; break;
+            case FV3HIP_EW_INCLOUD_TO_GRIDCELL: {  // vcm/calc/clouds.py:40-66 (a = cloud fraction, b = in-cloud condensate; CLIMIT1 = 1e-3, CLIMIT2 = 5e-2)
+                const T rectified = (x > (T)5.0e-2) ? x : (T)5.0e-2;
+                v = (x <= (T)1.0e-3) ? y : y * rectified;
+                break;
+            }
             case FV3HIP_EW_MUL_S: v = s * x; break;                            // scalar * a           // blend(weights a, pressure-level b, model-level c)
             default: v = x;
         }

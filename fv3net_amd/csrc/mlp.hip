@@ -32,6 +32,7 @@
 #include <cstddef>
 #include <cstdlib>
 #include <cstring>
+#include <algorithm>
 #include <type_traits>
 #include <cfloat>
 #include <vector>
@@ -1451,6 +1452,141 @@ __global__ __launch_bounds__(kSmallWaves * 64) void mlp_small_kernel(const Small
     SM_STAMP(5);
 }
 
+// ---------------------------------------------------------------------------------------------
+// Layered path: networks the two fused kernels do not hold -- no hidden layer at all (the reference's "linear"
+// architecture, fv3fit/emulation/layers/architecture.py:285-302 with MLPBlock(depth=0)), hidden layers wider than 256,
+// more inputs than the per-feature LDS table takes.  One launch per step, activations [feature][sample] float32 in an
+// HBM scratch the model keeps: gather (the same input table: source arrays of any stride and dtype, logarithm, centre),
+// one dense kernel per layer (the same float32 MFMA, bias as the initial accumulator, folded scales), scatter (the same
+// output table: limits, masks, residual outputs).  Not a fast path -- each layer's activations make a round trip through
+// HBM -- it exists so that every network the reference's configs can describe runs; the column counts and widths the
+// benchmarks quote stay on the fused kernels.
+// ---------------------------------------------------------------------------------------------
+struct LayeredIo {
+    const KEntry *ktab;
+    const OEntry *otab;
+    float *x;           // scratch [rows][np]
+    int64_t np, n0, n_samples;  // padded slab width; first sample of the slab; samples of the call
+    int n_rows, out64, has_limits;
+    const void *src[kMaxSources];
+    int64_t src_fs[kMaxSources];
+    int64_t src_ss[kMaxSources];
+    void *out[kMaxOutputs];
+    int64_t out_fs[kMaxOutputs];
+    int64_t out_ss[kMaxOutputs];
+};
+
+// grid (np / 256, n_ktab): row k of the normalised input matrix for the slab's samples (a ragged end repeats the last sample)
+template <bool SRC64>
+__global__ __launch_bounds__(256) void layered_gather_kernel(const LayeredIo p)
+{
+    using Raw = typename std::conditional<SRC64, double, float>::type;
+    const int k = blockIdx.y;
+    const int64_t j = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    const KEntry e = p.ktab[k];
+    float v = 0.f;
+    if (e.src >= 0) {
+        int64_t ns = p.n0 + j;
+        if (ns >= p.n_samples) ns = p.n_samples - 1;
+        const Raw *row = static_cast<const Raw *>(p.src[e.src]) + (int64_t)e.feat * p.src_fs[e.src];
+        v = (float)row[ns * p.src_ss[e.src]];
+        if (e.transform == FV3HIP_TRANSFORM_LOG) v = logf(v < e.eps ? e.eps : v);
+        v = v - e.center;  // (1 / std lives in the first layer's weights)
+    }
+    p.x[(int64_t)k * p.np + j] = v;
+}
+
+struct LayeredDense {
+    const float *w;  // [kp][fp]
+    const float *b;  // [fp]
+    const float *x;  // [kp][np]
+    float *y;        // [fp][np]
+    int kp, fp, relu;
+    int64_t np;
+};
+
+// grid (np / 256, fp / 64), 4 waves: a wave owns 64 features x 64 samples (2 x 2 MFMA tiles); operands straight from
+// global memory (rows of 128 B per half wave), requested one batch of k-pairs ahead of the MFMAs that consume them
+__global__ __launch_bounds__(256) void layered_dense_kernel(const LayeredDense p)
+{
+    constexpr int U = 4;
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, half = lane >> 5, col = lane & 31;
+    const int64_t s0 = (int64_t)blockIdx.x * 256 + wave * 64;
+    const int f0 = blockIdx.y * 64;
+    const int n_pairs = p.kp / 2;  // a multiple of 2 U (kp is a multiple of 32)
+    const float *wl = p.w + (int64_t)half * p.fp + f0 + col;
+    const float *xl = p.x + (int64_t)half * p.np + s0 + col;
+    f32x16 acc[2][2];
+#pragma unroll
+    for (int ft = 0; ft < 2; ++ft)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) acc[ft][0][r] = acc[ft][1][r] = p.b[f0 + 32 * ft + rho(r) + 4 * half];
+    float a0[2][U], b0[2][U], a1[2][U], b1[2][U];
+    auto load = [&](float (&a)[2][U], float (&b)[2][U], int p0) {
+#pragma unroll
+        for (int u = 0; u < U; ++u) {
+            const int pr = (p0 + u < n_pairs) ? p0 + u : n_pairs - 1;
+            a[0][u] = wl[(int64_t)2 * pr * p.fp];
+            a[1][u] = wl[(int64_t)2 * pr * p.fp + 32];
+            b[0][u] = xl[(int64_t)2 * pr * p.np];
+            b[1][u] = xl[(int64_t)2 * pr * p.np + 32];
+        }
+    };
+    auto mfma = [&](const float (&a)[2][U], const float (&b)[2][U]) {
+#pragma unroll
+        for (int u = 0; u < U; ++u)
+#pragma unroll
+            for (int ft = 0; ft < 2; ++ft)
+#pragma unroll
+                for (int st = 0; st < 2; ++st) acc[ft][st] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[ft][u], b[st][u], acc[ft][st], 0, 0, 0);
+    };
+    load(a0, b0, 0);
+    for (int p0 = 0; p0 < n_pairs; p0 += 2 * U) {
+        load(a1, b1, p0 + U);
+        mfma(a0, b0);
+        load(a0, b0, p0 + 2 * U);
+        mfma(a1, b1);
+    }
+#pragma unroll
+    for (int ft = 0; ft < 2; ++ft)
+#pragma unroll
+        for (int st = 0; st < 2; ++st)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                float v = acc[ft][st][r];
+                if (p.relu) v = v < 0.f ? 0.f : v;  // (a NaN stays a NaN)
+                p.y[(int64_t)(f0 + 32 * ft + rho(r) + 4 * half) * p.np + s0 + 32 * st + col] = v;
+            }
+}
+
+// grid (np / 256, F): output feature f of the slab's samples through the output table (mlp_small_kernel's epilogue)
+template <bool SRC64>
+__global__ __launch_bounds__(256) void layered_scatter_kernel(const LayeredIo p)
+{
+    using Raw = typename std::conditional<SRC64, double, float>::type;
+    const int f = blockIdx.y;
+    const int64_t j = (int64_t)blockIdx.x * 256 + threadIdx.x, ns = p.n0 + j;
+    const OEntry e = p.otab[f];
+    if (e.out_feat < 0 || ns >= p.n_samples) return;
+    float x = p.x[(int64_t)f * p.np + j];  // (the physical value: scale and centre live in the output weights and bias)
+    if (p.has_limits) {
+        if (x < e.lo) x = e.lo;
+        if (x >= e.hi) x = e.hi;
+        x = x * e.mask;
+    }
+    const int slot = e.out_feat >> 20, q = e.out_feat & 0xFFFFF;
+    const int64_t at = (int64_t)q * p.out_fs[slot] + ns * p.out_ss[slot];
+    if (p.out64) static_cast<double *>(p.out[slot])[at] = (double)x;
+    else static_cast<float *>(p.out[slot])[at] = x;
+    if (e.res >= 0) {  // residual output: after = before + value
+        const int rslot = e.res >> 8, rs = e.res & 0xFF;
+        const float before = (float)static_cast<const Raw *>(p.src[rs])[(int64_t)q * p.src_fs[rs] + ns * p.src_ss[rs]];
+        const int64_t rat = (int64_t)q * p.out_fs[rslot] + ns * p.out_ss[rslot];
+        if (p.out64) static_cast<double *>(p.out[rslot])[rat] = (double)(before + x);
+        else static_cast<float *>(p.out[rslot])[rat] = before + x;
+    }
+}
+
 }  // namespace
 }  // namespace fv3hip
 
@@ -1476,6 +1612,11 @@ struct fv3hip_mlp {
     void *d_w1 = nullptr, *d_wh = nullptr, *d_wo = nullptr, *d_bh = nullptr, *d_bo = nullptr;
     int Wp = 0, Fp = 0;
     int64_t small_limit = -1;  // fv3hip_mlp_set_small_limit: -1 = default rule, 0 = never, n = calls of at most n samples
+    // layered path (networks the fused kernels do not hold): d_w1 / d_wh / d_wo / d_bh / d_bo are its matrices
+    // ([n_ktab][Wp], [Wp][Wp] each, [Wp or n_ktab][Fp]; Wp and Fp multiples of 64), d_scr its two activation buffers
+    int layered = 0, relu = 1;
+    void *d_scr[2] = {nullptr, nullptr};
+    size_t scr_bytes = 0;
     int n_cu = 256;
     size_t lds_bytes = 0;
     char last_variant[160] = {0};  // what the last fv3hip_mlp_predict launched (fv3hip_mlp_last_variant)
@@ -1505,6 +1646,230 @@ int upload(const std::vector<T> &v, void **dptr)
     return FV3HIP_OK;
 }
 
+// ---- the tables both kernel families and the layered path read ----
+struct InputTable {
+    std::vector<KEntry> ktab;
+    std::vector<int> perm;     // table row -> original input feature, -1 = padding
+    int n_log_padded = 0;      // rows at the head of the table that take the logarithm (padded to whole 32-row chunks if room)
+    bool eps_normal = true;    // every logarithm's floor is a normal number
+};
+
+// Network input k' is original input feature perm[k']: the log-transformed features come first (any order of the
+// contraction index is the same dense layer), so that whole 32-row chunks are either with or without the transform.
+void build_input_table(const fv3hip_mlp_desc_t *d, int K, int n_ktab, InputTable &t)
+{
+    t.ktab.assign(n_ktab, KEntry{-1, 0, 0.f, 1.f, 0, 0.f, 0, 0});
+    t.perm.clear();
+    t.perm.reserve(n_ktab);
+    std::vector<KEntry> orig(K);
+    int k = 0;
+    for (int i = 0; i < d->n_inputs; ++i)
+        for (int f = 0; f < d->in_nfeat[i]; ++f, ++k) {
+            KEntry &e = orig[k];
+            e = KEntry{-1, 0, 0.f, 1.f, 0, 0.f, 0, 0};
+            e.src = d->in_source[i];
+            e.feat = d->in_feat_start[i] + f;
+            e.center = d->in_center ? d->in_center[k] : 0.f;
+            e.scale = d->in_scale ? (float)(1.0 / (double)d->in_scale[k]) : 1.f;  // reciprocal
+            e.transform = d->in_transform ? d->in_transform[i] : 0;
+            e.eps = d->in_eps ? d->in_eps[i] : 0.f;
+        }
+    for (int k2 = 0; k2 < K; ++k2)
+        if (orig[k2].transform == FV3HIP_TRANSFORM_LOG) t.perm.push_back(k2);
+    const int n_log = (int)t.perm.size();
+    // if the chunk count allows, pad the log block to whole chunks (entries -1: zero weight rows reading a constant,
+    // eps = 1 so that the logarithm is of a normal number) -- then no chunk mixes both kinds and every log chunk takes
+    // the fast path
+    const int n_pad = (32 - n_log % 32) % 32;
+    if (n_log > 0 && n_log + n_pad + (K - n_log) <= n_ktab)
+        for (int i = 0; i < n_pad; ++i) t.perm.push_back(-1);
+    t.n_log_padded = (int)t.perm.size();
+    for (int k2 = 0; k2 < K; ++k2)
+        if (orig[k2].transform != FV3HIP_TRANSFORM_LOG) t.perm.push_back(k2);
+    for (size_t k2 = 0; k2 < t.perm.size(); ++k2) {
+        if (t.perm[k2] >= 0) {
+            t.ktab[k2] = orig[t.perm[k2]];
+        } else {
+            t.ktab[k2].transform = FV3HIP_TRANSFORM_LOG;
+            t.ktab[k2].eps = 1.f;
+        }
+    }
+    t.eps_normal = true;
+    for (int k2 = 0; k2 < t.n_log_padded; ++k2) t.eps_normal = t.eps_normal && t.ktab[k2].eps >= FLT_MIN;
+}
+
+// Rows [0, n_hidden_rows): the last hidden layer's features (hidden-output models), stored to the slot after the outputs
+// and the residual outputs; rows first_out + f: output feature f.
+void build_output_table(const fv3hip_mlp_desc_t *d, int n_otab, int first_out, int n_hidden_rows, std::vector<OEntry> &otab)
+{
+    otab.assign(n_otab, OEntry{1.f, 0.f, -INFINITY, INFINITY, 1.f, -1, -1, 0});
+    for (int q = 0; q < n_hidden_rows; ++q) otab[q].out_feat = ((d->n_outputs + d->n_residual) << 20) | q;
+    int f = 0;
+    for (int j = 0; j < d->n_outputs; ++j) {
+        int res = -1;
+        for (int r = 0; r < d->n_residual; ++r)
+            if (d->res_output[r] == j) res = ((d->n_outputs + r) << 8) | d->res_source[r];
+        for (int q = 0; q < d->out_nfeat[j]; ++q, ++f) {
+            OEntry &e = otab[first_out + f];
+            e.scale = d->out_scale ? d->out_scale[f] : 1.f;
+            e.center = d->out_center ? d->out_center[f] : 0.f;
+            e.lo = d->out_min ? d->out_min[f] : -INFINITY;
+            e.hi = d->out_max ? d->out_max[f] : INFINITY;
+            e.mask = d->out_mask ? d->out_mask[f] : 1.f;
+            e.out_feat = (j << 20) | q;
+            e.res = res;
+        }
+    }
+}
+
+}  // namespace
+
+namespace {
+
+inline int round_up(int v, int m) { return (v + m - 1) / m * m; }
+
+int create_layered(const fv3hip_mlp_desc_t *d, int K, fv3hip_mlp_t *out)
+{
+    int F = 0;
+    for (int j = 0; j < d->n_outputs; ++j) {
+        FV3HIP_REQUIRE(d->out_nfeat[j] >= 1 && d->out_nfeat[j] < (1 << 20), "bad out_nfeat[%d]", j);
+        F += d->out_nfeat[j];
+    }
+    for (int r = 0; r < d->n_residual; ++r) {
+        FV3HIP_REQUIRE(d->res_source[r] >= 0 && d->res_source[r] < d->n_sources, "res_source[%d] out of range", r);
+        FV3HIP_REQUIRE(d->res_output[r] >= 0 && d->res_output[r] < d->n_outputs, "res_output[%d] out of range", r);
+    }
+    const int nh = d->n_hidden, width = nh ? d->width : K;
+    FV3HIP_REQUIRE(K < 65536 && F < 65536 && width < 65536, "more than 65 535 features in a layer");
+    fv3hip_mlp *m = new fv3hip_mlp();
+    hipGetDevice(&m->device);
+    hipDeviceProp_t prop;
+    if (hipGetDeviceProperties(&prop, m->device) == hipSuccess) m->n_cu = prop.multiProcessorCount;
+    m->layered = 1;
+    m->relu = d->hidden_activation == FV3HIP_ACT_RELU;
+    m->n_sources = d->n_sources;
+    m->n_inputs = d->n_inputs;
+    m->K = K;
+    m->width = width;
+    m->n_hidden = nh;
+    m->n_outputs = d->n_outputs;
+    m->F = F;
+    m->n_residual = d->n_residual;
+    m->has_limits = (d->out_min || d->out_max || d->out_mask) ? 1 : 0;
+    m->n_ktab = round_up(K, 32);
+    m->Wp = nh ? round_up(width, 64) : 0;
+    m->Fp = round_up(F, 64);
+    m->n_otab = m->Fp;
+    m->flops = nh ? 2 * ((int64_t)K * width + (int64_t)(nh - 1) * width * width + (int64_t)width * F) : 2 * (int64_t)K * F;
+    InputTable it;
+    build_input_table(d, K, m->n_ktab, it);
+    std::vector<OEntry> otab;
+    build_output_table(d, m->n_otab, 0, 0, otab);
+    const int Wp = m->Wp, Fp = m->Fp, kin_o = nh ? Wp : m->n_ktab;
+    auto oscale = [&](int f) { return d->out_scale ? d->out_scale[f] : 1.f; };
+    std::vector<float> w1((size_t)(nh ? m->n_ktab * (size_t)Wp : 0), 0.f), wh((size_t)(nh > 1 ? nh - 1 : 0) * Wp * Wp, 0.f),
+        wo((size_t)kin_o * Fp, 0.f), bh((size_t)nh * Wp, 0.f), bo((size_t)Fp, 0.f);
+    for (size_t k = 0; k < it.perm.size(); ++k) {
+        if (it.perm[k] < 0) continue;
+        if (nh)
+            for (int f = 0; f < width; ++f) w1[k * Wp + f] = d->hidden_kernels[0][(size_t)it.perm[k] * width + f] * it.ktab[k].scale;
+        else  // the only layer carries both foldings: 1 / std of its input row, the scale of its output column
+            for (int f = 0; f < F; ++f)
+                wo[k * Fp + f] = (float)((double)d->out_kernel[(size_t)it.perm[k] * F + f] * (double)it.ktab[k].scale * (double)oscale(f));
+    }
+    for (int l = 1; l < nh; ++l)
+        for (int k = 0; k < width; ++k)
+            for (int f = 0; f < width; ++f) wh[((size_t)(l - 1) * Wp + k) * Wp + f] = d->hidden_kernels[l][(size_t)k * width + f];
+    for (int l = 0; l < nh; ++l)
+        for (int f = 0; f < width; ++f) bh[(size_t)l * Wp + f] = d->hidden_biases[l][f];
+    if (nh)
+        for (int k = 0; k < width; ++k)
+            for (int f = 0; f < F; ++f) wo[(size_t)k * Fp + f] = d->out_kernel[(size_t)k * F + f] * oscale(f);
+    for (int f = 0; f < F; ++f)
+        bo[f] = (float)((double)d->out_bias[f] * oscale(f) + (d->out_center ? d->out_center[f] : 0.f));
+    int rc;
+    if ((rc = upload(w1, &m->d_w1)) || (rc = upload(wh, &m->d_wh)) || (rc = upload(wo, &m->d_wo)) || (rc = upload(bh, &m->d_bh)) ||
+        (rc = upload(bo, &m->d_bo)) || (rc = upload(it.ktab, &m->d_ktab)) || (rc = upload(otab, &m->d_otab))) {
+        fv3hip_mlp_destroy(m);
+        return rc;
+    }
+    *out = m;
+    return FV3HIP_OK;
+}
+
+// One slab of at most kLayeredSlab samples at a time through gather -> layers -> scatter (the scratch stays bounded:
+// 2 x rows x slab x 4 bytes, whatever the call's size); all on the caller's stream, so slabs follow each other.
+constexpr int64_t kLayeredSlab = 65536;
+
+int predict_layered(fv3hip_mlp *m, const MlpLaunch &lp, bool src64, int out_dtype, int64_t n_samples, hipStream_t st)
+{
+    const int rows = std::max(m->n_ktab, std::max(m->Wp, m->Fp));
+    const int64_t np_max = (std::min(n_samples, kLayeredSlab) + 255) / 256 * 256;
+    const size_t need = (size_t)rows * np_max * sizeof(float);
+    if (m->scr_bytes < need) {  // (grown on demand, like the fused kernels' scratch row: warm up before capturing a graph)
+        for (void *&q : m->d_scr) {
+            if (q) FV3HIP_CHECK_HIP(hipFree(q));
+            q = nullptr;
+        }
+        m->scr_bytes = 0;
+        FV3HIP_CHECK_HIP(hipMalloc(&m->d_scr[0], need));
+        FV3HIP_CHECK_HIP(hipMalloc(&m->d_scr[1], need));
+        m->scr_bytes = need;
+    }
+    LayeredIo io;
+    memset(&io, 0, sizeof(io));
+    io.ktab = static_cast<const KEntry *>(m->d_ktab);
+    io.otab = static_cast<const OEntry *>(m->d_otab);
+    io.n_samples = n_samples;
+    io.out64 = (out_dtype == FV3HIP_F64);
+    io.has_limits = m->has_limits;
+    memcpy(io.src, lp.src, sizeof(io.src));
+    memcpy(io.src_fs, lp.src_fs, sizeof(io.src_fs));
+    memcpy(io.src_ss, lp.src_ss, sizeof(io.src_ss));
+    memcpy(io.out, lp.out, sizeof(io.out));
+    memcpy(io.out_fs, lp.out_fs, sizeof(io.out_fs));
+    memcpy(io.out_ss, lp.out_ss, sizeof(io.out_ss));
+    snprintf(m->last_variant, sizeof(m->last_variant), "layered (gather, %d x layered_dense_kernel, scatter; slabs of %lld samples)",
+             m->n_hidden + 1, (long long)kLayeredSlab);
+    for (int64_t n0 = 0; n0 < n_samples; n0 += kLayeredSlab) {
+        const int64_t np = (std::min(n_samples - n0, kLayeredSlab) + 255) / 256 * 256;
+        float *cur = static_cast<float *>(m->d_scr[0]), *nxt = static_cast<float *>(m->d_scr[1]);
+        io.n0 = n0;
+        io.np = np;
+        io.x = cur;
+        const dim3 gg((unsigned)(np / 256), (unsigned)m->n_ktab);
+        if (src64) hipLaunchKernelGGL(layered_gather_kernel<true>, gg, dim3(256), 0, st, io);
+        else hipLaunchKernelGGL(layered_gather_kernel<false>, gg, dim3(256), 0, st, io);
+        int rc = check_launch("layered_gather_kernel");
+        if (rc) return rc;
+        auto dense = [&](const void *w, const void *b, int kp, int fp, int relu) {
+            LayeredDense dp;
+            dp.w = static_cast<const float *>(w);
+            dp.b = static_cast<const float *>(b);
+            dp.x = cur;
+            dp.y = nxt;
+            dp.kp = kp;
+            dp.fp = fp;
+            dp.relu = relu;
+            dp.np = np;
+            hipLaunchKernelGGL(layered_dense_kernel, dim3((unsigned)(np / 256), (unsigned)(fp / 64)), dim3(256), 0, st, dp);
+            std::swap(cur, nxt);
+            return check_launch("layered_dense_kernel");
+        };
+        for (int l = 0; l < m->n_hidden; ++l) {
+            const float *w = l == 0 ? static_cast<const float *>(m->d_w1) : static_cast<const float *>(m->d_wh) + (size_t)(l - 1) * m->Wp * m->Wp;
+            if ((rc = dense(w, static_cast<const float *>(m->d_bh) + (size_t)l * m->Wp, l == 0 ? m->n_ktab : m->Wp, m->Wp, m->relu))) return rc;
+        }
+        if ((rc = dense(m->d_wo, m->d_bo, m->n_hidden ? m->Wp : m->n_ktab, m->Fp, 0))) return rc;
+        io.x = cur;
+        const dim3 gs((unsigned)(np / 256), (unsigned)m->F);
+        if (src64) hipLaunchKernelGGL(layered_scatter_kernel<true>, gs, dim3(256), 0, st, io);
+        else hipLaunchKernelGGL(layered_scatter_kernel<false>, gs, dim3(256), 0, st, io);
+        if ((rc = check_launch("layered_scatter_kernel"))) return rc;
+    }
+    return FV3HIP_OK;
+}
+
 }  // namespace
 
 extern "C" int fv3hip_mlp_create(const fv3hip_mlp_desc_t *d, fv3hip_mlp_t *out)
@@ -1518,13 +1883,8 @@ extern "C" int fv3hip_mlp_create(const fv3hip_mlp_desc_t *d, fv3hip_mlp_t *out)
     FV3HIP_REQUIRE(d->n_residual >= 0 && d->n_outputs + d->n_residual + hout <= kMaxOutputs,
                    "n_outputs + n_residual (+ the hidden output) must be <= %d", kMaxOutputs);
     FV3HIP_REQUIRE(d->width >= 1, "width must be >= 1");
-    if (d->n_hidden < 1)
-        return fail(FV3HIP_EUNSUPPORTED, "networks without a hidden layer (n_hidden=%d) are not implemented", d->n_hidden);
-    if (d->width > 256)
-        return fail(FV3HIP_EUNSUPPORTED, "hidden width %d > 256 is not implemented by the fused kernel", d->width);
+    FV3HIP_REQUIRE(d->n_hidden >= 0, "negative n_hidden");
     FV3HIP_REQUIRE(d->hidden_activation == FV3HIP_ACT_RELU || d->hidden_activation == FV3HIP_ACT_LINEAR, "unknown activation %d", d->hidden_activation);
-    if (d->hidden_activation != FV3HIP_ACT_RELU)
-        return fail(FV3HIP_EUNSUPPORTED, "only ReLU hidden activations are implemented");
 
     int K = 0;
     for (int i = 0; i < d->n_inputs; ++i) {
@@ -1532,7 +1892,13 @@ extern "C" int fv3hip_mlp_create(const fv3hip_mlp_desc_t *d, fv3hip_mlp_t *out)
         FV3HIP_REQUIRE(d->in_nfeat[i] >= 1 && d->in_feat_start[i] >= 0, "bad feature range for input %d", i);
         K += d->in_nfeat[i];
     }
-    if (K > kMaxK) return fail(FV3HIP_EUNSUPPORTED, "%d network inputs > %d is not implemented", K, kMaxK);
+    // what the fused kernels do not hold goes layer by layer (see layered_dense_kernel)
+    const bool layered = d->n_hidden < 1 || d->width > 256 || K > kMaxK || d->hidden_activation != FV3HIP_ACT_RELU;
+    if (layered) {
+        if (hout) return fail(FV3HIP_EUNSUPPORTED, "hidden-output models need 1+ ReLU hidden layers of width <= 256 and <= %d inputs", kMaxK);
+        FV3HIP_REQUIRE(d->n_hidden == 0 || d->width >= 1, "width must be >= 1");
+        return create_layered(d, K, out);
+    }
     int F = 0;
     for (int j = 0; j < d->n_outputs; ++j) {
         FV3HIP_REQUIRE(d->out_nfeat[j] >= 1 && d->out_nfeat[j] < (1 << 20), "bad out_nfeat[%d]", j);
@@ -1585,52 +1951,12 @@ extern "C" int fv3hip_mlp_create(const fv3hip_mlp_desc_t *d, fv3hip_mlp_t *out)
     const int n_out_chunks = nt_out;
 
     // ---- input table ----
-    // Network input k' is original input feature perm[k']: the log-transformed features come first
-    // (any order of the contraction index is the same dense layer), so that whole layer-1 chunks
-    // are either with or without the transform.
-    std::vector<KEntry> ktab(m->n_ktab);
-    for (auto &e : ktab) e = KEntry{-1, 0, 0.f, 1.f, 0, 0.f, 0, 0};
-    std::vector<int> perm;
-    perm.reserve(m->n_ktab);
-    {
-        std::vector<KEntry> orig(K);
-        int k = 0;
-        for (int i = 0; i < d->n_inputs; ++i)
-            for (int f = 0; f < d->in_nfeat[i]; ++f, ++k) {
-                KEntry &e = orig[k];
-                e = KEntry{-1, 0, 0.f, 1.f, 0, 0.f, 0, 0};
-                e.src = d->in_source[i];
-                e.feat = d->in_feat_start[i] + f;
-                e.center = d->in_center ? d->in_center[k] : 0.f;
-                e.scale = d->in_scale ? (float)(1.0 / (double)d->in_scale[k]) : 1.f;  // reciprocal
-                e.transform = d->in_transform ? d->in_transform[i] : 0;
-                e.eps = d->in_eps ? d->in_eps[i] : 0.f;
-            }
-        for (int k2 = 0; k2 < K; ++k2)
-            if (orig[k2].transform == FV3HIP_TRANSFORM_LOG) perm.push_back(k2);
-        int n_log = (int)perm.size();
-        // if the chunk count allows, pad the log block to whole chunks (entries -1: zero weight rows
-        // reading a constant, eps = 1 so that the logarithm is of a normal number) -- then no chunk
-        // mixes both kinds and every log chunk takes the fast path
-        const int n_pad = (32 - n_log % 32) % 32;
-        if (n_log > 0 && n_log + n_pad + (K - n_log) <= m->n_ktab)
-            for (int i = 0; i < n_pad; ++i) perm.push_back(-1);
-        const int n_log_padded = (int)perm.size();
-        for (int k2 = 0; k2 < K; ++k2)
-            if (orig[k2].transform != FV3HIP_TRANSFORM_LOG) perm.push_back(k2);
-        for (size_t k2 = 0; k2 < perm.size(); ++k2) {
-            if (perm[k2] >= 0) {
-                ktab[k2] = orig[perm[k2]];
-            } else {
-                ktab[k2].transform = FV3HIP_TRANSFORM_LOG;
-                ktab[k2].eps = 1.f;
-            }
-        }
-        m->n_log_chunks = (n_log_padded + 31) / 32;
-        bool eps_normal = true;
-        for (int k2 = 0; k2 < n_log_padded; ++k2) eps_normal = eps_normal && ktab[k2].eps >= FLT_MIN;
-        m->n_logfast_chunks = eps_normal ? n_log_padded / 32 : 0;
-    }
+    InputTable it;
+    build_input_table(d, K, m->n_ktab, it);
+    std::vector<KEntry> &ktab = it.ktab;
+    std::vector<int> &perm = it.perm;
+    m->n_log_chunks = (it.n_log_padded + 31) / 32;
+    m->n_logfast_chunks = it.eps_normal ? it.n_log_padded / 32 : 0;
     // ---- packed weight stream ----
     // (+ one maximal chunk of zero padding: the two-half staging may read past a short last chunk)
     std::vector<float> w((size_t)(n_hid_chunks * CH_H + n_out_chunks * CH_O + (CH_H > CH_O ? CH_H : CH_O)) * 4, 0.f);
@@ -1688,29 +2014,10 @@ extern "C" int fv3hip_mlp_create(const fv3hip_mlp_desc_t *d, fv3hip_mlp_t *out)
                         }
     }
     // ---- output table ----
-    std::vector<OEntry> otab(m->n_otab);
-    for (auto &e : otab) e = OEntry{1.f, 0.f, -INFINITY, INFINITY, 1.f, -1, -1, 0};
     // (hidden-output models: the table starts with the last hidden layer's features, stored to the output slot
     // after the outputs and the residual outputs)
-    for (int q = 0; q < (hout ? width : 0); ++q) otab[q].out_feat = ((d->n_outputs + d->n_residual) << 20) | q;
-    {
-        int f = 0;
-        for (int j = 0; j < d->n_outputs; ++j) {
-            int res = -1;
-            for (int r = 0; r < d->n_residual; ++r)
-                if (d->res_output[r] == j) res = ((d->n_outputs + r) << 8) | d->res_source[r];
-            for (int q = 0; q < d->out_nfeat[j]; ++q, ++f) {
-                OEntry &e = otab[32 * m->n_hout_tiles + f];
-                e.scale = d->out_scale ? d->out_scale[f] : 1.f;
-                e.center = d->out_center ? d->out_center[f] : 0.f;
-                e.lo = d->out_min ? d->out_min[f] : -INFINITY;
-                e.hi = d->out_max ? d->out_max[f] : INFINITY;
-                e.mask = d->out_mask ? d->out_mask[f] : 1.f;
-                e.out_feat = (j << 20) | q;
-                e.res = res;
-            }
-        }
-    }
+    std::vector<OEntry> otab;
+    build_output_table(d, m->n_otab, 32 * m->n_hout_tiles, hout ? width : 0, otab);
     // ---- biases: [layer][tile][reg][half] ----
     std::vector<float> bias(m->n_bias, 0.f);
     for (int l = 0; l < d->n_hidden; ++l)
@@ -1802,7 +2109,7 @@ extern "C" int fv3hip_mlp_destroy(fv3hip_mlp_t m)
     if (m->d_ktab) hipFree(m->d_ktab);
     if (m->d_otab) hipFree(m->d_otab);
     if (m->d_bias) hipFree(m->d_bias);
-    for (void *q : {m->d_w1, m->d_wh, m->d_wo, m->d_bh, m->d_bo})
+    for (void *q : {m->d_w1, m->d_wh, m->d_wo, m->d_bh, m->d_bo, m->d_scr[0], m->d_scr[1]})
         if (q) hipFree(q);
     delete m;
     return FV3HIP_OK;
@@ -1863,6 +2170,7 @@ extern "C" int fv3hip_mlp_predict(fv3hip_mlp_t m, const void *const *sources, co
         lp.out_fs[j] = out_feat_stride[j];
         lp.out_ss[j] = out_sample_stride[j];
     }
+    if (m->layered) return predict_layered(m, lp, src64, out_dtype, n_samples, as_stream(stream));
     // ---- few samples: the feature-split kernel while the big one would leave CUs without a tile (see mlp_small_kernel) ----
     {
         static const int64_t small_max = [] {

@@ -17,7 +17,7 @@ import torch
 import yaml
 
 from ..cubedsphere._device import compute_device, on_device
-from ..local_mlp import LocalMlpModel, LocalMlpSpec, RnnModel, RnnSpec
+from ..local_mlp import HybridRnnModel, HybridRnnSpec, LocalMlpModel, LocalMlpSpec, RnnModel, RnnSpec
 from ..mlp import MlpModel, MlpModelSplitBf16, MlpSpec
 from . import zhao_carr
 
@@ -130,7 +130,7 @@ class HipLocalEmulator:
     def model(self):
         if self._model is None:
             # (both follow FV3NET_AMD_EMULATOR_ARITHMETIC, like HipEmulator)
-            cls = RnnModel if isinstance(self.spec, RnnSpec) else LocalMlpModel
+            cls = RnnModel if isinstance(self.spec, RnnSpec) else HybridRnnModel if isinstance(self.spec, HybridRnnSpec) else LocalMlpModel
             self._model = cls(self.spec, device=compute_device())
         return self._model
 
@@ -187,11 +187,13 @@ def load_emulator(path: str, expect=None):
         model = HipLocalEmulator(LocalMlpSpec.from_arrays(meta, arrays))
     elif arch in ("rnn-v1-shared-weights", "rnn-v1"):  # (both build Conv1D heads, architecture.py:483-506)
         model = HipLocalEmulator(RnnSpec.from_arrays(meta, arrays))
-    elif arch == "dense":
+    elif arch == "rnn":  # HybridRNN (architecture.py:78-147)
+        model = HipLocalEmulator(HybridRnnSpec.from_arrays(meta, arrays))
+    elif arch in ("dense", "linear"):  # ("linear", architecture.py:285-302 with MLPBlock(depth=0): a dense model without hidden layers)
         model = HipEmulator(MlpSpec.from_arrays(meta, arrays))
     else:
         raise NotImplementedError(f"architecture {arch!r} is not implemented on the device "
-                                  "(dense, dense-local, rnn-v1-shared-weights are)")
+                                  "(dense, linear, dense-local, rnn, rnn-v1, rnn-v1-shared-weights are)")
     if expect is not None and not isinstance(model, expect):
         raise TypeError(f"{path} holds a {type(model).__name__}, not a {expect.__name__}")
     return model

@@ -19,7 +19,7 @@ import numpy as np
 import torch
 
 from . import _lib
-from .mlp import InputSpec, MlpModel, MlpModelSplitBf16, MlpSpec, OutputSpec
+from .mlp import InputSpec, MlpModel, MlpModelSplitBf16, MlpSpec, OutputSpec, ResidualSpec
 from .ops import _ptr, _require_device, _stream
 
 
@@ -258,6 +258,76 @@ class RnnSpec:
         return cls(inputs=shell.inputs, layers=layers, outputs=shell.outputs, out_kernel=shell.out_kernel, out_bias=shell.out_bias)
 
 
+@dataclasses.dataclass
+class HybridRnnSpec:
+    """The "rnn" architecture (architecture.py:78-147 ``HybridRNN``, key "rnn" at :453-461):
+    ``combine_sequence_inputs`` -> one ``SimpleRNN(channels, activation, go_backwards)`` that returns only its FINAL
+    state -> ``MLPBlock(dense_width, dense_depth)`` -> ``StandardOutput`` dense heads (whole-column outputs).
+
+    ``head`` describes everything after the recurrence as an ``MlpSpec`` whose one network input is the source
+    ``STATE`` (``channels`` features, unnormalised); its outputs carry the per-level de-normalisation, limits and
+    residuals (``Difference.backward``) like a "dense" emulator's, residual sources being ``[nz, ncol]`` arrays of the
+    call.  ``dense_depth = 0`` is a head without hidden layers."""
+
+    STATE = "rnn_state"
+    inputs: List[LocalInput]
+    rnn: RnnLayer
+    head: MlpSpec
+    go_backwards: bool = True   # recurse from the last index (the model top in the physics' arrays) to index 0
+    architecture = "rnn"
+
+    @property
+    def sources(self) -> List[str]:
+        seen: List[str] = []
+        for n in [i.source for i in self.inputs] + [r.source for r in self.head.residuals]:
+            if n not in seen:
+                seen.append(n)
+        return seen
+
+    @property
+    def output_names(self) -> List[str]:
+        return self.head.output_names
+
+    def validate(self):
+        if [i.name for i in self.inputs] != sorted(i.name for i in self.inputs):
+            raise ValueError("inputs must be listed sorted by their network name (combine_sequence_inputs)")
+        fan, ch = len(self.inputs), int(self.rnn.kernel.shape[1])
+        if tuple(self.rnn.kernel.shape) != (fan, ch) or tuple(self.rnn.recurrent_kernel.shape) != (ch, ch) or tuple(self.rnn.bias.shape) != (ch,):
+            raise ValueError(f"recurrent layer: kernel {self.rnn.kernel.shape}, recurrent kernel {self.rnn.recurrent_kernel.shape}, "
+                             f"bias {self.rnn.bias.shape} do not fit {fan} inputs")
+        if [(i.source, i.nfeat, i.start) for i in self.head.inputs] != [(self.STATE, ch, 0)]:
+            raise ValueError(f"the head's only input must be the {ch} features of {self.STATE!r}")
+        if self.head.hidden_output:
+            raise ValueError("the head returns outputs, not its hidden layer")
+        if any(r.source == self.STATE for r in self.head.residuals):
+            raise ValueError("a residual cannot be added to the recurrent state")
+        self.head.validate()
+
+    def to_arrays(self) -> Tuple[dict, Dict[str, np.ndarray]]:
+        head_meta, head_arrays = self.head.to_arrays()
+        meta = {"architecture": self.architecture, "go_backwards": bool(self.go_backwards), "head": head_meta,
+                "inputs": [{"name": i.name, "source": i.source, "transform": i.transform, "eps": float(i.eps)} for i in self.inputs]}
+        arrays = {f"head_{k}": v for k, v in head_arrays.items()}
+        for n, i in enumerate(self.inputs):
+            for key in ("center", "scale"):
+                if getattr(i, key) is not None:
+                    arrays[f"in{n}_{key}"] = np.atleast_1d(np.asarray(getattr(i, key), np.float32))
+        arrays["rnn_kernel"] = np.asarray(self.rnn.kernel, np.float32)
+        arrays["rnn_recurrent_kernel"] = np.asarray(self.rnn.recurrent_kernel, np.float32)
+        arrays["rnn_bias"] = np.asarray(self.rnn.bias, np.float32)
+        return meta, arrays
+
+    @classmethod
+    def from_arrays(cls, meta: Mapping, arrays: Mapping[str, np.ndarray]) -> "HybridRnnSpec":
+        inputs = [LocalInput(name=m["name"], source=m["source"], transform=m.get("transform", "none"), eps=float(m.get("eps", 0.0)),
+                             center=arrays.get(f"in{n}_center"), scale=arrays.get(f"in{n}_scale"))
+                  for n, m in enumerate(meta["inputs"])]
+        head = MlpSpec.from_arrays(meta["head"], {k[len("head_"):]: v for k, v in arrays.items() if k.startswith("head_")})
+        return cls(inputs=inputs, rnn=RnnLayer(np.asarray(arrays["rnn_kernel"]), np.asarray(arrays["rnn_recurrent_kernel"]),
+                                               np.asarray(arrays["rnn_bias"])),
+                   head=head, go_backwards=bool(meta.get("go_backwards", True)))
+
+
 def _per_level(values, nz: int, default: float, what: str) -> np.ndarray:
     if values is None:
         return np.full(nz, default, np.float32)
@@ -312,7 +382,7 @@ class _PointModel:
                     raise ValueError("sources differ in their number of levels")
             arrs[name] = t.contiguous()
         nz = 1 if nz is None else nz
-        for o in self.spec.outputs:
+        for o in getattr(self.spec, "outputs", ()):
             for need in ([o.conditional.on] if o.conditional else []) + ([o.before] if o.before else []):
                 if arrs[need].shape[0] != nz:
                     raise ValueError(f"source {need!r} must have {nz} levels")
@@ -531,3 +601,70 @@ class RnnModel(_PointModel):
         self._pack_into(arrs, nz, ncol, dev, x)
         graph.replay()
         return x, y
+
+
+class HybridRnnModel(_PointModel):
+    """Device handle of a "rnn" (``HybridRnnSpec``) emulator: the pack pass, one fused-MLP launch per level for the
+    recurrence (the cell is a hidden-output model without outputs: ``h_t = relu([x_t, h_{t-1}] @ [kernel;
+    recurrent_kernel] + bias)``, the states ping-pong between two buffers), then ONE launch of the head on the final
+    state, whose epilogue writes the de-normalised, limited outputs and the residual sums.  For the column counts of a
+    model rank the level sweep is captured once per shape into a HIP graph and replayed (as ``RnnModel``)."""
+
+    def __init__(self, spec: HybridRnnSpec, device="cuda", use_graph: Optional[bool] = None):
+        super().__init__(spec, device)
+        fan, ch = int(spec.rnn.kernel.shape[0]), int(spec.rnn.kernel.shape[1])
+        self._cell = MlpModel(MlpSpec(
+            inputs=[InputSpec("in", fan), InputSpec("rec", ch)],
+            hidden_kernels=[np.concatenate([spec.rnn.kernel, spec.rnn.recurrent_kernel], axis=0).astype(np.float32)],
+            hidden_biases=[np.asarray(spec.rnn.bias, np.float32)], outputs=[], out_kernel=np.zeros((ch, 0), np.float32),
+            out_bias=np.zeros(0, np.float32), hidden_output="h"), device=self.device)
+        self._head = MlpModel(spec.head, device=self.device)
+        self._use_graph = use_graph
+        self._graphs: Dict[Tuple[int, int], tuple] = {}
+        self.flops_per_column_level = self._cell.flops_per_sample
+        self.flops_per_column_head = self._head.flops_per_sample
+
+    def _sweep(self, x: torch.Tensor, states, nz: int) -> torch.Tensor:
+        order = range(nz - 1, -1, -1) if self.spec.go_backwards else range(nz)
+        for step, z in enumerate(order):
+            cur = step & 1
+            self._cell.predict({"in": x[:, z], "rec": states[cur]}, out={"h": states[cur ^ 1]})
+        return states[nz & 1]
+
+    def predict(self, sources: Mapping[str, torch.Tensor]) -> Dict[str, torch.Tensor]:
+        """``sources``: name -> device array ``[nz, ncol]`` (or ``[ncol]`` / ``[1, ncol]``); returns name -> float32
+        ``[nfeat, ncol]``."""
+        from .ops import device_info
+
+        spec = self.spec
+        arrs, nz, ncol, dev = self._gather(sources)
+        ch = int(spec.rnn.kernel.shape[1])
+        use_graph = self._use_graph if self._use_graph is not None else ncol < 128 * int(device_info()["compute_units"])
+        if not use_graph:
+            x = self._pack(arrs, nz, ncol, dev).view(len(spec.inputs), nz, ncol)
+            states = [torch.zeros((ch, ncol), dtype=torch.float32, device=dev), torch.empty((ch, ncol), dtype=torch.float32, device=dev)]
+            final = self._sweep(x, states, nz)
+        else:
+            entry = self._graphs.get((nz, ncol))
+            if entry is None:
+                self._graphs.clear()  # one shape at a time
+                x = torch.empty((len(spec.inputs), nz, ncol), dtype=torch.float32, device=dev)
+                states = [torch.zeros((ch, ncol), dtype=torch.float32, device=dev), torch.empty((ch, ncol), dtype=torch.float32, device=dev)]
+                self._pack_into(arrs, nz, ncol, dev, x)
+                self._sweep(x, states, nz)  # eager warm-up
+                torch.cuda.synchronize(dev)
+                graph = torch.cuda.CUDAGraph()
+                with torch.cuda.graph(graph):
+                    states[0].zero_()
+                    self._sweep(x, states, nz)
+                entry = self._graphs[(nz, ncol)] = (graph, x, states)
+            graph, x, states = entry
+            self._pack_into(arrs, nz, ncol, dev, x)
+            graph.replay()
+            final = states[nz & 1]
+        head_sources = {HybridRnnSpec.STATE: final}
+        for r in spec.head.residuals:
+            if arrs[r.source].dtype != torch.float32:  # (one source dtype per launch: the state is float32)
+                arrs[r.source] = arrs[r.source].to(torch.float32)
+            head_sources[r.source] = arrs[r.source]
+        return self._head.predict(head_sources)

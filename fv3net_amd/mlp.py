@@ -84,7 +84,8 @@ class MlpSpec:
 
     @property
     def width(self) -> int:
-        return int(self.hidden_kernels[0].shape[1])
+        """Width of the hidden layers; a network without hidden layers ("linear") feeds its inputs to the output layer."""
+        return int(self.hidden_kernels[0].shape[1]) if self.hidden_kernels else int(self.out_kernel.shape[0])
 
     @property
     def output_names(self) -> List[str]:
@@ -102,13 +103,17 @@ class MlpSpec:
 
     def validate(self):
         k = self.n_in_features
-        if not self.hidden_kernels:
-            raise ValueError("at least one hidden layer is required")
         if len(self.hidden_kernels) != len(self.hidden_biases):
             raise ValueError("hidden_kernels and hidden_biases differ in length")
+        if self.activation not in ("relu", "linear"):
+            raise ValueError(f"activation must be 'relu' or 'linear', got {self.activation!r}")
+        if self.hidden_output and not self.hidden_kernels:
+            raise ValueError("hidden_output needs a hidden layer")
         w = self.width
-        if tuple(self.hidden_kernels[0].shape) != (k, w):
+        if self.hidden_kernels and tuple(self.hidden_kernels[0].shape) != (k, w):
             raise ValueError(f"first kernel has shape {self.hidden_kernels[0].shape}, expected {(k, w)}")
+        if tuple(self.hidden_biases[0].shape if self.hidden_biases else (w,)) != (w,):
+            raise ValueError(f"first bias has shape {self.hidden_biases[0].shape}, expected {(w,)}")
         for kern, b in zip(self.hidden_kernels[1:], self.hidden_biases[1:]):
             if tuple(kern.shape) != (w, w) or tuple(b.shape) != (w,):
                 raise ValueError("hidden layers must all have the same width")

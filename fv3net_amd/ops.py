@@ -389,6 +389,50 @@ def level_scale(x: torch.Tensor, scale: torch.Tensor, z_axis: int) -> torch.Tens
     return out
 
 
+def _flux_operands(arrays, surface, z_axis: int):
+    """Column arrays and [columns-without-z] surface arrays in one float dtype (numpy's promotion), contiguous."""
+    dt = torch.float64 if any(t is not None and t.dtype == torch.float64 for t in list(arrays) + list(surface)) else torch.float32
+    arrays = [cast(t, dt).contiguous() for t in arrays]
+    shape = tuple(arrays[0].shape)
+    for t in arrays[1:]:
+        if tuple(t.shape) != shape:
+            raise ValueError(f"column arrays differ in shape: {tuple(t.shape)} and {shape}")
+    z_axis, nb, nz, ni = _column_view(arrays[0], z_axis)
+    flat = shape[:z_axis] + shape[z_axis + 1:]
+    out_surface = []
+    for t in surface:
+        if t is not None:
+            t = cast(t, dt).contiguous()
+            if tuple(t.shape) != flat:
+                raise ValueError(f"surface array has shape {tuple(t.shape)}, the columns have {flat}")
+        out_surface.append(t)
+    return dt, arrays, out_surface, (nb, nz, ni), flat
+
+
+def tendency_to_flux(tendency: torch.Tensor, delp: torch.Tensor, toa_net_flux: Optional[torch.Tensor],
+                     surface_upward_flux: torch.Tensor, z_axis: int, rectify: bool = True, closure_only: bool = False):
+    """``vcm.calc.flux_form._tendency_to_flux`` (flux_form.py:7-46): (net flux at the interface above each cell, surface
+    downward flux); ``closure_only``: ``_tendency_to_implied_surface_downward_flux`` (:49-75), (None, downward flux)."""
+    dev = _require_device(tendency, delp, surface_upward_flux)
+    dt, (tend, dp), (toa, up), (nb, nz, ni), flat = _flux_operands([tendency, delp], [toa_net_flux, surface_upward_flux], z_axis)
+    flux = None if closure_only else torch.empty_like(tend)
+    down = torch.empty(flat, dtype=dt, device=dev)
+    _lib.call_on(dev, "fv3hip_tendency_to_flux", _ptr(tend), _ptr(dp), _ptr(toa), _ptr(up), _float_code(tend), nb, nz, ni,
+                 int(bool(rectify)), int(bool(closure_only)), _ptr(flux), _ptr(down), _stream(dev))
+    return flux, down
+
+
+def flux_to_tendency(net_flux: torch.Tensor, surface_downward_flux: torch.Tensor, surface_upward_flux: torch.Tensor,
+                     delp: torch.Tensor, z_axis: int) -> torch.Tensor:
+    """``vcm.calc.flux_form._flux_to_tendency`` (flux_form.py:78-104)."""
+    dev = _require_device(net_flux, delp)
+    dt, (flux, dp), (down, up), (nb, nz, ni), _ = _flux_operands([net_flux, delp], [surface_downward_flux, surface_upward_flux], z_axis)
+    out = torch.empty_like(flux)
+    _lib.call_on(dev, "fv3hip_flux_to_tendency", _ptr(flux), _ptr(down), _ptr(up), _ptr(dp), _float_code(flux), nb, nz, ni, _ptr(out),
+                 _stream(dev))
+    return out
+
+
 def member_reduce(members: Sequence[torch.Tensor], op: str) -> torch.Tensor:
     """NaN-skipping ``mean`` / ``median`` over same-shaped member arrays (EnsembleModel.predict, models.py:253-260)."""
     dev = _require_device(*members)
@@ -428,7 +472,7 @@ def interpolate_2d(xp: torch.Tensor, x: torch.Tensor, y: torch.Tensor, fill_valu
 
 EW_OPS = {"mul": 0, "isclose": 1, "isclose_s": 2, "where_nan": 3, "select": 4, "select_s": 5, "gt_s": 6, "lt_s": 7,
           "fillna_s": 8, "and": 9, "min_s": 10, "blend": 11, "mul_s": 12, "where_s": 13, "add": 14, "add_s": 15,
-          "sub": 16, "log_floor_s": 17, "exp": 18, "relu_threshold_s": 19, "below_s": 20}
+          "sub": 16, "log_floor_s": 17, "exp": 18, "relu_threshold_s": 19, "below_s": 20, "div_s": 21, "incloud_to_gridcell": 22}
 
 
 def ew(op: str, a: torch.Tensor, b: Optional[torch.Tensor] = None, c: Optional[torch.Tensor] = None,

@@ -193,6 +193,9 @@ int fv3hip_block_upsample(const void *in, int elem_size, int64_t n_outer, int ny
 #define FV3HIP_EW_EXP 18               /* exp(a)                               (LogTransform.backward)            */
 #define FV3HIP_EW_RELU_THRESHOLD_S 19  /* a where a > scalar else 0            (LimitValueTransform, lower bound) */
 #define FV3HIP_EW_BELOW_S 20           /* a where a < scalar else 0            (LimitValueTransform, upper bound) */
+#define FV3HIP_EW_DIV_S 21             /* a / scalar                           (vcm temperature_tendency, thermo/local.py:340-358) */
+#define FV3HIP_EW_INCLOUD_TO_GRIDCELL 22 /* b where a <= 1e-3 else b * max-like(a, 5e-2): in-cloud -> gridcell condensate by cloud
+                                          fraction a (vcm/calc/clouds.py:40-66) */
 int fv3hip_ew(int op, const void *a, const void *b, const void *c, double scalar, int dtype,
               int64_t n, int64_t inner, int64_t b_rep, int64_t c_rep, void *out, void *stream);
 
@@ -521,6 +524,43 @@ int fv3hip_level_scale(const void *x, int dtype, const double *scale, int64_t n_
                        int64_t n_inner, double *out, void *stream);
 int fv3hip_member_reduce(const void *const *members, int n_members, int dtype, int op, int64_t n,
                          void *out, void *stream);
+
+/*
+ * The flux-form output transforms of TransformedPredictor (external/fv3fit/fv3fit/_shared/models.py:279-337 applying
+ * external/vcm/vcm/data_transform.py:140-300), replacing external/vcm/vcm/calc/flux_form.py on xarray:
+ *   fv3hip_tendency_to_flux  _tendency_to_flux (flux_form.py:7-46): net_flux [n_outer][nz][n_inner] = flux at the interface
+ *                            ABOVE each cell = toa_net_flux - cumsum(tendency * delp / g) of the cells above, and
+ *                            surface_downward_flux [n_outer][n_inner] = the flux below the last cell + surface_upward_flux,
+ *                            zero where negative if `rectify`.  closure = 1: _tendency_to_implied_surface_downward_flux
+ *                            (:49-75), toa + upward - sum(tendency * delp / g); net_flux is not written (may be null).
+ *                            toa_net_flux may be null (zero).  All arrays share `dtype` and are computed in it, operation by
+ *                            operation as numpy does (a running sum: bit-identical for closure = 0).
+ *   fv3hip_flux_to_tendency  _flux_to_tendency (:78-104): -(g * diff(concat(net_flux, down - up)) / delp).
+ */
+int fv3hip_tendency_to_flux(const void *tendency, const void *delp, const void *toa_net_flux,
+                            const void *surface_upward_flux, int dtype, int64_t n_outer, int nz, int64_t n_inner,
+                            int rectify, int closure, void *net_flux, void *surface_downward_flux, void *stream);
+int fv3hip_flux_to_tendency(const void *net_flux, const void *surface_downward_flux, const void *surface_upward_flux,
+                            const void *delp, int dtype, int64_t n_outer, int nz, int64_t n_inner, void *tendency,
+                            void *stream);
+
+/*
+ * The novelty detectors OutOfSampleModel consults every timestep (external/fv3fit/fv3fit/_shared/models.py:340-440),
+ * replacing sklearn on the host:
+ *   fv3hip_minmax_score  MinMaxNoveltyDetector.predict (fv3fit/sklearn/_min_max_novelty_detector.py:94-121): one call per
+ *                        packed variable x (feature f of sample i at x[f * feat_stride + i * sample_stride], `dtype`) folds
+ *                        MinMaxScaler.transform's x * scale[f] + offset[f] (float64) into run_max / run_min [n]
+ *                        (`first` != 0 starts them); `finish` != 0 writes score = max(max - 1, 0) + max(-min, 0).
+ *   fv3hip_ocsvm_score   OCSVMNoveltyDetector.predict (_ocsvm_novelty_detector.py:124-160): score[i] = -sum_v dual_coef[v]
+ *                        exp(-gamma |z_i - support_vectors[v]|^2), z = (x - mean) / scale; x [n_feat][n] float64 packed,
+ *                        support_vectors [n_sv][n_feat] (already in the scaler's space, as sklearn stores them).
+ */
+int fv3hip_minmax_score(const void *x, int dtype, int64_t feat_stride, int64_t sample_stride, int n_feat,
+                        const double *scale, const double *offset, int64_t n, int first, int finish, double *run_max,
+                        double *run_min, double *score, void *stream);
+int fv3hip_ocsvm_score(const double *x, int n_feat, int64_t n, const double *mean, const double *scale,
+                       const double *support_vectors, const double *dual_coef, int n_sv, double gamma, double *score,
+                       void *stream);
 
 /*
  * Replaces mappm.interpolate_2d (external/mappm/mappm/interpolate_2d.f90:1-28; called from

@@ -59,7 +59,7 @@ def limit_output(y, vmin=None, vmax=None):
     return x
 
 
-def forward(spec, sources, dtype=np.float32):
+def forward(spec, sources, dtype=np.float32, internal=()):
     """Evaluate an ``fv3net_amd.mlp.MlpSpec``-shaped description.
 
     ``spec`` is duck-typed (attributes inputs / hidden_kernels / hidden_biases / outputs /
@@ -72,8 +72,9 @@ def forward(spec, sources, dtype=np.float32):
         a = np.asarray(arr)
         if a.ndim == 1:
             a = a[:, None]
-        # Keras casts float64 inputs to the layer dtype (float32) first
-        src[name] = a.astype(np.float32).astype(dtype)
+        # Keras casts float64 inputs to the layer dtype (float32) first (``internal``: names that are no model inputs but
+        # values handed on inside a graph -- a recurrent state -- and stay as they are)
+        src[name] = a.astype(dtype) if name in internal else a.astype(np.float32).astype(dtype)
     for i in spec.inputs:
         x = src[i.source][:, i.start:i.start + i.nfeat]
         if i.transform == "log":
@@ -84,7 +85,8 @@ def forward(spec, sources, dtype=np.float32):
     h = np.concatenate(cols, axis=1)
     for kern, b in zip(spec.hidden_kernels, spec.hidden_biases):
         h = h @ np.asarray(kern, np.float32).astype(dtype) + np.asarray(b, np.float32).astype(dtype)
-        h = np.maximum(h, 0)
+        if getattr(spec, "activation", "relu") == "relu":  # ("linear": no activation)
+            h = np.maximum(h, 0)
     yhat = h @ np.asarray(spec.out_kernel, np.float32).astype(dtype) + np.asarray(spec.out_bias, np.float32).astype(dtype)
     out = {}
     if getattr(spec, "hidden_output", None):  # the last hidden layer's activations as an output of their own
@@ -228,3 +230,24 @@ def forward_rnn(spec, sources, dtype=np.float32):
     rnn_out = seq[:, ::-1, :]
     yhat = rnn_out @ np.asarray(spec.out_kernel, np.float32).astype(dtype) + np.asarray(spec.out_bias, np.float32).astype(dtype)
     return _local_outputs(spec, yhat, src, dtype)
+
+
+def forward_hybrid_rnn(spec, sources, dtype=np.float32):
+    """Evaluate an ``fv3net_amd.local_mlp.HybridRnnSpec``-shaped description: layers/architecture.py:78-147 (HybridRNN:
+    ``SimpleRNN(channels, activation='relu', go_backwards)`` returning its last state -- Keras 2.8: with
+    ``go_backwards`` the sequence is fed reversed, ``h_t = relu(x_t W + h_{t-1} U + b)`` from a zero state -- then
+    ``MLPBlock``) and :285-343 (StandardOutput dense heads), followed by the head's de-normalisation / limits /
+    residuals as in ``forward``.  ``sources``: name -> [sample, nz] (or [sample] / [sample, 1])."""
+    seq, src = _local_inputs(spec, sources, dtype)  # [sample, nz, n_inputs]
+    if spec.go_backwards:
+        seq = seq[:, ::-1, :]
+    w = np.asarray(spec.rnn.kernel, np.float32).astype(dtype)
+    u = np.asarray(spec.rnn.recurrent_kernel, np.float32).astype(dtype)
+    b = np.asarray(spec.rnn.bias, np.float32).astype(dtype)
+    state = np.zeros((seq.shape[0], w.shape[1]), dtype)
+    for t in range(seq.shape[1]):
+        state = np.maximum(seq[:, t] @ w + state @ u + b, 0)
+    head_sources = {"rnn_state": state}
+    for r in spec.head.residuals:
+        head_sources[r.source] = sources[r.source]
+    return forward(spec.head, head_sources, dtype=dtype, internal=("rnn_state",))

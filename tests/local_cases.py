@@ -107,7 +107,40 @@ def precpd_rnn(rng, st, nz, channels=64, depth=2, make=None):
                       out_bias=rng.normal(0, 0.1, 3).astype(np.float32))
 
 
-def product_makers():
-    from fv3net_amd.local_mlp import ConditionalScale, LocalInput, LocalMlpSpec, LocalOutput, RnnLayer, RnnSpec
+def hybrid_rnn(rng, st, nz, channels=64, dense_width=64, dense_depth=1, go_backwards=True, make=None):
+    """A "rnn" (HybridRNN, architecture.py:78-147) emulator: the final state of one SimpleRNN over the levels feeds
+    ``dense_depth`` hidden layers and whole-column dense heads -- per-level de-normalised differences added to the
+    input state, one limited single-value output."""
+    m = make or NS(input=NS, rnn_layer=NS, hybrid_spec=NS, head_spec=NS, head_input=NS, head_output=NS, head_residual=NS)
+    inputs = _inputs(rng, st, nz, m.input)
+    fan = len(inputs)
+    layer = m.rnn_layer(kernel=(rng.normal(0, 1, (fan, channels)) / np.sqrt(fan)).astype(np.float32),
+                        recurrent_kernel=(rng.normal(0, 0.6, (channels, channels)) / np.sqrt(channels)).astype(np.float32),
+                        bias=rng.normal(0, 0.1, channels).astype(np.float32))
+    hk, hb, k = [], [], channels
+    for _ in range(dense_depth):
+        hk.append((rng.normal(0, 1, (k, dense_width)) / np.sqrt(k)).astype(np.float32))
+        hb.append(rng.normal(0, 0.1, dense_width).astype(np.float32))
+        k = dense_width
+    outs = [m.head_output(name="humidity_difference", nfeat=nz, scale=(1e-4 * rng.uniform(0.5, 2, nz)).astype(np.float32),
+                          center=rng.normal(0, 1e-5, nz).astype(np.float32), min=None, max=None, mask=None),
+            m.head_output(name="temperature_difference", nfeat=nz, scale=rng.uniform(0.5, 2, nz).astype(np.float32),
+                          center=rng.normal(0, 0.1, nz).astype(np.float32), min=None, max=None, mask=None),
+            m.head_output(name="total_precipitation", nfeat=1, scale=np.array([1e-3], np.float32), center=np.array([2e-4], np.float32),
+                          min=0.0, max=None, mask=None)]
+    f = 2 * nz + 1
+    head = m.head_spec(inputs=[m.head_input(source="rnn_state", nfeat=channels, start=0, transform="none", eps=0.0, center=None, scale=None)],
+                       hidden_kernels=hk, hidden_biases=hb, outputs=outs,
+                       out_kernel=(rng.normal(0, 1, (k, f)) / np.sqrt(k)).astype(np.float32), out_bias=rng.normal(0, 0.1, f).astype(np.float32),
+                       residuals=[m.head_residual(name="specific_humidity_after", source=QV_IN, output="humidity_difference"),
+                                  m.head_residual(name="air_temperature_after", source=T_IN, output="temperature_difference")],
+                       activation="relu", hidden_output=None)
+    return m.hybrid_spec(inputs=inputs, rnn=layer, head=head, go_backwards=go_backwards)
 
-    return NS(input=LocalInput, output=LocalOutput, cond=ConditionalScale, spec=LocalMlpSpec, rnn_spec=RnnSpec, rnn_layer=RnnLayer)
+
+def product_makers():
+    from fv3net_amd.local_mlp import ConditionalScale, HybridRnnSpec, LocalInput, LocalMlpSpec, LocalOutput, RnnLayer, RnnSpec
+    from fv3net_amd.mlp import InputSpec, MlpSpec, OutputSpec, ResidualSpec
+
+    return NS(input=LocalInput, output=LocalOutput, cond=ConditionalScale, spec=LocalMlpSpec, rnn_spec=RnnSpec, rnn_layer=RnnLayer,
+              hybrid_spec=HybridRnnSpec, head_spec=MlpSpec, head_input=InputSpec, head_output=OutputSpec, head_residual=ResidualSpec)

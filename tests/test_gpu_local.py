@@ -345,3 +345,58 @@ def test_online_schedule_switches_between_physics_and_emulator(tmp_path):
                 np.testing.assert_array_equal(state[name], fortran[name])
         # outputs the Fortran state does not hold come from the emulator either way
         _check(state["humidity_gscond_difference"], truth["humidity_gscond_difference"].T, "humidity_gscond_difference")
+
+
+@pytest.mark.parametrize("nz,ncol,dtype,channels,dense_width,dense_depth,go_backwards", [
+    (79, 1024, np.float64, 256, 256, 1, True), (79, 333, np.float32, 64, 128, 2, False), (5, 64, np.float64, 32, 32, 0, True),
+    (79, 200, np.float32, 128, 384, 1, True)])
+def test_hybrid_rnn_emulator_matches_oracle(nz, ncol, dtype, channels, dense_width, dense_depth, go_backwards, tmp_path):
+    """The "rnn" architecture (HybridRNN, architecture.py:78-147; VERDICT r02 missing #2): SimpleRNN final state ->
+    dense head; a head without hidden layers and one wider than 256 go through the layered path.  Graph replay and eager
+    launches give the same bits; the saved directory loads back through ``load_emulator``."""
+    from fv3net_amd.emulation.models import HipLocalEmulator, load_emulator
+    from fv3net_amd.local_mlp import HybridRnnModel
+
+    rng = np.random.default_rng(nz * 1000 + ncol)
+    st = cases.state(rng, nz, ncol, dtype)
+    spec = cases.hybrid_rnn(rng, st, nz, channels=channels, dense_width=dense_width, dense_depth=dense_depth,
+                            go_backwards=go_backwards, make=cases.product_makers())
+    got = HybridRnnModel(spec, device="cuda", use_graph=True).predict(_dev(st))
+    eager = HybridRnnModel(spec, device="cuda", use_graph=False).predict(_dev(st))
+    src = {k: v.T for k, v in st.items()}
+    truth = mlp_np.forward_hybrid_rnn(spec, src, dtype=np.float64)
+    f32 = mlp_np.forward_hybrid_rnn(spec, src, dtype=np.float32)
+    assert list(got) == spec.output_names
+    for name in spec.output_names:
+        assert torch.equal(got[name], eager[name]), name
+        _check(got[name].cpu().numpy(), truth[name].T, name, f32=f32[name].T)
+    assert float(got["total_precipitation"].min()) >= 0.0
+    HipLocalEmulator(spec).dump(str(tmp_path / "hybrid"))
+    assert yaml.safe_load(open(tmp_path / "hybrid" / "spec.yaml"))["architecture"] == "rnn"
+    loaded = load_emulator(str(tmp_path / "hybrid"))
+    again = loaded({k: v.T for k, v in st.items()})  # [sample, feature] numpy in, as the hook's models are called
+    for name in spec.output_names:
+        np.testing.assert_array_equal(again[name], got[name].cpu().numpy().T, err_msg=name)
+
+
+def test_linear_architecture_loads_as_a_dense_emulator_without_hidden_layers(tmp_path):
+    """architecture "linear" (architecture.py:285-302, MLPBlock(depth=0)): dumped and loaded like a dense model."""
+    from fv3net_amd.emulation.models import HipEmulator, load_emulator
+    from fv3net_amd.mlp import InputSpec, MlpSpec, OutputSpec
+
+    rng = np.random.default_rng(3)
+    nz, n = 79, 500
+    spec = MlpSpec(inputs=[InputSpec("T", nz, center=rng.normal(250, 5, nz), scale=rng.uniform(5, 20, nz)),
+                           InputSpec("q", nz, transform="log", eps=1e-8, center=rng.normal(-8, 1, nz), scale=rng.uniform(1, 2, nz))],
+                   hidden_kernels=[], hidden_biases=[], outputs=[OutputSpec("dT", nz, scale=rng.uniform(0.5, 2, nz), center=rng.normal(0, 1, nz))],
+                   out_kernel=(rng.normal(0, 1, (2 * nz, nz)) / np.sqrt(2 * nz)).astype(np.float32), out_bias=rng.normal(0, 0.1, nz).astype(np.float32))
+    HipEmulator(spec).dump(str(tmp_path / "lin"))
+    meta = yaml.safe_load(open(tmp_path / "lin" / "spec.yaml"))
+    meta["architecture"] = "linear"
+    yaml.safe_dump(meta, open(tmp_path / "lin" / "spec.yaml", "w"))
+    model = load_emulator(str(tmp_path / "lin"))
+    state = {"T": rng.uniform(200, 300, (n, nz)), "q": 10.0 ** rng.uniform(-8, -2, (n, nz))}
+    got = model(state)["dT"]
+    truth = mlp_np.forward(spec, state, dtype=np.float64)["dT"]
+    f32 = mlp_np.forward(spec, state, dtype=np.float32)["dT"]
+    assert_close_per_level(got, truth, f32, "dT")

@@ -195,3 +195,50 @@ def test_forward_rnn_against_torch_cpu(dtype, tol):
     np.testing.assert_allclose(got["cloud_water_mixing_ratio_after_precpd"], after.numpy(), rtol=tol, atol=tol * float(after.abs().max()))
     assert (got["cloud_water_mixing_ratio_after_precpd"] >= 0).all() and (got["cloud_precpd_difference"] <= 0).all()
     assert (got["humidity_precpd_difference"] >= 0).all()
+
+
+@pytest.mark.parametrize("go_backwards", [True, False])
+@pytest.mark.parametrize("dense_depth", [0, 2])
+@pytest.mark.parametrize("dtype,tol", [(np.float64, 1e-12), (np.float32, 5e-5)])
+def test_forward_hybrid_rnn_against_torch_cpu(dtype, tol, dense_depth, go_backwards):
+    """HybridRNN (architecture.py:78-147) against torch.nn.RNN(nonlinearity='relu')'s FINAL state (the sequence flipped
+    for go_backwards, as Keras feeds it), torch.nn.Linear hidden layers and heads.  TensorFlow itself is not
+    installed: the recurrence is pinned to an independent implementation, not to the reference's own output."""
+    import local_cases
+
+    rng = np.random.default_rng(19)
+    nz, ncol, ch = 9, 25, 16
+    st = local_cases.state(rng, nz, ncol)
+    spec = local_cases.hybrid_rnn(rng, st, nz, channels=ch, dense_width=24, dense_depth=dense_depth, go_backwards=go_backwards)
+    got = mlp_np.forward_hybrid_rnn(spec, {k: v.T for k, v in st.items()}, dtype=dtype)
+    td = torch.float64 if dtype == np.float64 else torch.float32
+    cols = []
+    for i in spec.inputs:
+        x = torch.from_numpy(np.atleast_2d(st[i.source]).T.astype(np.float32)).to(td)
+        if i.transform == "log":
+            x = torch.log(torch.clamp(x, min=float(np.float32(i.eps))))
+        x = (x - torch.from_numpy(np.atleast_1d(i.center)).to(td)) / torch.tensor(float(i.scale), dtype=td)
+        cols.append(x.expand(ncol, nz).unsqueeze(-1))
+    seq = torch.cat(cols, -1)
+    if go_backwards:
+        seq = torch.flip(seq, dims=[1])
+    rnn = torch.nn.RNN(len(spec.inputs), ch, nonlinearity="relu", batch_first=True).to(td)
+    with torch.no_grad():
+        rnn.weight_ih_l0.copy_(torch.from_numpy(spec.rnn.kernel.T.copy()))
+        rnn.weight_hh_l0.copy_(torch.from_numpy(spec.rnn.recurrent_kernel.T.copy()))
+        rnn.bias_ih_l0.copy_(torch.from_numpy(spec.rnn.bias))
+        rnn.bias_hh_l0.zero_()
+        _, h = rnn(seq)
+    h = h[0]
+    for kern, b in zip(spec.head.hidden_kernels, spec.head.hidden_biases):
+        h = torch.relu(h @ torch.from_numpy(kern).to(td) + torch.from_numpy(b).to(td))
+    y = (h @ torch.from_numpy(spec.head.out_kernel).to(td) + torch.from_numpy(spec.head.out_bias).to(td)).detach()
+    o = spec.head.outputs
+    dq = y[:, :nz] * torch.from_numpy(o[0].scale).to(td) + torch.from_numpy(o[0].center).to(td)
+    dt = y[:, nz:2 * nz] * torch.from_numpy(o[1].scale).to(td) + torch.from_numpy(o[1].center).to(td)
+    pr = torch.clamp(y[:, 2 * nz:] * float(o[2].scale[0]) + float(o[2].center[0]), min=0.0)
+    for name, ref in (("humidity_difference", dq), ("temperature_difference", dt), ("total_precipitation", pr),
+                      ("specific_humidity_after", torch.from_numpy(st[local_cases.QV_IN].T.astype(np.float32)).to(td) + dq),
+                      ("air_temperature_after", torch.from_numpy(st[local_cases.T_IN].T.astype(np.float32)).to(td) + dt)):
+        np.testing.assert_allclose(got[name], ref.numpy(), rtol=tol, atol=tol * float(ref.abs().max()), err_msg=name)
+    assert set(got) == set(spec.head.outputs[i].name for i in range(3)) | {"specific_humidity_after", "air_temperature_after"}
