@@ -24,7 +24,7 @@ from ..mlp import InputSpec, MlpModel, MlpSpec, OutputSpec
 from ..xr_compat import DataArray, Dataset, from_compat, to_compat
 from . import io
 from .predictor import Predictor
-from .stacking import _infer_dimension_order, match_prediction_to_input_coords
+from .stacking import column_sources, match_prediction_to_input_coords
 
 
 @io.register("hip-dense")
@@ -59,41 +59,7 @@ class HipDenseModel(Predictor):
     def predict(self, X):
         """Predict an output dataset from an input dataset.  Does not mutate ``X``."""
         x = to_compat(X)
-        arrays = {name: x[name] for name in self.spec.sources}  # KeyError for a missing variable
-        zdims = set(self._unstacked_dims)
-        order = _infer_dimension_order(Dataset({k: v for k, v in arrays.items()}))
-        sample_dims = [d for d in order if d not in zdims]
-        sizes: Dict[Hashable, int] = {}
-        for da in arrays.values():
-            for d, n in da.sizes.items():
-                if sizes.setdefault(d, n) != n:
-                    raise ValueError(f"conflicting sizes for dimension {d!r}")
-        n_samples = int(np.prod([sizes[d] for d in sample_dims])) if sample_dims else 1
-        zname = next((d for d in order if d in zdims), self._unstacked_dims[0] if self._unstacked_dims else "z")
-
-        host_input = None
-        sources = {}
-        for name, da in arrays.items():
-            zs = [d for d in da.dims if d in zdims]
-            if len(zs) > 1:
-                raise ValueError(f"variable {name!r} has more than one unstacked dim: {zs}")
-            own_samples = [d for d in da.dims if d not in zdims]
-            if set(own_samples) != set(sample_dims):
-                raise ValueError(
-                    f"variable {name!r} has sample dims {own_samples}, expected {sample_dims} "
-                    "(broadcasting inputs over sample dims is not supported)"
-                )
-            if host_input is None:
-                host_input = da.data
-            nfeat = da.sizes[zs[0]] if zs else 1
-            t = on_device(da.data)
-            if own_samples == sample_dims and (not zs or da.dims[0] == zs[0]):
-                t2 = t.contiguous().reshape(nfeat, n_samples)            # native [z, ...]: a view
-            elif own_samples == sample_dims and da.dims[-1] == zs[0]:
-                t2 = t.contiguous().reshape(n_samples, nfeat).t()        # [..., z]: a strided view
-            else:
-                t2 = on_device(da.transpose(*zs, *sample_dims).data).contiguous().reshape(nfeat, n_samples)
-            sources[name] = t2
+        sources, sample_dims, sizes, zname, host_input = column_sources(x, self.spec.sources, self._unstacked_dims)
         outs = self.model.predict(sources, layout="feature_sample")
 
         result = Dataset()

@@ -59,3 +59,49 @@ def match_prediction_to_input_coords(input: Dataset, prediction: Dataset) -> Dat
         order += [d for d in da.dims if d not in order]
         out[name] = da._replace(coords=coords).transpose(*order)
     return out
+
+
+def column_sources(x: Dataset, names: Sequence[Hashable], unstacked_dims: Sequence[str]):
+    """The variables ``names`` of ``x`` as device arrays ``[feature, sample]`` over one common sample order -- what the
+    reference gets from ``stack`` + ``pack`` (stacking.py:7-37), here views of the native ``[z, ...]`` (or ``[..., z]``)
+    memory wherever the dim order allows.  Returns (name -> tensor, sample dims, dim sizes, the vertical dim's name, the
+    first variable's own data -- the caller returns host arrays for host input)."""
+    import numpy as np
+
+    from ..cubedsphere._device import on_device
+
+    arrays = {name: x[name] for name in names}  # KeyError for a missing variable
+    zdims = set(unstacked_dims)
+    order = _infer_dimension_order(Dataset({k: v for k, v in arrays.items()}))
+    sample_dims = [d for d in order if d not in zdims]
+    sizes = {}
+    for da in arrays.values():
+        for d, n in da.sizes.items():
+            if sizes.setdefault(d, n) != n:
+                raise ValueError(f"conflicting sizes for dimension {d!r}")
+    n_samples = int(np.prod([sizes[d] for d in sample_dims])) if sample_dims else 1
+    zname = next((d for d in order if d in zdims), unstacked_dims[0] if unstacked_dims else "z")
+    host_input = None
+    sources = {}
+    for name, da in arrays.items():
+        zs = [d for d in da.dims if d in zdims]
+        if len(zs) > 1:
+            raise ValueError(f"variable {name!r} has more than one unstacked dim: {zs}")
+        own_samples = [d for d in da.dims if d not in zdims]
+        if set(own_samples) != set(sample_dims):
+            raise ValueError(
+                f"variable {name!r} has sample dims {own_samples}, expected {sample_dims} "
+                "(broadcasting inputs over sample dims is not supported)"
+            )
+        if host_input is None:
+            host_input = da.data
+        nfeat = da.sizes[zs[0]] if zs else 1
+        t = on_device(da.data)
+        if own_samples == sample_dims and (not zs or da.dims[0] == zs[0]):
+            t2 = t.contiguous().reshape(nfeat, n_samples)            # native [z, ...]: a view
+        elif own_samples == sample_dims and da.dims[-1] == zs[0]:
+            t2 = t.contiguous().reshape(n_samples, nfeat).t()        # [..., z]: a strided view
+        else:
+            t2 = on_device(da.transpose(*zs, *sample_dims).data).contiguous().reshape(nfeat, n_samples)
+        sources[name] = t2
+    return sources, sample_dims, sizes, zname, host_input

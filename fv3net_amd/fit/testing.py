@@ -9,7 +9,8 @@ import yaml
 from ..xr_compat import DataArray, Dataset, from_compat, to_compat
 from . import io
 from .predictor import Predictor
-from .stacking import match_prediction_to_input_coords
+from .novelty import NoveltyDetector
+from .stacking import Z_DIM_NAMES, match_prediction_to_input_coords
 
 
 @io.register("constant-output")
@@ -59,3 +60,34 @@ class ConstantOutputPredictor(Predictor):
         obj = cls(config["input_variables"], config["output_variables"], config.get("unstacked_dims", ("z",)))
         obj.set_outputs(**{k: np.asarray(v) for k, v in config.get("outputs", {}).items()})
         return obj
+
+
+
+@io.register("constant-output-novelty")
+class ConstantOutputNoveltyDetector(NoveltyDetector):
+    """The reference's fake detector (external/fv3fit/fv3fit/testing.py:135-170): scores are always 0, so the cutoff
+    alone decides what counts as a novelty."""
+
+    def __init__(self, input_variables: Iterable[Hashable]):
+        super().__init__(input_variables=input_variables)
+
+    def predict(self, data):
+        x = to_compat(data)
+        first = x[next(iter(self.input_variables))]
+        dims = [d for d in first.dims if d not in Z_DIM_NAMES]
+        zeros = DataArray(np.zeros([first.sizes[d] for d in dims], dtype=first.dtype), dims=dims,
+                          coords={k: v for k, v in first.coords.items() if k in dims})
+        out = Dataset()
+        out[self._SCORE_OUTPUT_VAR] = zeros
+        out[self._CENTERED_SCORE_OUTPUT_VAR] = zeros
+        return from_compat(out, data)
+
+    def dump(self, path: str) -> None:
+        os.makedirs(path, exist_ok=True)
+        with open(os.path.join(path, "attrs.yaml"), "w") as f:
+            yaml.safe_dump({"input_variables": list(self.input_variables)}, f)
+
+    @classmethod
+    def load(cls, path: str) -> "ConstantOutputNoveltyDetector":
+        with open(os.path.join(path, "attrs.yaml")) as f:
+            return cls(**yaml.safe_load(f))

@@ -433,6 +433,39 @@ def flux_to_tendency(net_flux: torch.Tensor, surface_downward_flux: torch.Tensor
     return out
 
 
+def minmax_score(variables: Sequence[torch.Tensor], scales: Sequence[torch.Tensor], offsets: Sequence[torch.Tensor]) -> torch.Tensor:
+    """MinMaxNoveltyDetector's score (fv3fit/sklearn/_min_max_novelty_detector.py:94-121) of ``[feature, sample]`` arrays
+    (any strides) scaled as ``MinMaxScaler.transform`` does: ``max(max_f - 1, 0) + max(-min_f, 0)``, float64 ``[sample]``."""
+    dev = _require_device(*variables)
+    n = int(variables[0].shape[1])
+    run_max = torch.empty(n, dtype=torch.float64, device=dev)
+    run_min = torch.empty(n, dtype=torch.float64, device=dev)
+    score = torch.empty(n, dtype=torch.float64, device=dev)
+    for k, (t, sc, off) in enumerate(zip(variables, scales, offsets)):
+        if t.dim() != 2 or int(t.shape[1]) != n or tuple(sc.shape) != (t.shape[0],) or tuple(off.shape) != (t.shape[0],):
+            raise ValueError("variables must be [feature, sample] arrays over the same samples with [feature] scales and offsets")
+        _lib.call_on(dev, "fv3hip_minmax_score", _ptr(t), _float_code(t), int(t.stride(0)), int(t.stride(1)), int(t.shape[0]),
+                     _ptr(sc.to(torch.float64).contiguous()), _ptr(off.to(torch.float64).contiguous()), n, int(k == 0),
+                     int(k == len(variables) - 1), _ptr(run_max), _ptr(run_min), _ptr(score), _stream(dev))
+    return score
+
+
+def ocsvm_score(x: torch.Tensor, mean: torch.Tensor, scale: torch.Tensor, support_vectors: torch.Tensor, dual_coef: torch.Tensor,
+                gamma: float) -> torch.Tensor:
+    """``-Pipeline(StandardScaler, OneClassSVM(rbf)).score_samples`` of the packed float64 ``x`` [feature, sample]
+    (fv3fit/sklearn/_ocsvm_novelty_detector.py:124-160)."""
+    dev = _require_device(x, mean, scale, support_vectors, dual_coef)
+    x = x.to(torch.float64).contiguous()
+    nf, n = int(x.shape[0]), int(x.shape[1])
+    sv = support_vectors.to(torch.float64).contiguous()
+    if tuple(sv.shape[1:]) != (nf,) or tuple(dual_coef.shape) != (sv.shape[0],) or tuple(mean.shape) != (nf,) or tuple(scale.shape) != (nf,):
+        raise ValueError("support vectors [n_sv, feature], dual_coef [n_sv], mean / scale [feature] do not fit x [feature, sample]")
+    out = torch.empty(n, dtype=torch.float64, device=dev)
+    _lib.call_on(dev, "fv3hip_ocsvm_score", _ptr(x), nf, n, _ptr(mean.to(torch.float64).contiguous()), _ptr(scale.to(torch.float64).contiguous()),
+                 _ptr(sv), _ptr(dual_coef.to(torch.float64).contiguous()), int(sv.shape[0]), float(gamma), _ptr(out), _stream(dev))
+    return out
+
+
 def member_reduce(members: Sequence[torch.Tensor], op: str) -> torch.Tensor:
     """NaN-skipping ``mean`` / ``median`` over same-shaped member arrays (EnsembleModel.predict, models.py:253-260)."""
     dev = _require_device(*members)
@@ -472,7 +505,8 @@ def interpolate_2d(xp: torch.Tensor, x: torch.Tensor, y: torch.Tensor, fill_valu
 
 EW_OPS = {"mul": 0, "isclose": 1, "isclose_s": 2, "where_nan": 3, "select": 4, "select_s": 5, "gt_s": 6, "lt_s": 7,
           "fillna_s": 8, "and": 9, "min_s": 10, "blend": 11, "mul_s": 12, "where_s": 13, "add": 14, "add_s": 15,
-          "sub": 16, "log_floor_s": 17, "exp": 18, "relu_threshold_s": 19, "below_s": 20, "div_s": 21, "incloud_to_gridcell": 22}
+          "sub": 16, "log_floor_s": 17, "exp": 18, "relu_threshold_s": 19, "below_s": 20, "div_s": 21, "incloud_to_gridcell": 22,
+          "clip01": 23, "pow_base_s": 24, "minimum_s": 25}
 
 
 def ew(op: str, a: torch.Tensor, b: Optional[torch.Tensor] = None, c: Optional[torch.Tensor] = None,

@@ -196,6 +196,9 @@ int fv3hip_block_upsample(const void *in, int elem_size, int64_t n_outer, int ny
 #define FV3HIP_EW_DIV_S 21             /* a / scalar                           (vcm temperature_tendency, thermo/local.py:340-358) */
 #define FV3HIP_EW_INCLOUD_TO_GRIDCELL 22 /* b where a <= 1e-3 else b * max-like(a, 5e-2): in-cloud -> gridcell condensate by cloud
                                           fraction a (vcm/calc/clouds.py:40-66) */
+#define FV3HIP_EW_CLIP01 23            /* np.clip(a, 0, 1), a NaN stays        (taper_ramp, fv3fit/_shared/taper_function.py:41-51) */
+#define FV3HIP_EW_POW_BASE_S 24        /* scalar ** a                          (taper_decay, taper_function.py:54-64) */
+#define FV3HIP_EW_MINIMUM_S 25         /* np.minimum(a, scalar), a NaN stays   (taper_decay) */
 int fv3hip_ew(int op, const void *a, const void *b, const void *c, double scalar, int dtype,
               int64_t n, int64_t inner, int64_t b_rep, int64_t c_rep, void *out, void *stream);
 
