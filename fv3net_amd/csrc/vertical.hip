@@ -254,7 +254,242 @@ __device__ __forceinline__ ColumnAddr column_addr_coarse_target(int64_t col, int
     return a;
 }
 
-// One column, the Fortran control flow verbatim (all iv, kord <= 7, any input whatsoever).
+// cs_limiters (mappm.f90:532-611) for one level; mode = the routine's `iv` argument
+__device__ __forceinline__ void cs_limiters1(bool extm, float a1, float &a2, float &a3, float &a4, int mode)
+{
+    const float r12 = 1.f / 12.f;
+    if (mode == 0) {  // positive definite constraint
+        if (a1 <= 0.f) {
+            a2 = a1;
+            a3 = a1;
+            a4 = 0.f;
+        } else if (fabsf(a3 - a2) < -a4) {
+            if ((a1 + 0.25f * ((a3 - a2) * (a3 - a2)) / a4 + a4 * r12) < 0.f) {  // the local minimum is negative
+                if (a1 < a3 && a1 < a2) {
+                    a3 = a1;
+                    a2 = a1;
+                    a4 = 0.f;
+                } else if (a3 > a2) {
+                    a4 = 3.f * (a2 - a1);
+                    a3 = a2 - a4;
+                } else {
+                    a4 = 3.f * (a3 - a1);
+                    a2 = a3 - a4;
+                }
+            }
+        }
+        return;
+    }
+    if (mode == 1 ? ((a1 - a2) * (a1 - a3) >= 0.f) : extm) {
+        a2 = a1;
+        a3 = a1;
+        a4 = 0.f;
+        return;
+    }
+    const float da1 = a3 - a2, da2 = da1 * da1, a6da = a4 * da1;
+    if (a6da < -da2) {
+        a4 = 3.f * (a2 - a1);
+        a3 = a2 - a4;
+    } else if (a6da > da2) {
+        a4 = 3.f * (a3 - a1);
+        a2 = a3 - a4;
+    }
+}
+
+// cs_profile (mappm.f90:132-529, kord > 7, iv != -2) for one column, the Fortran's operations in its order.  The edge
+// values q(1:km) live in the QE plane of the workspace (q(km+1) in a register), the tridiagonal's gam in the GAM plane; the
+// differences of the cell means the constraints use and the extremum flags ext5 / ext6 are recomputed where they are
+// read (the flags from the edge values as they were BEFORE the subgrid constraints, which is what QE keeps).
+template <typename FQ, typename FDP>
+__device__ __forceinline__ void cs_profile_column(FQ Q, FDP DP, float *AL, float *AR, float *A6, float *GAM, float *QE,
+                                                  int64_t ws_cols, int km, int iv, int kord)
+{
+#define W_(arr, k) arr[(int64_t)((k)-1) * ws_cols]
+    float d4 = 0.f, qe_last;
+    {
+        const float grat = DP(2) / DP(1);
+        const float bet = grat * (grat + 0.5f);
+        W_(QE, 1) = ((grat + grat) * (grat + 1.f) * Q(1) + Q(2)) / bet;
+        W_(GAM, 1) = (1.f + grat * (grat + 1.5f)) / bet;
+    }
+    for (int k = 2; k <= km; ++k) {
+        d4 = DP(k - 1) / DP(k);
+        const float bet = 2.f + d4 + d4 - W_(GAM, k - 1);
+        W_(QE, k) = (3.f * (Q(k - 1) + d4 * Q(k)) - W_(QE, k - 1)) / bet;
+        W_(GAM, k) = d4 / bet;
+    }
+    {
+        const float a_bot = 1.f + d4 * (d4 + 1.5f);
+        qe_last = (2.f * d4 * (d4 + 1.f) * Q(km) + Q(km - 1) - a_bot * W_(QE, km)) / (d4 * (d4 + 0.5f) - a_bot * W_(GAM, km));
+    }
+    {
+        float below = qe_last;
+        for (int k = km; k >= 1; --k) {
+            below = W_(QE, k) - W_(GAM, k) * below;
+            W_(QE, k) = below;
+        }
+    }
+    auto QEK = [&](int k) { return k > km ? qe_last : W_(QE, k); };
+    if (kord > 16) {  // perfectly linear scheme
+        for (int k = 1; k <= km; ++k) {
+            const float al = QEK(k), ar = QEK(k + 1);
+            W_(AL, k) = al;
+            W_(AR, k) = ar;
+            W_(A6, k) = 3.f * (2.f * Q(k) - (al + ar));
+        }
+        return;
+    }
+    auto G = [&](int k) { return Q(k) - Q(k - 1); };  // gam(i,k) of the constraints, k = 2 .. km
+    auto bound = [&](float q, int k) {  // min(q, max(a1(k-1), a1(k))) then max(.., min(a1(k-1), a1(k)))
+        q = f_min2(q, f_max2(Q(k - 1), Q(k)));
+        return f_max2(q, f_min2(Q(k - 1), Q(k)));
+    };
+    W_(QE, 2) = bound(W_(QE, 2), 2);
+    for (int k = 3; k <= km - 1; ++k) {
+        float q = W_(QE, k);
+        const float gm = G(k - 1);
+        if (gm * G(k + 1) > 0.f) {
+            q = bound(q, k);
+        } else if (gm > 0.f) {  // a local maximum
+            q = f_max2(q, f_min2(Q(k - 1), Q(k)));
+        } else {                // a local minimum
+            q = f_min2(q, f_max2(Q(k - 1), Q(k)));
+            if (iv == 0) q = f_max2(0.f, q);
+        }
+        W_(QE, k) = q;
+    }
+    W_(QE, km) = bound(W_(QE, km), km);
+    for (int k = 1; k <= km; ++k) {
+        W_(AL, k) = QEK(k);
+        W_(AR, k) = QEK(k + 1);
+    }
+    const bool extm_top = (QEK(1) - Q(1)) * (QEK(2) - Q(1)) > 0.f, extm_bot = (QEK(km) - Q(km)) * (qe_last - Q(km)) > 0.f;
+    auto EXTM = [&](int k) { return k == 1 ? extm_top : k == km ? extm_bot : (G(k) * G(k + 1) < 0.f); };
+    auto EXT5 = [&](int k) {
+        const float l = QEK(k), r = QEK(k + 1);
+        return fabsf(2.f * Q(k) - (l + r)) > fabsf(l - r);
+    };
+    auto EXT6 = [&](int k) {
+        const float l = QEK(k), r = QEK(k + 1);
+        return fabsf(3.f * (2.f * Q(k) - (l + r))) > fabsf(l - r);
+    };
+    auto edges_a6 = [](float a1, float al, float ar) { return 3.f * (2.f * a1 - (al + ar)); };
+    auto huynh = [&](int k, float a1, float &al, float &ar) {
+        const float pmp_1 = a1 - 2.f * G(k + 1), lac_1 = pmp_1 + 1.5f * G(k + 2);
+        al = f_min2(f_max2(al, f_min3(a1, pmp_1, lac_1)), f_max3(a1, pmp_1, lac_1));
+        const float pmp_2 = a1 + 2.f * G(k), lac_2 = pmp_2 - 1.5f * G(k - 1);
+        ar = f_min2(f_max2(ar, f_min3(a1, pmp_2, lac_2)), f_max3(a1, pmp_2, lac_2));
+    };
+    auto store = [&](int k, float al, float ar, float a6) {
+        W_(AL, k) = al;
+        W_(AR, k) = ar;
+        W_(A6, k) = a6;
+    };
+    {   // top layer
+        const float a1 = Q(1);
+        float al = W_(AL, 1), ar = W_(AR, 1), a6 = 0.f;
+        if (iv == 0) {
+            al = f_max2(0.f, al);
+        } else if (iv == -1) {
+            if (al * a1 <= 0.f) al = 0.f;
+        } else if (iv == 2) {
+            al = a1;
+            ar = a1;
+        }
+        if (iv != 2) {
+            a6 = edges_a6(a1, al, ar);
+            cs_limiters1(extm_top, a1, al, ar, a6, 1);
+        }
+        store(1, al, ar, a6);
+    }
+    {   // k = 2
+        const float a1 = Q(2);
+        float al = W_(AL, 2), ar = W_(AR, 2), a6 = edges_a6(a1, al, ar);
+        cs_limiters1(EXTM(2), a1, al, ar, a6, 2);
+        store(2, al, ar, a6);
+    }
+    for (int k = 3; k <= km - 2; ++k) {
+        const float a1 = Q(k);
+        float al = W_(AL, k), ar = W_(AR, k), a6;
+        if (kord < 9) {
+            huynh(k, a1, al, ar);
+            a6 = edges_a6(a1, al, ar);
+        } else if (kord == 9 || kord == 12) {
+            if (kord == 9 ? (EXTM(k) && (EXTM(k - 1) || EXTM(k + 1))) : EXTM(k)) {  // a 2-delta-z wave
+                al = a1;
+                ar = a1;
+                a6 = 0.f;
+            } else {
+                a6 = 6.f * a1 - 3.f * (al + ar);
+                if (fabsf(a6) > fabsf(al - ar)) {  // not monotonic inside the smooth region
+                    huynh(k, a1, al, ar);
+                    a6 = 6.f * a1 - 3.f * (al + ar);
+                }
+            }
+        } else if (kord == 10 || kord == 16) {
+            if (EXT5(k)) {
+                if (EXT5(k - 1) || EXT5(k + 1)) {
+                    al = a1;
+                    ar = a1;
+                } else if (EXT6(k - 1) || EXT6(k + 1)) {
+                    huynh(k, a1, al, ar);
+                }
+            } else if (kord == 10 && EXT6(k)) {
+                if (EXT5(k - 1) || EXT5(k + 1)) huynh(k, a1, al, ar);
+            }
+            a6 = edges_a6(a1, al, ar);
+        } else if (kord == 13) {
+            if (EXT6(k) && EXT6(k - 1) && EXT6(k + 1)) {
+                al = a1;
+                ar = a1;
+            }
+            a6 = edges_a6(a1, al, ar);
+        } else if (kord == 14) {
+            a6 = edges_a6(a1, al, ar);
+        } else if (kord == 15) {
+            if (EXT5(k)) {
+                if (EXT5(k - 1) || EXT5(k + 1)) {
+                    al = a1;
+                    ar = a1;
+                }
+            } else if (EXT6(k)) {
+                huynh(k, a1, al, ar);
+            }
+            a6 = edges_a6(a1, al, ar);
+        } else {  // kord == 11
+            if (EXT5(k) && (EXT5(k - 1) || EXT5(k + 1))) {  // a noisy region
+                al = a1;
+                ar = a1;
+                a6 = 0.f;
+            } else {
+                a6 = edges_a6(a1, al, ar);
+            }
+        }
+        if (iv == 0) cs_limiters1(EXTM(k), a1, al, ar, a6, 0);
+        store(k, al, ar, a6);
+    }
+    {   // bottom two layers
+        float ar_km = W_(AR, km);
+        if (iv == 0) {
+            ar_km = f_max2(0.f, ar_km);
+        } else if (iv == -1) {
+            if (ar_km * Q(km) <= 0.f) ar_km = 0.f;
+        }
+        {
+            const float a1 = Q(km - 1);
+            float al = W_(AL, km - 1), ar = W_(AR, km - 1), a6 = edges_a6(a1, al, ar);
+            cs_limiters1(EXTM(km - 1), a1, al, ar, a6, 2);
+            store(km - 1, al, ar, a6);
+        }
+        const float a1 = Q(km);
+        float al = W_(AL, km), a6 = edges_a6(a1, al, ar_km);
+        cs_limiters1(extm_bot, a1, al, ar_km, a6, 1);
+        store(km, al, ar_km, a6);
+    }
+#undef W_
+}
+
+// One column, the Fortran control flow verbatim (all iv and kord, any input whatsoever).
 template <typename Tin>
 __device__ __noinline__ void mappm_column_exact(const Tin *__restrict__ pe1_, const Tin *__restrict__ q1_,
                                                 const Tin *__restrict__ pe2_, float *__restrict__ q2_,
@@ -275,6 +510,9 @@ __device__ __noinline__ void mappm_column_exact(const Tin *__restrict__ pe1_, co
 #define W_(arr, k) arr[(int64_t)((k)-1) * ws_cols]
 
     const int km1 = km - 1;
+    if (kord > 7) {
+        cs_profile_column(Q, DP, AL, AR, A6, DC, H2, ws_cols, km, iv, kord);
+    } else {
     // ---- ppm_profile (mappm.f90:651-683) ----
     for (int k = 2; k <= km1; ++k) {
         const float dpk = DP(k), d4k = D4(k), d4k1 = D4(k + 1);
@@ -383,6 +621,7 @@ __device__ __noinline__ void mappm_column_exact(const Tin *__restrict__ pe1_, co
         for (int k = 3; k <= km - 2; ++k) finish_level(k, lmt, kord != 4, kord != 6);
     }
     for (int k = km1; k <= km; ++k) finish_level(k, 0, true, true);
+    }  // kord <= 7
 
     // ---- remap (mappm.f90:58-124) ----
     const float r3 = 1.f / 3.f, r23 = 2.f / 3.f;
@@ -1320,8 +1559,8 @@ extern "C" int fv3hip_mappm(const void *pe1, const void *q1, const void *pe2, in
     FV3HIP_REQUIRE(layout == FV3HIP_LAYOUT_COL_LEVEL || layout == FV3HIP_LAYOUT_LEVEL_COL, "unknown layout %d", layout);
     FV3HIP_REQUIRE(n_batch >= 0 && n_inner >= 0 && kn >= 0, "negative extent");
     FV3HIP_REQUIRE(iv >= -2 && iv <= 2, "iv must be in [-2, 2], got %d", iv);
-    if (kord > 7)
-        return fail(FV3HIP_EUNSUPPORTED, "kord=%d selects cs_profile (mappm.f90:132-611), which is not implemented; kord <= 7 only", kord);
+    if (kord > 7 && iv == -2)
+        return fail(FV3HIP_EUNSUPPORTED, "kord=%d with iv=-2: cs_profile would read the array qs that mappm never sets (mappm.f90:34,51,152-176)", kord);
     FV3HIP_REQUIRE(km >= 4, "km must be >= 4 (ppm_profile reads a4(2,i,3)), got %d", km);
     if (layout == FV3HIP_LAYOUT_COL_LEVEL)
         FV3HIP_REQUIRE(n_inner == 1, "COL_LEVEL layout requires n_inner == 1");
@@ -1407,7 +1646,7 @@ extern "C" int fv3hip_mappm_multi(const void *pe1, const void *const *q1, const 
     FV3HIP_REQUIRE(n_fields >= 0, "negative field count");
     if (n_fields == 0) return FV3HIP_OK;
     FV3HIP_REQUIRE(q1 && q2, "null pointer");
-    if (kord > 6 || n_fields == 1) {  // kord 7 needs the sequential routine (and kord > 7 is refused there)
+    if (kord > 6 || n_fields == 1) {  // kord >= 7 goes through the sequential routine
         for (int f = 0; f < n_fields; ++f) {
             const int rc = fv3hip_mappm(pe1, q1[f], pe2, in_dtype, q2[f], n_batch, n_inner, km, kn, iv, kord, layout, arith, workspace,
                                         workspace_bytes, stream);

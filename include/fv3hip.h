@@ -298,7 +298,8 @@ int fv3hip_mask_weights_coarse(const void *weights, int w_dtype, const void *p_c
  *   COL_LEVEL: pe1 [ncol][km+1], q1 [ncol][km], pe2 [ncol][kn+1], q2 [ncol][kn]
  *              (n_batch = ncol, n_inner = 1)
  *   LEVEL_COL: pe1 [n_batch][km+1][n_inner], ... ; ncol = n_batch * n_inner
- * kord <= 7 only (ppm_profile); kord > 7 (cs_profile) returns FV3HIP_EUNSUPPORTED.
+ * Every kord: ppm_profile (kord <= 7) and cs_profile / cs_limiters (kord > 7, mappm.f90:132-611: schemes 8 .. 16 and the linear
+ * one above); kord > 7 with iv = -2 returns FV3HIP_EUNSUPPORTED (cs_profile would read the array qs that mappm never sets).
  * `arith`: FV3HIP_ARITH_EXACT or FV3HIP_ARITH_FAST (see above).
  * `workspace` must hold fv3hip_mappm_workspace_bytes(...) bytes of device memory; it carries the call's
  * list of columns to redo, so concurrent calls (other streams) need workspaces of their own.

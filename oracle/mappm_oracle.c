@@ -9,8 +9,11 @@
  *   external/mappm/mappm/mappm.f90:10-126    subroutine mappm
  *   external/mappm/mappm/mappm.f90:614-851   subroutine ppm_profile  (kord <= 7)
  *   external/mappm/mappm/mappm.f90:854-931   subroutine ppm_limiters
- * kord > 7 (cs_profile, mappm.f90:132-611) is not restated: callers only ever
- * pass iv=1, kord=1 (external/vcm/vcm/cubedsphere/regridz.py:227-228,296).
+ *   external/mappm/mappm/mappm.f90:132-529   subroutine cs_profile   (kord > 7)
+ *   external/mappm/mappm/mappm.f90:532-611   subroutine cs_limiters
+ * (callers only ever pass iv=1, kord=1, external/vcm/vcm/cubedsphere/regridz.py:227-228,296;
+ * kord > 7 with iv = -2 reads the array `qs` that mappm never sets, mappm.f90:34,51 and
+ * :152-176, and is refused here.)
  *
  * Arithmetic is written in the same association order as the Fortran source
  * (default REAL = real*4, `x**2` = x*x, left-to-right `*` and `/`) and this
@@ -38,6 +41,7 @@
 #define FV3_ORACLE_OK 0
 #define FV3_ORACLE_EKORD -1
 #define FV3_ORACLE_EKM -2
+#define FV3_ORACLE_EIV -4
 
 static inline float f_sign(float a, float b) { return copysignf(fabsf(a), b); }
 /* Fortran MIN/MAX as flang lowers them: a compare-and-select chain. */
@@ -95,6 +99,222 @@ static void ppm_limiters1(float dm, float *a1, float *a2, float *a3, float *a4, 
             }
         }
     }
+}
+
+/* mappm.f90:532-611; one column, one level.  mode = the routine's `iv` argument. */
+static void cs_limiters1(int extm, float a1, float *a2, float *a3, float *a4, int mode)
+{
+    const float r12 = 1.f / 12.f;
+    float da1, da2, a6da;
+    if (mode == 0) {
+        /* Positive definite constraint */
+        if (a1 <= 0.f) {
+            *a2 = a1;
+            *a3 = a1;
+            *a4 = 0.f;
+        } else if (fabsf(*a3 - *a2) < -*a4) {
+            if ((a1 + 0.25f * ((*a3 - *a2) * (*a3 - *a2)) / *a4 + *a4 * r12) < 0.f) {
+                /* local minimum is negative */
+                if (a1 < *a3 && a1 < *a2) {
+                    *a3 = a1;
+                    *a2 = a1;
+                    *a4 = 0.f;
+                } else if (*a3 > *a2) {
+                    *a4 = 3.f * (*a2 - a1);
+                    *a3 = *a2 - *a4;
+                } else {
+                    *a4 = 3.f * (*a3 - a1);
+                    *a2 = *a3 - *a4;
+                }
+            }
+        }
+        return;
+    }
+    if (mode == 1 ? ((a1 - *a2) * (a1 - *a3) >= 0.f) : extm) {
+        *a2 = a1;
+        *a3 = a1;
+        *a4 = 0.f;
+        return;
+    }
+    /* (mode 1 and the standard PPM constraint share the rest) */
+    da1 = *a3 - *a2;
+    da2 = da1 * da1;
+    a6da = *a4 * da1;
+    if (a6da < -da2) {
+        *a4 = 3.f * (*a2 - a1);
+        *a3 = *a2 - *a4;
+    } else if (a6da > da2) {
+        *a4 = 3.f * (*a3 - a1);
+        *a2 = *a3 - *a4;
+    }
+}
+
+/*
+ * mappm.f90:132-529 for one column (iv != -2).  1-based arrays of at least km+2 entries:
+ * a1 = a4(1,:) (the cell means, untouched), al / ar / a6 = a4(2:4,:), qe = the edge values
+ * q(1:km+1), gam = the tridiagonal's work array and then the differences of the means.
+ * ext holds three flags per level: bit 0 extm, bit 1 ext5, bit 2 ext6.
+ */
+static void cs_profile1(const float *a1, float *al, float *ar, float *a6, const float *delp, int km, int iv,
+                        int kord, float *qe, float *gam, int *ext)
+{
+    int k;
+    float grat, bet, d4 = 0.f, a_bot, pmp_1, lac_1, pmp_2, lac_2, x0, x1;
+
+    grat = delp[2] / delp[1];
+    bet = grat * (grat + 0.5f);
+    qe[1] = ((grat + grat) * (grat + 1.f) * a1[1] + a1[2]) / bet;
+    gam[1] = (1.f + grat * (grat + 1.5f)) / bet;
+    for (k = 2; k <= km; ++k) {
+        d4 = delp[k - 1] / delp[k];
+        bet = 2.f + d4 + d4 - gam[k - 1];
+        qe[k] = (3.f * (a1[k - 1] + d4 * a1[k]) - qe[k - 1]) / bet;
+        gam[k] = d4 / bet;
+    }
+    a_bot = 1.f + d4 * (d4 + 1.5f);
+    qe[km + 1] = (2.f * d4 * (d4 + 1.f) * a1[km] + a1[km - 1] - a_bot * qe[km]) / (d4 * (d4 + 0.5f) - a_bot * gam[km]);
+    for (k = km; k >= 1; --k) qe[k] = qe[k] - gam[k] * qe[k + 1];
+
+    if (kord > 16) { /* perfectly linear scheme */
+        for (k = 1; k <= km; ++k) {
+            al[k] = qe[k];
+            ar[k] = qe[k + 1];
+            a6[k] = 3.f * (2.f * a1[k] - (al[k] + ar[k]));
+        }
+        return;
+    }
+
+    /* large-scale constraints */
+    qe[2] = f_min2(qe[2], f_max2(a1[1], a1[2]));
+    qe[2] = f_max2(qe[2], f_min2(a1[1], a1[2]));
+    for (k = 2; k <= km; ++k) gam[k] = a1[k] - a1[k - 1];
+    for (k = 3; k <= km - 1; ++k) {
+        if (gam[k - 1] * gam[k + 1] > 0.f) {
+            qe[k] = f_min2(qe[k], f_max2(a1[k - 1], a1[k]));
+            qe[k] = f_max2(qe[k], f_min2(a1[k - 1], a1[k]));
+        } else if (gam[k - 1] > 0.f) { /* a local maximum */
+            qe[k] = f_max2(qe[k], f_min2(a1[k - 1], a1[k]));
+        } else { /* a local minimum */
+            qe[k] = f_min2(qe[k], f_max2(a1[k - 1], a1[k]));
+            if (iv == 0) qe[k] = f_max2(0.f, qe[k]);
+        }
+    }
+    qe[km] = f_min2(qe[km], f_max2(a1[km - 1], a1[km]));
+    qe[km] = f_max2(qe[km], f_min2(a1[km - 1], a1[km]));
+
+    for (k = 1; k <= km; ++k) {
+        al[k] = qe[k];
+        ar[k] = qe[k + 1];
+    }
+    for (k = 1; k <= km; ++k) {
+        ext[k] = (k == 1 || k == km) ? ((al[k] - a1[k]) * (ar[k] - a1[k]) > 0.f) : (gam[k] * gam[k + 1] < 0.f);
+        if (kord > 9) {
+            x0 = 2.f * a1[k] - (al[k] + ar[k]);
+            x1 = fabsf(al[k] - ar[k]);
+            a6[k] = 3.f * x0;
+            if (fabsf(x0) > x1) ext[k] |= 2;
+            if (fabsf(a6[k]) > x1) ext[k] |= 4;
+        }
+    }
+#define EXTM(k) (ext[k] & 1)
+#define EXT5(k) (ext[k] & 2)
+#define EXT6(k) (ext[k] & 4)
+#define A6_FROM_EDGES(k) a6[k] = 3.f * (2.f * a1[k] - (al[k] + ar[k]))
+#define HUYNH(k)                                                                              \
+    do {                                                                                      \
+        pmp_1 = a1[k] - 2.f * gam[k + 1];                                                     \
+        lac_1 = pmp_1 + 1.5f * gam[k + 2];                                                    \
+        al[k] = f_min2(f_max2(al[k], f_min3(a1[k], pmp_1, lac_1)), f_max3(a1[k], pmp_1, lac_1)); \
+        pmp_2 = a1[k] + 2.f * gam[k];                                                         \
+        lac_2 = pmp_2 - 1.5f * gam[k - 1];                                                    \
+        ar[k] = f_min2(f_max2(ar[k], f_min3(a1[k], pmp_2, lac_2)), f_max3(a1[k], pmp_2, lac_2)); \
+    } while (0)
+#define FLAT(k)        \
+    do {               \
+        al[k] = a1[k]; \
+        ar[k] = a1[k]; \
+    } while (0)
+
+    /* subgrid constraints: the top two and the bottom two layers always use the monotonic mapping */
+    if (iv == 0) {
+        al[1] = f_max2(0.f, al[1]);
+    } else if (iv == -1) {
+        if (al[1] * a1[1] <= 0.f) al[1] = 0.f;
+    } else if (iv == 2) {
+        FLAT(1);
+        a6[1] = 0.f;
+    }
+    if (iv != 2) {
+        A6_FROM_EDGES(1);
+        cs_limiters1(EXTM(1), a1[1], &al[1], &ar[1], &a6[1], 1);
+    }
+    A6_FROM_EDGES(2);
+    cs_limiters1(EXTM(2), a1[2], &al[2], &ar[2], &a6[2], 2);
+
+    for (k = 3; k <= km - 2; ++k) {
+        if (kord < 9) {
+            HUYNH(k);
+            A6_FROM_EDGES(k);
+        } else if (kord == 9 || kord == 12) {
+            if (kord == 9 ? (EXTM(k) && (EXTM(k - 1) || EXTM(k + 1))) : EXTM(k)) { /* a 2-delta-z wave */
+                FLAT(k);
+                a6[k] = 0.f;
+            } else {
+                a6[k] = 6.f * a1[k] - 3.f * (al[k] + ar[k]);
+                if (fabsf(a6[k]) > fabsf(al[k] - ar[k])) { /* not monotonic inside the smooth region */
+                    HUYNH(k);
+                    a6[k] = 6.f * a1[k] - 3.f * (al[k] + ar[k]);
+                }
+            }
+        } else if (kord == 10 || kord == 16) {
+            if (EXT5(k)) {
+                if (EXT5(k - 1) || EXT5(k + 1)) {
+                    FLAT(k);
+                } else if (EXT6(k - 1) || EXT6(k + 1)) {
+                    HUYNH(k);
+                }
+            } else if (kord == 10 && EXT6(k)) {
+                if (EXT5(k - 1) || EXT5(k + 1)) HUYNH(k);
+            }
+            A6_FROM_EDGES(k);
+        } else if (kord == 13) {
+            if (EXT6(k) && EXT6(k - 1) && EXT6(k + 1)) FLAT(k);
+            A6_FROM_EDGES(k);
+        } else if (kord == 14) {
+            A6_FROM_EDGES(k);
+        } else if (kord == 15) {
+            if (EXT5(k)) {
+                if (EXT5(k - 1) || EXT5(k + 1)) FLAT(k);
+            } else if (EXT6(k)) {
+                HUYNH(k);
+            }
+            A6_FROM_EDGES(k);
+        } else { /* kord == 11 */
+            if (EXT5(k) && (EXT5(k - 1) || EXT5(k + 1))) { /* a noisy region */
+                FLAT(k);
+                a6[k] = 0.f;
+            } else {
+                A6_FROM_EDGES(k);
+            }
+        }
+        if (iv == 0) cs_limiters1(EXTM(k), a1[k], &al[k], &ar[k], &a6[k], 0);
+    }
+
+    if (iv == 0) {
+        ar[km] = f_max2(0.f, ar[km]);
+    } else if (iv == -1) {
+        if (ar[km] * a1[km] <= 0.f) ar[km] = 0.f;
+    }
+    A6_FROM_EDGES(km - 1);
+    cs_limiters1(EXTM(km - 1), a1[km - 1], &al[km - 1], &ar[km - 1], &a6[km - 1], 2);
+    A6_FROM_EDGES(km);
+    cs_limiters1(EXTM(km), a1[km], &al[km], &ar[km], &a6[km], 1);
+#undef EXTM
+#undef EXT5
+#undef EXT6
+#undef A6_FROM_EDGES
+#undef HUYNH
+#undef FLAT
 }
 
 /*
@@ -310,16 +530,17 @@ static void remap_column(int km, const float *pe1, const float *q1, int kn, cons
  * (level fastest), i.e. the C-order arrays the reference's Python caller
  * passes to f2py (external/vcm/vcm/cubedsphere/regridz.py:326-334).
  *   pe1: [ncol][km+1], q1: [ncol][km], pe2: [ncol][kn+1], q2: [ncol][kn]
- * Returns 0, or a negative error code (unsupported kord, km < 4).
+ * Returns 0, or a negative error code (km < 4; kord > 7 with iv = -2).
  */
 int fv3_oracle_mappm(const float *pe1, const float *q1, const float *pe2, float *q2, long ncol,
                      int km, int kn, int iv, int kord)
 {
-    if (kord > 7) return FV3_ORACLE_EKORD;
+    if (kord > 7 && iv == -2) return FV3_ORACLE_EIV;
     if (km < 4) return FV3_ORACLE_EKM;
     const int n = km + 3;
-    float *buf = (float *)malloc(sizeof(float) * (size_t)n * 12 + sizeof(float) * (size_t)(kn + 3) * 2);
+    float *buf = (float *)malloc(sizeof(float) * (size_t)n * 12 + sizeof(float) * (size_t)(kn + 3) * 2 + sizeof(int) * (size_t)n);
     if (!buf) return -3;
+    int *ext = (int *)(buf + (size_t)n * 12 + (size_t)(kn + 3) * 2);
     float *p1 = buf, *q = p1 + n, *dp = q + n, *al = dp + n, *ar = al + n, *a6 = ar + n,
           *dc = a6 + n, *h2 = dc + n, *delq = h2 + n, *df2 = delq + n, *d4 = df2 + n;
     float *p2 = d4 + n, *o = p2 + (kn + 3);
@@ -329,7 +550,10 @@ int fv3_oracle_mappm(const float *pe1, const float *q1, const float *pe2, float 
         for (int k = 1; k <= km; ++k) q[k] = q1[i * km + (k - 1)];
         for (int k = 1; k <= kn + 1; ++k) p2[k] = pe2[i * (kn + 1) + (k - 1)];
         for (int k = 1; k <= km; ++k) dp[k] = p1[k + 1] - p1[k];
-        ppm_profile1(q, al, ar, a6, dp, km, iv, kord, dc, h2, delq, df2, d4);
+        if (kord > 7)
+            cs_profile1(q, al, ar, a6, dp, km, iv, kord, h2, dc, ext);
+        else
+            ppm_profile1(q, al, ar, a6, dp, km, iv, kord, dc, h2, delq, df2, d4);
         remap_column(km, p1, q, kn, p2, o, dp, al, ar, a6);
         for (int k = 1; k <= kn; ++k) q2[i * kn + (k - 1)] = o[k];
     }
@@ -341,11 +565,12 @@ int fv3_oracle_mappm(const float *pe1, const float *q1, const float *pe2, float 
 int fv3_oracle_ppm_profile(const float *pe1, const float *q1, float *al_out, float *ar_out,
                            float *a6_out, long ncol, int km, int iv, int kord)
 {
-    if (kord > 7) return FV3_ORACLE_EKORD;
+    if (kord > 7 && iv == -2) return FV3_ORACLE_EIV;
     if (km < 4) return FV3_ORACLE_EKM;
     const int n = km + 3;
-    float *buf = (float *)malloc(sizeof(float) * (size_t)n * 12);
+    float *buf = (float *)malloc(sizeof(float) * (size_t)n * 12 + sizeof(int) * (size_t)n);
     if (!buf) return -3;
+    int *ext = (int *)(buf + (size_t)n * 12);
     float *p1 = buf, *q = p1 + n, *dp = q + n, *al = dp + n, *ar = al + n, *a6 = ar + n,
           *dc = a6 + n, *h2 = dc + n, *delq = h2 + n, *df2 = delq + n, *d4 = df2 + n;
     for (long i = 0; i < ncol; ++i) {
@@ -353,7 +578,10 @@ int fv3_oracle_ppm_profile(const float *pe1, const float *q1, float *al_out, flo
         for (int k = 1; k <= km + 1; ++k) p1[k] = pe1[i * (km + 1) + (k - 1)];
         for (int k = 1; k <= km; ++k) q[k] = q1[i * km + (k - 1)];
         for (int k = 1; k <= km; ++k) dp[k] = p1[k + 1] - p1[k];
-        ppm_profile1(q, al, ar, a6, dp, km, iv, kord, dc, h2, delq, df2, d4);
+        if (kord > 7)
+            cs_profile1(q, al, ar, a6, dp, km, iv, kord, h2, dc, ext);
+        else
+            ppm_profile1(q, al, ar, a6, dp, km, iv, kord, dc, h2, delq, df2, d4);
         for (int k = 1; k <= km; ++k) {
             al_out[i * km + (k - 1)] = al[k];
             ar_out[i * km + (k - 1)] = ar[k];

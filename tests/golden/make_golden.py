@@ -71,6 +71,30 @@ def make_mappm():
             q = np.round(q)
         for iv, kord in [(1, 1), (0, 7), (-1, 4)]:
             add(pe1, q, pe2, iv, kord)
+    # kord > 7: cs_profile / cs_limiters, every scheme, noise / smooth / tied / NaN-holed columns (its own generator, so that
+    # the cases above stay what they were)
+    rng = np.random.default_rng(2025)
+    for kord in range(8, 19):
+        for iv in (-1, 0, 1, 2):
+            km, kn, ncol = [(79, 79, 24), (30, 41, 24), (7, 12, 16), (4, 9, 16)][(kord + iv) % 4]
+            kind = ["noise", "smooth", "ties", "nans"][(kord + 2 * iv) % 4]
+            dp1 = rng.uniform(300, 1500, (ncol, km))
+            pe1 = np.concatenate([np.full((ncol, 1), 300.0), 300 + np.cumsum(dp1, 1)], 1).astype(np.float32)
+            pe2 = np.concatenate([np.full((ncol, 1), rng.choice([100.0, 300.0, 500.0])), 300 + np.cumsum(rng.uniform(300, 1500, (ncol, kn)), 1)],
+                                 1).astype(np.float32)
+            z = np.linspace(0, 1, km)[None, :]
+            if kind == "noise":
+                q = rng.uniform(-1000, 1000, (ncol, km))
+            elif kind == "smooth":
+                q = 300 * np.sin(2 * np.pi * (z * rng.uniform(0.5, 3, (ncol, 1)) + rng.uniform(0, 1, (ncol, 1))))
+                q = q + rng.normal(0, 1, (ncol, km)) * (rng.random((ncol, km)) < 0.1)
+            else:
+                q = np.round(rng.uniform(-3, 3, (ncol, km)))
+                if kind == "nans":
+                    q[rng.random((ncol, km)) < 0.03] = np.nan
+            if iv == 0:
+                q = np.abs(q) if kind != "smooth" else q + 250
+            add(pe1, q.astype(np.float32), pe2, iv, kord)
     cases["n_cases"] = np.array(n)
     np.savez_compressed(os.path.join(HERE, "mappm_reference.npz"), **cases)
     print("mappm cases:", n)

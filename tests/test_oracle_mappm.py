@@ -41,7 +41,7 @@ def test_reference_known_answers():
 def test_golden_vectors_from_reference_fortran_bit_exact():
     z = np.load(GOLDEN)
     n = int(z["n_cases"])
-    assert n >= 60
+    assert n >= 100 and {int(z[f"case{i}_ivkord"][1]) for i in range(n)} >= set(range(1, 18))
     for i in range(n):
         iv, kord = (int(v) for v in z[f"case{i}_ivkord"])
         got = mappm_c.mappm(z[f"case{i}_pe1"], z[f"case{i}_q1"], z[f"case{i}_pe2"], iv, kord)
@@ -61,10 +61,36 @@ def test_against_compiled_reference_bit_exact(iv):
         assert bits_equal(mappm_c.mappm(pe1, q, pe2, iv, kord), mappm_c.reference_mappm(pe1, q, pe2, iv, kord)), kord
 
 
+@pytest.mark.skipif(not mappm_c.have_reference(), reason="oracle/_ref is only built where /root/reference is mounted")
+@pytest.mark.parametrize("iv", [-1, 0, 1, 2])
+def test_cs_profile_against_compiled_reference_bit_exact(iv):
+    """kord > 7 (cs_profile / cs_limiters, mappm.f90:132-611): schemes 8 .. 16 and the linear one above, on noise, smooth
+    profiles, ties and NaNs, short and long columns."""
+    rng = np.random.default_rng(iv + 50)
+    for kord in range(8, 19):
+        for km, kn, ncol in ((79, 79, 256), (4, 9, 64), (5, 5, 64), (7, 12, 64), (30, 41, 128)):
+            pe1 = np.concatenate([np.full((ncol, 1), 300.0), 300 + np.cumsum(rng.uniform(300, 1500, (ncol, km)), 1)], 1)
+            pe2 = np.concatenate([np.full((ncol, 1), rng.choice([100.0, 300.0, 500.0])), 300 + np.cumsum(rng.uniform(300, 1500, (ncol, kn)), 1)], 1)
+            z = np.linspace(0, 1, km)[None, :]
+            for kind in ("noise", "smooth", "ties", "nans"):
+                if kind == "noise":
+                    q = rng.uniform(-1000, 1000, (ncol, km))
+                elif kind == "smooth":
+                    q = 300 * np.sin(2 * np.pi * (z * rng.uniform(0.5, 3, (ncol, 1)) + rng.uniform(0, 1, (ncol, 1))))
+                    q = q + rng.normal(0, 1, (ncol, km)) * (rng.random((ncol, km)) < 0.1)
+                else:
+                    q = np.round(rng.uniform(-3, 3, (ncol, km)))
+                    if kind == "nans":
+                        q[rng.random((ncol, km)) < 0.03] = np.nan
+                if iv == 0:
+                    q = np.abs(q) if kind != "smooth" else q + 250
+                assert bits_equal(mappm_c.mappm(pe1, q, pe2, iv, kord), mappm_c.reference_mappm(pe1, q, pe2, iv, kord)), (kord, km, kind)
+
+
 def test_unsupported_kord_and_short_columns():
     z = np.zeros((2, 8))
-    with pytest.raises(ValueError):
-        mappm_c.mappm(z, np.zeros((2, 7)), z, 1, 9)
+    with pytest.raises(ValueError):  # cs_profile with iv = -2 reads an array mappm never sets
+        mappm_c.mappm(z, np.zeros((2, 7)), z, -2, 9)
     with pytest.raises(ValueError):
         mappm_c.mappm(np.zeros((2, 4)), np.zeros((2, 3)), np.zeros((2, 4)), 1, 1)
 
