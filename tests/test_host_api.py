@@ -32,8 +32,11 @@ def test_library_reports_errors_without_touching_the_gpu():
     rc = lib.fv3hip_weighted_block_average(None, 7, None, 0, 1, 4, 4, 1, 2, None, None)
     assert rc == _lib.EINVAL
     assert b"dtype" in lib.fv3hip_last_error()
-    rc = lib.fv3hip_mappm(None, None, None, 0, None, 1, 1, 79, 79, 1, 9, 0, 0, None, 0, None)
+    # kord > 7 is served (cs_profile); only its iv = -2 branch, which reads the array mappm never sets, is refused
+    rc = lib.fv3hip_mappm(None, None, None, 0, None, 1, 1, 79, 79, -2, 9, 0, 0, None, 0, None)
     assert rc == _lib.EUNSUPPORTED and b"cs_profile" in lib.fv3hip_last_error()
+    rc = lib.fv3hip_mappm(None, None, None, 0, None, 1, 1, 79, 79, 1, 9, 0, 0, None, 0, None)
+    assert rc == _lib.EINVAL and b"null pointer" in lib.fv3hip_last_error()
 
 
 @pytest.mark.skipif(torch.cuda.is_available(), reason="checks the no-GPU behaviour")
