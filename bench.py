@@ -416,6 +416,43 @@ def remap_benchmark(dev, steps):
     return out
 
 
+def block_mean_benchmark(dev, steps):
+    """The opt-in fused remap + masked block mean (fv3hip_mappm_block_mean; FV3NET_AMD_FUSED_BLOCK_MEAN=1 in the pipelines)
+    beside the three launches it replaces, 4 float64 fields, on both data sets: one entry, times in ms."""
+    from fv3net_amd import ops
+
+    n, ncol = 384, 6 * 384 * 384
+    reps = max(3, min(steps, 10))
+    table = {}
+    for data_label, noise in (("configs[2] data (iid delp)", 1.0), ("smooth delp (a tenth of the spread)", 0.1)):
+        g = torch.Generator(device=dev).manual_seed(0)
+        delp = 900 + (torch.rand((6, NZ, n, n), device=dev, generator=g, dtype=torch.float64) - 0.5) * 1200 * noise
+        area = (torch.rand((6, n, n), device=dev, generator=g, dtype=torch.float64) * 0.5 + 0.5).float()
+        pe1 = ops.pressure_at_interface(delp, 300.0, 1)
+        pe2c = ops.pressure_at_interface(ops.weighted_block_average(delp, area, 8), 300.0, 1)
+        qs = [torch.rand((6, NZ, n, n), device=dev, generator=g, dtype=torch.float64) * 2000 - 1000 for _ in range(4)]
+
+        def three_calls(arith):
+            q2 = ops.mappm_multi_coarse_target(pe1, qs, pe2c, 8, z_axis=1, arith=arith)
+            return ops.weighted_block_average_multi(q2, ops.mask_weights(area, pe2c, pe1, 1, coarse_factor=8), 8)
+
+        for arith in ("exact", "fast"):
+            fused, plain = (lambda: ops.mappm_block_mean(pe1, qs, pe2c, area, arith=arith)), (lambda: three_calls(arith))
+            same = all(torch.equal(a, b) for a, b in zip(fused(), plain()))
+            torch.cuda.synchronize(dev)
+            table[f"{data_label}, arith={arith}"] = {"fused_ms": time_kernel(fused, reps, dev), "three_calls_ms": time_kernel(plain, reps, dev),
+                                                    "bit_identical": bool(same)}
+        del delp, pe1, pe2c, qs
+        torch.cuda.empty_cache()
+    alg = ncol * ((NZ + 1) * 8 + 4 * NZ * 8 + 4)
+    best = min(v["fused_ms"] for v in table.values())
+    return [{"kernel": "mappm_sweep_kernel<double, 2, 2, *, true, MEAN> + mean_rest_kernel (opt-in fused remap + masked 8x8 block mean)",
+             "workload": "C384 -> C48: 884736 columns x 4 float64 fields, km=kn=79, against mappm_multi_coarse_target + mask_weights + weighted_block_average",
+             "ms": best, "calls": table,
+             "roofline": {"bound": "hbm", "achieved": alg / best / 1e6, "peak": PEAK_HBM_GBPS, "unit": "GB/s", "frac": alg / best / 1e6 / PEAK_HBM_GBPS,
+                          "traffic": None, "note": "fastest of the four fused calls; inputs only (the fine result is never written)"}}]
+
+
 def pipelines_benchmark(dev):
     """The three restart pipelines end to end, in the remap's exact arithmetic (the library default) and in the fast one."""
     from fv3net_amd import ops
@@ -444,6 +481,7 @@ def secondary_benchmarks(dev, steps):
     _guarded(out, streaming_benchmark, dev)                        # PCIe-inclusive
     _guarded(out, io_pipeline_benchmark, dev)                      # file I/O inclusive
     _guarded(out, rank_latency_benchmark, dev)                     # one model rank's columns per call
+    _guarded(out, block_mean_benchmark, dev, steps)                # opt-in fused remap + block mean
     _guarded(out, plain_network_benchmark, dev, steps)
     _guarded(out, wavg_benchmark, dev, steps, "C384->C48", 384)
     _guarded(out, remap_benchmark, dev, steps)

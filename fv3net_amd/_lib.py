@@ -124,6 +124,9 @@ SIGNATURES = {
                                    c_int, c_int, c_void_p, c_size_t, c_void_p]),
     "fv3hip_mappm_multi_coarse_target": (c_int, [c_void_p, c_void_p, c_void_p, c_int, c_void_p, c_int, c_int64, c_int, c_int, c_int, c_int, c_int,
                                                  c_int, c_int, c_int, c_void_p, c_size_t, c_void_p]),
+    "fv3hip_mappm_block_mean_workspace_bytes": (c_size_t, [c_int64, c_int]),
+    "fv3hip_mappm_block_mean": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_void_p, c_int64, c_void_p, c_void_p,
+                                        c_int, c_int64, c_int, c_int, c_int, c_int, c_int, c_int, c_int, c_int, c_void_p, c_size_t, c_void_p]),
     "fv3hip_mask_weights_coarse": (c_int, [c_void_p, c_int, c_void_p, c_int, c_int, c_void_p, c_int, c_int64, c_int, c_int, c_int, c_int,
                                            c_int64, c_void_p, c_void_p]),
     "fv3hip_level_scale": (c_int, [c_void_p, c_int, c_void_p, c_int64, c_int, c_int64, c_void_p, c_void_p]),

@@ -142,9 +142,102 @@ constexpr int kSweepRing = 16;
 // (occupancy, or the modulo by 12), 16 rows lost everywhere.
 template <typename Tin, int NF, bool FAST> constexpr int sweep_out_rows() { return (sizeof(Tin) == 8 && NF == 4 && FAST) ? 12 : 8; }
 
-template <typename Tin, int NV, int W, bool FAST, bool TGT>
+// ---- MEAN: the fused remap + masked 8 x 8 block mean (fv3hip_mappm_block_mean) ----
+// What the restart pipelines do with a remapped field is average it at once over the 8 x 8 blocks of the coarse grid, with the
+// area masked where the coarse layer lies below the fine surface (regridz.py:149-220, coarsen_restarts.py:483-495, 940-961).
+// With a wave's 64 lanes on ONE block the target grid is the wave's own coarse column, and a finished target row need not
+// leave the chip: lane l parks p = q2 * w (w = area_l or 0) in its column of an LDS ring, and once every lane is past four
+// rows the wave sums them -- 32 lanes, each over one half-row of one (row, field) in the order of wavg_block_kernel /
+// mass_wavg_block_kernel (coarsen.hip: dy = 0..7, x = 0..3 | 4..7, then the two halves), so the result is bit-identical to
+// mask_weights + weighted_block_average of the unfused route -- divides by the row's sum of weights and writes NF x 4 floats.
+// No 4-byte scatter of result rows (what the sweep kernel loses a fifth of its time to on BASELINE configs[2]'s data, see
+// DESIGN 4.3b), no fine-size q2 written and read back, no masked-weights array.
+// A ring line is one (row, field): 64 values in half-major order (pos = (x >> 2) * 32 + y * 4 + (x & 3)) so that a summing lane
+// reads its 32 values as eight ds_read_b128; lines are 68 floats apart, which spreads the 16 lines of a group over the banks.
+// A lane that runs kOut rows ahead of the slowest evicts its own oldest value to the fine-size scratch q2[] and the flush
+// brings it back -- same value, same sum.  A block with an ill-formed column is listed and redone (mean_redo_kernel).
+constexpr int kMeanStride = 68;
+constexpr int kMeanGroup = 4;   // rows per flush
+#ifndef MEAN_KOUT
+#define MEAN_KOUT 8
+#endif
+template <typename Tin, int NF, bool FAST> constexpr int mean_out_rows() { return MEAN_KOUT; }   // a multiple of kMeanGroup
+__host__ __device__ constexpr int mean_n1(int kn) { return (kn + 2 + 3) & ~3; }   // kn + 1 interfaces and one spare word (the spill flag)
+__host__ __device__ constexpr int mean_nl(int kn, int esz) { return ((kn * esz + 15) & ~15) / 4; }
+// LDS of a MEAN wave, in floats: [target interfaces: n1][compared levels: kn of Tin][row weight sums: n1][ring]
+__host__ __device__ constexpr int mean_tab_floats(int kn, int esz) { return 2 * mean_n1(kn) + mean_nl(kn, esz); }
+
+__device__ __forceinline__ int mean_pos(int lane) { return ((lane & 4) << 3) | ((lane >> 3) << 2) | (lane & 3); }
+__device__ __forceinline__ bool f_isnan(float x) { return x != x; }
+
+// The tables of one block: compared levels -> lvl[0..kn), the block's row weight sums -> den[0..kn).  `tmp` (64 floats + 64 Tin,
+// the ring's first bytes) holds the lanes' areas and surface pressures in half-major order while the sums are formed.
+template <typename Tin>
+__device__ __forceinline__ void mean_tables(const char *lvl_col, unsigned int row_p2, int cmp_offset, int kn, int lane, float area_l,
+                                            Tin ps_raw, Tin *lvl, float *den, float *tmp)
+{
+#pragma unroll
+    for (int j = 0; j < 2; ++j) {
+        const int i = lane + 64 * j;
+        const Tin x = *reinterpret_cast<const Tin *>(lvl_col + (size_t)((i < kn ? i : kn - 1) + cmp_offset) * row_p2);
+        if (i < kn) lvl[i] = x;
+    }
+    float *tA = tmp;
+    Tin *tP = reinterpret_cast<Tin *>(tmp + 64);
+    const int pos = mean_pos(lane);
+    tA[pos] = area_l;
+    tP[pos] = ps_raw;
+    const int half = lane & 1;
+    for (int r0 = 0; r0 < kn; r0 += 32) {
+        const int r = r0 + (lane >> 1);
+        const Tin lv = lvl[r < kn ? r : kn - 1];
+        float s = 0.f;
+#pragma unroll 8
+        for (int t = 0; t < 32; ++t) {
+            const float w0 = (lv < tP[half * 32 + t]) ? tA[half * 32 + t] : 0.f;   // regridz.py:209-220
+            s += f_isnan(w0) ? 0.f : w0;
+        }
+        s += __shfl_xor(s, 1);
+        if (r < kn && half == 0) den[r] = s;
+    }
+}
+
+// Rows [row0, row0 + nrows) (nrows <= kMeanGroup) of NF fields, parked in the lines (slot0 + i) * NF + f of `ring`: their masked
+// block means to mean[f][row * plane2].
+template <int NF>
+__device__ __forceinline__ void mean_reduce(const float *ring, int slot0, int row0, int nrows, const float *den, float *const (&mean)[4],
+                                            int64_t plane2, int lane)
+{
+    const int pair = lane >> 1, half = lane & 1, ri = pair / NF, f = pair - ri * NF;
+    const bool act = ri < nrows;   // (ri < kMeanGroup follows: nrows <= kMeanGroup)
+    const float *src = ring + ((slot0 + (act ? ri : 0)) * NF + f) * kMeanStride + half * 32;
+    typedef float f32x4 __attribute__((ext_vector_type(4)));
+    float s = 0.f;
+#pragma unroll
+    for (int h = 0; h < 2; ++h) {  // (two batches of four reads: 16 registers in flight, not 32 -- the call sits inside the sweep's loop)
+        f32x4 v[4];
+#pragma unroll
+        for (int t = 0; t < 4; ++t) v[t] = *reinterpret_cast<const f32x4 *>(src + 16 * h + 4 * t);
+#pragma unroll
+        for (int t = 0; t < 4; ++t) {
+            s += v[t][0];
+            s += v[t][1];
+            s += v[t][2];
+            s += v[t][3];
+        }
+    }
+    s += __shfl_xor(s, 1);
+    if (act && half == 0) {
+        const int row = row0 + ri;
+        float *m = (f == 0) ? mean[0] : (f == 1) ? mean[1] : (f == 2) ? mean[2] : mean[3];
+        m[(int64_t)row * plane2] = s / den[row];
+    }
+}
+
+template <typename Tin, int NV, int W, bool FAST, bool TGT, bool MEAN = false>
 __global__ __launch_bounds__(64) void mappm_sweep_kernel(const SweepArgs a)
 {
+    static_assert(!MEAN || TGT, "the fused block mean keeps its (single) target column in LDS");
     using V = typename FieldVec<W>::type;
     constexpr int NF = NV * W;
     constexpr unsigned int ESZ = sizeof(Tin);
@@ -152,8 +245,22 @@ __global__ __launch_bounds__(64) void mappm_sweep_kernel(const SweepArgs a)
     // Workgroups go round-robin over the 8 XCDs (each with its own L2): give every XCD a contiguous eighth of the waves, so
     // the waves resident on one XCD at a time read neighbouring 256 / 512-byte pieces of a row.
     const unsigned int nwg = gridDim.x, wid = (nwg % 8u == 0u) ? (blockIdx.x % 8u) * (nwg / 8u) + blockIdx.x / 8u : blockIdx.x;
-    const int64_t wcol = a.col0 + (int64_t)wid * 64;  // first column of the wave (uniform)
-    const int64_t b = wcol / a.n_inner, c0 = wcol - b * a.n_inner;
+    int64_t b, c0;          // batch and first column (inside the batch plane) of the wave, uniform
+    unsigned int lcol;      // the lane's column, counted from c0
+    int64_t blk = 0;        // (MEAN) the wave's block inside the coarse plane
+    if constexpr (MEAN) {
+        const int64_t gw = a.col0 / 64 + wid;
+        b = gw / a.pe2_plane;
+        blk = gw - b * a.pe2_plane;
+        const int64_t Y = blk / a.pe2_nx, X = blk - Y * a.pe2_nx;
+        c0 = Y * 8 * a.nx + X * 8;
+        lcol = (unsigned int)(lane >> 3) * (unsigned int)a.nx + (unsigned int)(lane & 7);
+    } else {
+        const int64_t wcol = a.col0 + (int64_t)wid * 64;
+        b = wcol / a.n_inner;
+        c0 = wcol - b * a.n_inner;
+        lcol = (unsigned int)lane;
+    }
     const int km = a.km, kn = a.kn, iv = a.iv;
     const int64_t plane = a.n_inner;
     // uniform row bases of the wave's batch, first column of the wave
@@ -170,7 +277,7 @@ __global__ __launch_bounds__(64) void mappm_sweep_kernel(const SweepArgs a)
         q1_row[f] = static_cast<const char *>(a.q1[f]) + (b * km * plane + c0) * ESZ;
         q2_b[f] = reinterpret_cast<char *>(a.q2[f]) + (b * kn * plane + c0) * 4;
     }
-    const unsigned int lin = (unsigned int)lane * ESZ;     // lane offset inside a source row
+    const unsigned int lin = lcol * ESZ;                    // lane offset inside a source row
     const unsigned int row_in = (unsigned int)plane * ESZ;  // bytes between levels of the inputs (host: < 2^32 / levels)
     const unsigned int row_out = (unsigned int)plane * 4u;
     const float r3 = 1.f / 3.f, r23 = 2.f / 3.f;
@@ -185,7 +292,8 @@ __global__ __launch_bounds__(64) void mappm_sweep_kernel(const SweepArgs a)
     // ---- head of the column: pe1(1..5), q1(1..4) ----
     float pe_a = ld<Tin>(pe1_row, lin), pe_b = ld<Tin>(pe1_row + row_in, lin), pe_c = ld<Tin>(pe1_row + 2 * (size_t)row_in, lin),
           pe_d = ld<Tin>(pe1_row + 3 * (size_t)row_in, lin), pe_e = ld<Tin>(pe1_row + 4 * (size_t)row_in, lin);
-    const float pe1_top = pe_a, pe1_bot = ld<Tin>(pe1_row + (size_t)km * row_in, lin);
+    const Tin ps_raw = *reinterpret_cast<const Tin *>(pe1_row + (size_t)km * row_in + lin);  // (MEAN compares it in the input type)
+    const float pe1_top = pe_a, pe1_bot = (float)ps_raw;
     pe1_row += 5 * (size_t)row_in;  // -> pe1(6)
     V q0[NV], qp1[NV], qp2[NV], qp3[NV], q_top[NV], q_bot[NV];
 #pragma unroll
@@ -339,7 +447,14 @@ __global__ __launch_bounds__(64) void mappm_sweep_kernel(const SweepArgs a)
     }
     int jl = 0, jr = 0;  // interface rows (0-based) [0, jl) have landed in the ring, [jl, jr) are in flight (pv0, pv1)
     const float *tgt = sweep_lds;
-    if constexpr (TGT) {
+    if constexpr (MEAN) {   // one target column: the block's own coarse column
+#pragma unroll
+        for (int j = 0; j < 2; ++j) {
+            const int i = lane + 64 * j;   // (kn + 1 <= 128, host)
+            const Tin x = *reinterpret_cast<const Tin *>(pe2_b + (size_t)(i <= kn ? i : kn) * row_p2 + (size_t)blk * ESZ);
+            if (i <= kn) sweep_lds[i] = (float)x;
+        }
+    } else if constexpr (TGT) {
         const unsigned int y = (unsigned int)c0 / (unsigned int)a.nx, x0 = (unsigned int)c0 - y * (unsigned int)a.nx;
         const unsigned int sh = 31u - (unsigned int)__builtin_clz((unsigned int)a.pe2_f);  // log2 f
         const unsigned int cell0 = (y >> sh) * (unsigned int)a.pe2_nx + (x0 >> sh), cells = 64u >> sh;
@@ -367,7 +482,9 @@ __global__ __launch_bounds__(64) void mappm_sweep_kernel(const SweepArgs a)
     }
     Tin pv0 = (Tin)0, pv1 = (Tin)0;  // raw, converted when they land (see q_raw)
     auto PE2 = [&](int i) -> float {  // interface row i (0-based, <= kn)
-        if constexpr (TGT) {
+        if constexpr (MEAN) {
+            return tgt[i];
+        } else if constexpr (TGT) {
             return tgt[i * 8];
         } else {
             // (the LDS read is unconditional and the rare memory read sits in a branch of its own that waits for it right
@@ -381,7 +498,7 @@ __global__ __launch_bounds__(64) void mappm_sweep_kernel(const SweepArgs a)
             return v;
         }
     };
-    unsigned int offq = (unsigned int)lane * 4u;  // offset of q2(k)
+    unsigned int offq = lcol * 4u;  // offset of q2(k)
     int k = 1;
     float p2k = PE2(0), p2k1 = PE2(1);  // pe2(k), pe2(k+1)   (kn >= 1)
     bool accum = false;
@@ -389,7 +506,7 @@ __global__ __launch_bounds__(64) void mappm_sweep_kernel(const SweepArgs a)
     float dpsum = 0.f;
 #pragma unroll
     for (int v = 0; v < NV; ++v) qsum[v] = v_splat(q0[v], 0.f);
-    constexpr int kOut = sweep_out_rows<Tin, NF, FAST>();  // rows of the result ring (below)
+    constexpr int kOut = MEAN ? mean_out_rows<Tin, NF, FAST>() : sweep_out_rows<Tin, NF, FAST>();  // rows of the result ring (below)
     int oslot = 0, fslot = 0;  // ring slot of this lane's row k - 1 / of the wave's row rf, counted along (kOut need not be a power of two)
     auto advance = [&]() {
         ++k;
@@ -415,7 +532,92 @@ __global__ __launch_bounds__(64) void mappm_sweep_kernel(const SweepArgs a)
     int rl = 0;  // per lane (>= rf where it matters)
     V out_v[NV];
     auto OUT = [&](int v, V x) { out_v[v] = x; };
+    // (MEAN) tables and ring of the block, the lane's weight
+    Tin *m_lvl = nullptr;
+    float *m_den = nullptr, *m_ring = nullptr;
+    float area_l = 0.f;
+    float *m_mean[4] = {nullptr, nullptr, nullptr, nullptr};
+    const int mpos = mean_pos(lane);
+    if constexpr (MEAN) {
+        m_lvl = reinterpret_cast<Tin *>(sweep_lds + mean_n1(kn));
+        m_den = sweep_lds + mean_n1(kn) + mean_nl(kn, ESZ);
+        m_ring = sweep_lds + mean_tab_floats(kn, ESZ);
+        area_l = a.area[(b / a.area_repeat) * plane + c0 + lcol];
+        const char *lvl_col = static_cast<const char *>(a.lvl) + (b * a.cmp_levels * plane2 + blk) * ESZ;
+        mean_tables<Tin>(lvl_col, row_p2, a.cmp_offset, kn, lane, area_l, ps_raw, m_lvl, m_den, m_ring);
+#pragma unroll
+        for (int f = 0; f < NF; ++f) m_mean[f] = a.mean[f] + b * kn * plane2 + blk;
+        if (lane == 0) sweep_lds[mean_n1(kn) - 1] = 0.f;   // the wave's spill flag (see below)
+    }
+    // A ring of kOut rows holds the block while its lanes stay within kOut target rows of each other -- smooth thicknesses, i.e.
+    // most of a real restart file.  Where they do not (steep terrain inside the block; BASELINE configs[2]'s iid thicknesses
+    // everywhere) the first lane that finds its slot still occupied raises the wave's `spill` flag, and from the next iteration
+    // on the wave behaves like the plain sweep for the rest of its column: finished rows leave as coalesced stores of p to
+    // the scratch rows, a lane kOut rows ahead writes its own oldest row first, nothing waits for memory.  The block is
+    // listed with the first row it did not sum, and mean_rest_kernel sums those rows from the scratch afterwards -- same
+    // values, same order, same means.  (Bringing evicted rows back into the ring instead -- at the flush, or asynchronously a
+    // row per iteration -- was measured: every variant ends with most of the wave's rows making a round trip through memory
+    // on which the flush then waits; 1.2 - 2.7 ms against 0.95 for the plain sweep on the iid data.)
+    float *m_flag = sweep_lds + mean_n1(kn) - 1;   // (the spare word behind the kn + 1 interfaces)
+    bool spill = false;   // uniform
+    int spill_row = 0;    // uniform: first row that was not summed here
+    // (spilled rows lie BLOCK-major in the scratch -- [block][row][lane], a row of the wave = 256 contiguous bytes -- so they
+    // leave and come back as whole rows; the fine layout would cut them into the block's eight 32-byte pieces)
+    char *s_b[NF];
+#pragma unroll
+    for (int f = 0; f < NF; ++f) s_b[f] = nullptr;
+    if constexpr (MEAN) {
+#pragma unroll
+        for (int f = 0; f < NF; ++f) s_b[f] = reinterpret_cast<char *>(a.q2[f] + (a.col0 / 64 + wid) * (int64_t)kn * 64) + lane * 4;
+    }
+    auto out_end_mean = [&]() {
+        const int r = k - 1, slot = oslot;
+        if (r - kOut >= (rl > rf ? rl : rf)) {  // the slot still holds this lane's row r - kOut: that one goes to the scratch now
+#pragma unroll
+            for (int f = 0; f < NF; ++f)
+                *reinterpret_cast<float *>(s_b[f] + (r - kOut) * 256) = m_ring[(slot * NF + f) * kMeanStride + mpos];
+            rl = r - kOut + 1;
+            *m_flag = 1.f;
+        }
+        const float w = (m_lvl[r] < ps_raw) ? area_l : 0.f;   // regridz.py:209-220, compared in the pressures' own type
+#pragma unroll
+        for (int f = 0; f < NF; ++f) {
+            const float p = v_get(out_v[f / W], f % W) * w;
+            m_ring[(slot * NF + f) * kMeanStride + mpos] = f_isnan(p) ? 0.f : p;
+        }
+    };
+    auto flush_groups = [&](int max_groups) {  // uniform: groups of rows every lane has parked become block means
+#pragma unroll 1
+        for (int n = 0; n < max_groups && rf < kn; ++n) {
+            const int nrows = (kn - rf < kMeanGroup) ? kn - rf : kMeanGroup;
+            const bool past = bad | (k > rf + nrows);
+            if (__builtin_amdgcn_ballot_w64(past) != __builtin_amdgcn_ballot_w64(true)) break;
+#ifndef MEAN_NO_REDUCE  // (timing experiment: wrong results)
+            mean_reduce<NF>(m_ring, fslot, rf, nrows, m_den, m_mean, plane2, lane);
+#endif
+            rf += nrows;
+            fslot = (fslot + nrows >= kOut) ? fslot + nrows - kOut : fslot + nrows;
+        }
+    };
+    auto flush_spill = [&](int max_rows) {  // uniform, spill mode: rows every lane has parked go to the scratch as they are
+#pragma unroll 1
+        for (int n = 0; n < max_rows && rf < kn; ++n) {
+            const bool past = bad | (k - 1 > rf);
+            if (__builtin_amdgcn_ballot_w64(past) != __builtin_amdgcn_ballot_w64(true)) break;
+            if (rl <= rf) {
+#pragma unroll
+                for (int f = 0; f < NF; ++f)
+                    *reinterpret_cast<float *>(s_b[f] + rf * 256) = m_ring[(fslot * NF + f) * kMeanStride + mpos];
+            }
+            ++rf;
+            fslot = (fslot + 1 == kOut) ? 0 : fslot + 1;
+        }
+    };
     auto out_end = [&]() {  // after the OUTs of target k (before advance())
+        if constexpr (MEAN) {
+            out_end_mean();
+            return;
+        }
         const int r = k - 1, slot = oslot;
         if (r - kOut >= (rl > rf ? rl : rf)) {  // the slot still holds this lane's row r - kOut: write it out now
 #pragma unroll
@@ -427,6 +629,17 @@ __global__ __launch_bounds__(64) void mappm_sweep_kernel(const SweepArgs a)
         for (int f = 0; f < NF; ++f) oring[(f * kOut + slot) * 64] = v_get(out_v[f / W], f % W);
     };
     auto flush_rows = [&](int max_rows) {  // uniform: rows every lane has written go to memory
+        if constexpr (MEAN) {
+            if (!spill && *m_flag != 0.f) {   // (raised inside the emit code of the previous iteration; uniform: one LDS word)
+                spill = true;
+                spill_row = rf;
+            }
+            if (spill)
+                flush_spill(max_rows);
+            else
+                flush_groups(max_rows >= kn ? kn : 1);
+            return;
+        }
 #pragma unroll 1
         for (int n = 0; n < max_rows && rf < kn; ++n) {
             const bool past = bad | (k - 1 > rf);
@@ -668,9 +881,70 @@ __global__ __launch_bounds__(64) void mappm_sweep_kernel(const SweepArgs a)
         }
     }
     flush_rows(kn);  // every lane is done (or ill-formed): the rows still in the ring
-    if (bad) a.bad_cols[atomicAdd(a.n_bad, 1u)] = (unsigned int)(wid * 64 + lane);  // redone by mappm_fallback_kernel
+    if constexpr (MEAN) {
+        if (spill && __builtin_amdgcn_ballot_w64(bad) == 0 && lane == 0) {  // the rows from spill_row on are summed by mean_rest_kernel
+            const unsigned int i = atomicAdd(a.n_bad + 2, 1u);
+            a.rest_blocks[2 * i] = (unsigned int)(a.col0 / 64 + wid);
+            a.rest_blocks[2 * i + 1] = (unsigned int)spill_row;
+        }
+        if (__builtin_amdgcn_ballot_w64(bad) != 0) {  // the whole block is redone: its columns by mappm_fallback_kernel, its means by mean_redo_kernel
+            unsigned int base = 0;
+            if (lane == 0) {
+                base = atomicAdd(a.n_bad, 64u);
+                a.bad_blocks[atomicAdd(a.n_bad + 1, 1u)] = (unsigned int)(a.col0 / 64 + wid);
+            }
+            base = __builtin_amdgcn_readfirstlane(base);
+            a.bad_cols[base + lane] = (unsigned int)(b * plane + c0 + lcol);
+        }
+    } else {
+        if (bad) a.bad_cols[atomicAdd(a.n_bad, 1u)] = (unsigned int)(wid * 64 + lane);  // redone by mappm_fallback_kernel
+    }
 }
 
+// The blocks the fused kernel listed, after mappm_fallback_kernel has rewritten all their columns in the scratch rows: the same
+// masked means from there.  One wave per block, one field at a time; the arithmetic is mean_tables / mean_reduce, as above.
+template <typename Tin>
+__global__ __launch_bounds__(64) void mean_redo_kernel(const SweepArgs a, int nf)
+{
+    constexpr unsigned int ESZ = sizeof(Tin);
+    const int lane = threadIdx.x, kn = a.kn, km = a.km;
+    const unsigned int count = a.n_bad[1];
+    const int64_t plane = a.n_inner, plane2 = a.pe2_plane;
+    float *tgt_unused = sweep_lds;
+    (void)tgt_unused;
+    Tin *m_lvl = reinterpret_cast<Tin *>(sweep_lds + mean_n1(kn));
+    float *m_den = sweep_lds + mean_n1(kn) + mean_nl(kn, ESZ);
+    float *m_ring = sweep_lds + mean_tab_floats(kn, ESZ);
+    const int mpos = mean_pos(lane);
+    for (unsigned int i = blockIdx.x; i < count; i += gridDim.x) {
+        const int64_t gw = a.bad_blocks[i];
+        const int64_t b = gw / plane2, blk = gw - b * plane2, Y = blk / a.pe2_nx, X = blk - Y * a.pe2_nx;
+        const int64_t c0 = Y * 8 * a.nx + X * 8;
+        const unsigned int lcol = (unsigned int)(lane >> 3) * (unsigned int)a.nx + (unsigned int)(lane & 7);
+        const float area_l = a.area[(b / a.area_repeat) * plane + c0 + lcol];
+        const Tin ps_raw = static_cast<const Tin *>(a.pe1)[(b * (km + 1) + km) * plane + c0 + lcol];
+        const char *lvl_col = static_cast<const char *>(a.lvl) + (b * a.cmp_levels * plane2 + blk) * ESZ;
+        mean_tables<Tin>(lvl_col, (unsigned int)plane2 * ESZ, a.cmp_offset, kn, lane, area_l, ps_raw, m_lvl, m_den, m_ring);
+        for (int f = 0; f < nf; ++f) {
+            const float *q = a.q2[f] + b * kn * plane + c0 + lcol;
+            float *mean[4] = {a.mean[f] + b * kn * plane2 + blk, nullptr, nullptr, nullptr};
+            for (int row0 = 0; row0 < kn; row0 += kMeanGroup) {
+                const int nrows = (kn - row0 < kMeanGroup) ? kn - row0 : kMeanGroup;
+                for (int j = 0; j < nrows; ++j) {
+                    const int r = row0 + j;
+                    const float w = (m_lvl[r] < ps_raw) ? area_l : 0.f;
+                    const float p = q[(int64_t)r * plane] * w;
+                    m_ring[j * kMeanStride + mpos] = f_isnan(p) ? 0.f : p;
+                }
+                mean_reduce<1>(m_ring, 0, row0, nrows, m_den, mean, plane2, lane);
+            }
+        }
+    }
+}
+
+// (the file is compiled twice -- remap.o: the sweep launches, remap_mean.o: the fused block-mean launches -- so that the two
+// sets of instantiations build side by side; see the Makefile)
+#ifndef FV3HIP_REMAP_PART_MEAN
 template <typename Tin, int NV, int W>
 void launch_sweep2(const SweepArgs &a, int64_t n_waves, bool fast, bool tgt, hipStream_t st)
 {
@@ -689,16 +963,153 @@ void launch_sweep2(const SweepArgs &a, int64_t n_waves, bool fast, bool tgt, hip
 template <typename Tin>
 void launch_sweep1(const SweepArgs &a, int nf, int64_t n_waves, bool fast, bool tgt, hipStream_t st)
 {
+#ifdef FV3HIP_REMAP_SUBSET  // (experiment builds: the float64 four-field instantiations only)
+    if constexpr (sizeof(Tin) == 8) launch_sweep2<Tin, 2, 2>(a, n_waves, fast, tgt, st);
+#else
     switch (nf) {
         case 1: launch_sweep2<Tin, 1, 1>(a, n_waves, fast, tgt, st); break;
         case 2: launch_sweep2<Tin, 1, 2>(a, n_waves, fast, tgt, st); break;
         case 3: launch_sweep2<Tin, 3, 1>(a, n_waves, fast, tgt, st); break;
         default: launch_sweep2<Tin, 2, 2>(a, n_waves, fast, tgt, st); break;
     }
+#endif
 }
 
+#endif  // sweep part
+#ifndef FV3HIP_REMAP_PART_SWEEP
+// The blocks whose waves went into spill mode: rows [row0, kn) of their NF fields lie in the scratch, block-major, as parked
+// (p = q2 * w, NaN -> 0); their means from there -- mean_reduce again, so the same sums.  One wave per listed block, the loads of a group of
+// rows in flight while the previous group is summed.
+template <typename Tin, int NF>
+__global__ __launch_bounds__(64) void mean_rest_kernel(const SweepArgs a)
+{
+    constexpr unsigned int ESZ = sizeof(Tin);
+    const int lane = threadIdx.x, kn = a.kn, km = a.km;
+    const unsigned int count = a.n_bad[2];
+    const int64_t plane = a.n_inner, plane2 = a.pe2_plane;
+    Tin *m_lvl = reinterpret_cast<Tin *>(sweep_lds + mean_n1(kn));
+    float *m_den = sweep_lds + mean_n1(kn) + mean_nl(kn, ESZ);
+    float *m_ring = sweep_lds + mean_tab_floats(kn, ESZ);
+    const int mpos = mean_pos(lane);
+    const unsigned int lcol = (unsigned int)(lane >> 3) * (unsigned int)a.nx + (unsigned int)(lane & 7);
+    for (unsigned int i = blockIdx.x; i < count; i += gridDim.x) {
+        const int64_t gw = a.rest_blocks[2 * i];
+        const int row0 = (int)a.rest_blocks[2 * i + 1];
+        const int64_t b = gw / plane2, blk = gw - b * plane2, Y = blk / a.pe2_nx, X = blk - Y * a.pe2_nx;
+        const int64_t c0 = Y * 8 * a.nx + X * 8;
+        const float area_l = a.area[(b / a.area_repeat) * plane + c0 + lcol];
+        const Tin ps_raw = static_cast<const Tin *>(a.pe1)[(b * (km + 1) + km) * plane + c0 + lcol];
+        const char *lvl_col = static_cast<const char *>(a.lvl) + (b * a.cmp_levels * plane2 + blk) * ESZ;
+        const float *q[NF];
+        float *mean[4] = {nullptr, nullptr, nullptr, nullptr};
+#pragma unroll
+        for (int f = 0; f < NF; ++f) {
+            q[f] = a.q2[f] + gw * (int64_t)kn * 64 + lane;
+            mean[f] = a.mean[f] + b * kn * plane2 + blk;
+        }
+        float cur[kMeanGroup][NF], nxt[kMeanGroup][NF];
+        auto request = [&](float (&v)[kMeanGroup][NF], int r0) {
+#pragma unroll
+            for (int j = 0; j < kMeanGroup; ++j) {
+                const int r = (r0 + j < kn) ? r0 + j : kn - 1;
+#pragma unroll
+                for (int f = 0; f < NF; ++f) v[j][f] = q[f][r * 64];
+            }
+        };
+        request(cur, row0 < kn ? row0 : kn - 1);
+        mean_tables<Tin>(lvl_col, (unsigned int)plane2 * ESZ, a.cmp_offset, kn, lane, area_l, ps_raw, m_lvl, m_den, m_ring);
+        for (int r0 = row0; r0 < kn; r0 += kMeanGroup) {
+            const int nrows = (kn - r0 < kMeanGroup) ? kn - r0 : kMeanGroup;
+            if (r0 + kMeanGroup < kn) request(nxt, r0 + kMeanGroup);
+#pragma unroll
+            for (int j = 0; j < kMeanGroup; ++j)
+#pragma unroll
+                for (int f = 0; f < NF; ++f) m_ring[(j * NF + f) * kMeanStride + mpos] = cur[j][f];
+            mean_reduce<NF>(m_ring, 0, r0, nrows, m_den, mean, plane2, lane);
+#pragma unroll
+            for (int j = 0; j < kMeanGroup; ++j)
+#pragma unroll
+                for (int f = 0; f < NF; ++f) cur[j][f] = nxt[j][f];
+        }
+    }
+}
+
+template <typename Tin, int NV, int W>
+void launch_mean2(const SweepArgs &a, int64_t n_waves, bool fast, hipStream_t st)
+{
+#define MEAN_(F)                                                                                                                    \
+    hipLaunchKernelGGL((mappm_sweep_kernel<Tin, NV, W, F, true, true>), dim3((unsigned)n_waves), dim3(64),                          \
+                       (size_t)(mean_tab_floats(a.kn, (int)sizeof(Tin)) + NV * W * mean_out_rows<Tin, NV * W, F>() * kMeanStride) * sizeof(float), st, a)
+    if (fast) MEAN_(true); else MEAN_(false);
+#undef MEAN_
+}
+
+template <typename Tin>
+void launch_mean1(const SweepArgs &a, int nf, int64_t n_waves, bool fast, hipStream_t st)
+{
+#ifdef FV3HIP_REMAP_SUBSET
+    if constexpr (sizeof(Tin) == 8) launch_mean2<Tin, 2, 2>(a, n_waves, fast, st);
+#else
+    switch (nf) {
+        case 1: launch_mean2<Tin, 1, 1>(a, n_waves, fast, st); break;
+        case 2: launch_mean2<Tin, 1, 2>(a, n_waves, fast, st); break;
+        case 3: launch_mean2<Tin, 3, 1>(a, n_waves, fast, st); break;
+        default: launch_mean2<Tin, 2, 2>(a, n_waves, fast, st); break;
+    }
+#endif
+}
+
+#endif  // mean part
 }  // namespace
 
+#ifndef FV3HIP_REMAP_PART_SWEEP
+bool mappm_mean_eligible(int ny, int nx, int factor, int km, int kn, int kord, int in_dtype)
+{
+    const int64_t esz = (in_dtype == FV3HIP_F64) ? 8 : 4;
+    const int64_t levels = (km + 1 > kn + 1 ? km + 1 : kn + 1) + 5;
+    return factor == 8 && ny > 0 && nx > 0 && ny % 8 == 0 && nx % 8 == 0 && kord <= 3 && km >= 8 && kn >= 1 && kn + 1 <= 128 &&
+           (int64_t)ny * nx * esz * levels < ((int64_t)1 << 32);
+}
+
+void mappm_mean_launch(const SweepArgs &a, int nf, int in_dtype, int64_t col_end, bool fast, hipStream_t st)
+{
+    const int64_t n_waves = (col_end - a.col0) / 64;
+    if (in_dtype == FV3HIP_F32)
+        launch_mean1<float>(a, nf, n_waves, fast, st);
+    else
+        launch_mean1<double>(a, nf, n_waves, fast, st);
+}
+
+void mappm_mean_rest_launch(const SweepArgs &a, int nf, int in_dtype, int64_t n_blocks, hipStream_t st)
+{
+    const int esz = (in_dtype == FV3HIP_F64) ? 8 : 4;
+    const size_t lds = (size_t)(mean_tab_floats(a.kn, esz) + kMeanGroup * 4 * kMeanStride) * sizeof(float);
+    const unsigned grid = (unsigned)(n_blocks < 8192 ? (n_blocks < 1 ? 1 : n_blocks) : 8192);
+#define REST_(T, N) hipLaunchKernelGGL((mean_rest_kernel<T, N>), dim3(grid), dim3(64), lds, st, a)
+#define REST_T(T)                                                                                                                   \
+    switch (nf) {                                                                                                                   \
+        case 1: REST_(T, 1); break;                                                                                                 \
+        case 2: REST_(T, 2); break;                                                                                                 \
+        case 3: REST_(T, 3); break;                                                                                                 \
+        default: REST_(T, 4); break;                                                                                                \
+    }
+    if (in_dtype == FV3HIP_F32) { REST_T(float) } else { REST_T(double) }
+#undef REST_T
+#undef REST_
+}
+
+void mappm_mean_redo_launch(const SweepArgs &a, int nf, int in_dtype, hipStream_t st)
+{
+    const int esz = (in_dtype == FV3HIP_F64) ? 8 : 4;
+    const size_t lds = (size_t)(mean_tab_floats(a.kn, esz) + kMeanGroup * kMeanStride + 64 * 3) * sizeof(float);
+    if (in_dtype == FV3HIP_F32)
+        hipLaunchKernelGGL((mean_redo_kernel<float>), dim3(256), dim3(64), lds, st, a, nf);
+    else
+        hipLaunchKernelGGL((mean_redo_kernel<double>), dim3(256), dim3(64), lds, st, a, nf);
+}
+
+#endif  // mean part
+#ifndef FV3HIP_REMAP_PART_MEAN
 bool mappm_sweep_eligible(int64_t n_inner, int km, int kn, int kord, int layout, int in_dtype)
 {
     const int64_t esz = (in_dtype == FV3HIP_F64) ? 8 : 4;
@@ -718,4 +1129,5 @@ void mappm_sweep_launch(const SweepArgs &a, int nf, int in_dtype, int64_t col_en
         launch_sweep1<double>(a, nf, n_waves, fast, tgt, st);
 }
 
+#endif  // sweep part
 }  // namespace fv3hip

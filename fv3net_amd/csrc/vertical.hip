@@ -1796,6 +1796,99 @@ extern "C" int fv3hip_mappm_multi_coarse_target(const void *pe1, const void *con
     return FV3HIP_OK;
 }
 
+extern "C" size_t fv3hip_mappm_block_mean_workspace_bytes(int64_t ncol, int km)
+{
+    if (ncol <= 0 || km <= 0) return 0;
+    return fv3hip_mappm_workspace_bytes(ncol, km) + (size_t)(kMappmChunk / 64) * 3 * sizeof(unsigned int);  // block lists: redo, (rest, row)
+}
+
+extern "C" int fv3hip_mappm_block_mean(const void *pe1, const void *const *q1, const void *pe2_coarse, const void *level_coarse,
+                                       int cmp_levels, int cmp_offset, int in_dtype, const float *area, int64_t area_repeat,
+                                       float *const *scratch, float *const *mean, int n_fields, int64_t n_batch, int ny, int nx, int factor,
+                                       int km, int kn, int iv, int kord, int arith, void *workspace, size_t workspace_bytes, void *stream)
+{
+    FV3HIP_REQUIRE(arith == FV3HIP_ARITH_EXACT || arith == FV3HIP_ARITH_FAST, "unknown arithmetic mode %d", arith);
+    FV3HIP_REQUIRE(n_fields >= 0, "negative field count");
+    if (n_fields == 0) return FV3HIP_OK;
+    FV3HIP_REQUIRE(q1 && scratch && mean, "null pointer");
+    FV3HIP_REQUIRE(in_dtype == FV3HIP_F32 || in_dtype == FV3HIP_F64, "in_dtype must be F32 or F64, got %d", in_dtype);
+    FV3HIP_REQUIRE(n_batch >= 0 && ny >= 0 && nx >= 0 && kn >= 0, "negative extent");
+    FV3HIP_REQUIRE(iv >= -2 && iv <= 2, "iv must be in [-2, 2], got %d", iv);
+    FV3HIP_REQUIRE(km >= 4, "km must be >= 4 (ppm_profile reads a4(2,i,3)), got %d", km);
+    FV3HIP_REQUIRE(area_repeat >= 1, "area_repeat must be >= 1");
+    FV3HIP_REQUIRE(cmp_offset >= 0 && cmp_levels >= kn + cmp_offset, "compared levels: %d rows cannot serve %d layers at offset %d",
+                   cmp_levels, kn, cmp_offset);
+    const int64_t n_inner = (int64_t)ny * nx, ncol = n_batch * n_inner;
+    if (ncol == 0 || kn == 0) return FV3HIP_OK;
+    if (!mappm_mean_eligible(ny, nx, factor, km, kn, kord, in_dtype) || ncol >= ((int64_t)1 << 32))
+        return fail(FV3HIP_EUNSUPPORTED, "the fused remap + block mean needs factor 8, extents that are multiples of 8, kord <= 3, km >= 8, kn < 128");
+    const int nyc = ny / factor, nxc = nx / factor;
+    const int64_t plane2 = (int64_t)nyc * nxc;
+    FV3HIP_REQUIRE(pe1 && pe2_coarse && level_coarse && area, "null pointer");
+    for (int f = 0; f < n_fields; ++f) FV3HIP_REQUIRE(q1[f] && scratch[f] && mean[f], "null field pointer");
+    FV3HIP_REQUIRE(workspace && workspace_bytes >= fv3hip_mappm_block_mean_workspace_bytes(ncol, km),
+                   "workspace too small: need %zu bytes, got %zu", fv3hip_mappm_block_mean_workspace_bytes(ncol, km), workspace_bytes);
+    hipStream_t st = as_stream(stream);
+    const int64_t ws_cols = ws_slots(ncol);
+    unsigned int *n_bad = static_cast<unsigned int *>(workspace);
+    unsigned int *bad_cols = reinterpret_cast<unsigned int *>(static_cast<char *>(workspace) + kCounterBytes);
+    float *planes = reinterpret_cast<float *>(static_cast<char *>(workspace) + kCounterBytes + ws_list_bytes(ncol));
+    unsigned int *bad_blocks = reinterpret_cast<unsigned int *>(static_cast<char *>(workspace) + fv3hip_mappm_workspace_bytes(ncol, km));
+    unsigned int *rest_blocks = bad_blocks + kMappmChunk / 64;
+    // a launch = kMappmChunk columns' worth of blocks (the lists are sized for that); `col0` counts 64 columns per block
+    for (int64_t col0 = 0; col0 < ncol; col0 += kMappmChunk) {
+        const int64_t col_end = (col0 + kMappmChunk < ncol) ? col0 + kMappmChunk : ncol;
+        const int64_t fb_threads = (col_end - col0 < kFallbackSlots) ? (col_end - col0) : kFallbackSlots;
+        const int64_t fb_blocks = ceil_div(fb_threads, 256);
+        for (int f0 = 0; f0 < n_fields; f0 += kMaxMultiFields) {
+            const int nf = (n_fields - f0 < kMaxMultiFields) ? n_fields - f0 : kMaxMultiFields;
+            FV3HIP_CHECK_HIP(hipMemsetAsync(n_bad, 0, 16, st));
+            SweepArgs sa;
+            memset(&sa, 0, sizeof(sa));
+            sa.pe1 = pe1;
+            sa.pe2 = pe2_coarse;
+            for (int f = 0; f < nf; ++f) {
+                sa.q1[f] = q1[f0 + f];
+                sa.q2[f] = scratch[f0 + f];
+                sa.mean[f] = mean[f0 + f];
+            }
+            sa.col0 = col0;
+            sa.n_inner = n_inner;
+            sa.km = km;
+            sa.kn = kn;
+            sa.iv = iv;
+            sa.n_bad = n_bad;
+            sa.bad_cols = bad_cols;
+            sa.bad_blocks = bad_blocks;
+            sa.rest_blocks = rest_blocks;
+            sa.pe2_f = factor;
+            sa.nx = nx;
+            sa.pe2_nx = nxc;
+            sa.pe2_plane = plane2;
+            sa.area = area;
+            sa.area_repeat = area_repeat;
+            sa.lvl = level_coarse;
+            sa.cmp_levels = cmp_levels;
+            sa.cmp_offset = cmp_offset;
+            mappm_mean_launch(sa, nf, in_dtype, col_end, arith == FV3HIP_ARITH_FAST, st);
+            mappm_mean_rest_launch(sa, nf, in_dtype, (col_end - col0) / 64, st);
+            // blocks with an ill-formed column (normally none): all their columns through the sequential routine into the
+            // scratch rows (absolute column indices in the list: col0 = 0), then their means from there
+#define LAUNCH_(T)                                                                                                                  \
+    for (int f = 0; f < nf; ++f)                                                                                                    \
+        hipLaunchKernelGGL((mappm_fallback_kernel<T>), dim3((unsigned)fb_blocks), dim3(256), 0, st, static_cast<const T *>(pe1),    \
+                           static_cast<const T *>(q1[f0 + f]), static_cast<const T *>(pe2_coarse), scratch[f0 + f], (int64_t)0, n_inner, km, \
+                           kn, iv, kord, (int)FV3HIP_LAYOUT_LEVEL_COL, n_bad, bad_cols, planes, ws_cols, factor, nx, nxc, plane2)
+            if (in_dtype == FV3HIP_F32) { LAUNCH_(float); } else { LAUNCH_(double); }
+#undef LAUNCH_
+            mappm_mean_redo_launch(sa, nf, in_dtype, st);
+            const int rc = check_launch("mappm block-mean kernels");
+            if (rc) return rc;
+        }
+    }
+    return FV3HIP_OK;
+}
+
 extern "C" int fv3hip_interpolate_2d(const void *xp, const void *x, const void *y, int64_t n_batch, int64_t n_inner, int n_in,
                                      int n_out, double fill_value, int layout, void *out, void *stream)
 {

@@ -32,8 +32,9 @@ from .constants import (
     SFC_DATA_X_CENTER,
     SFC_DATA_Y_CENTER,
 )
-from .regridz import (EdgeLines, compute_edge_delp, edge_weighted_pressure_means, pressure_at_midpoint_log,
-                      regrid_to_area_weighted_pressure, regrid_to_edge_weighted_pressure)  # (pressure_at_midpoint_log: thermo imports this package's device helpers)
+from .regridz import (EdgeLines, area_weighted_pressure_means, compute_edge_delp, edge_weighted_pressure_means,
+                      fused_block_mean_enabled, pressure_at_midpoint_log, regrid_to_area_weighted_pressure,
+                      regrid_to_edge_weighted_pressure)  # (pressure_at_midpoint_log: thermo imports this package's device helpers)
 from .sfc_data import _coarse_grain_sfc_data_complex
 
 CATEGORY_LIST = ["fv_core.res", "fv_srf_wnd.res", "fv_tracer.res", "sfc_data"]
@@ -117,6 +118,10 @@ def _area_weighted_pressure_means(core, tracer, delp, area, toa_pressure, coarse
     names_tracer = FRACTION_TRACERS + NON_FRACTION_TRACERS
     t = to_compat(tracer)[names_tracer].rename({FV_TRACER_Y_CENTER: FV_CORE_Y_CENTER})
     both = merge([to_compat(core)[names_core], t])
+    if fused_block_mean_enabled():  # (opt-in: the remap and the masked mean in one kernel, same values)
+        means = to_compat(area_weighted_pressure_means(both, delp, area, toa_pressure, coarsening_factor, x_dim=FV_CORE_X_CENTER,
+                                                       y_dim=FV_CORE_Y_CENTER, extrapolate=extrapolate))
+        return means[names_core], means[names_tracer].rename({FV_CORE_Y_CENTER: FV_TRACER_Y_CENTER})
     regridded, masked_area = regrid_to_area_weighted_pressure(
         both, delp, area, toa_pressure, coarsening_factor, x_dim=FV_CORE_X_CENTER, y_dim=FV_CORE_Y_CENTER, extrapolate=extrapolate)
     means = to_compat(weighted_block_average(regridded, masked_area, coarsening_factor, x_dim=FV_CORE_X_CENTER, y_dim=FV_CORE_Y_CENTER))

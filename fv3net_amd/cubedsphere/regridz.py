@@ -174,6 +174,67 @@ def regrid_to_area_weighted_pressure(ds, delp, area, toa_pressure: float, coarse
                               extrapolate=extrapolate)
 
 
+def fused_block_mean_enabled() -> bool:
+    """``FV3NET_AMD_FUSED_BLOCK_MEAN=1`` routes the pressure-level means of cell-centred fields through the fused remap +
+    block-mean kernel (``ops.mappm_block_mean``).  Off by default: identical results, faster only where the 64 columns of
+    a coarse cell stay within a few target layers of each other."""
+    import os
+
+    return os.environ.get("FV3NET_AMD_FUSED_BLOCK_MEAN", "0").lower() in ("1", "true", "on")
+
+
+def area_weighted_pressure_means(ds, delp, area, toa_pressure: float, coarsening_factor: int, x_dim: str = FV_CORE_X_CENTER,
+                                 y_dim: str = FV_CORE_Y_CENTER, z_dim: str = RESTART_Z_CENTER, extrapolate: bool = False):
+    """``weighted_block_average(*regrid_to_area_weighted_pressure(ds, delp, area, ...), coarsening_factor)`` -- what the
+    pressure-level restart pipelines do with every cell-centred field (coarsen_restarts.py:483-495, 940-961) -- with the
+    remapped fine fields and the masked area never materialised where the fused kernel applies (factor 8, float32 area,
+    [.., z, y, x] order); anything else takes the two calls.  Identical values and labels either way."""
+    def two_calls():
+        regridded, masked = regrid_to_area_weighted_pressure(ds, delp, area, toa_pressure, coarsening_factor, x_dim=x_dim, y_dim=y_dim,
+                                                             z_dim=z_dim, extrapolate=extrapolate)
+        return weighted_block_average(regridded, masked, coarsening_factor, x_dim=x_dim, y_dim=y_dim)
+
+    d, dl, ar = to_compat(ds), to_compat(delp), to_compat(area)
+    das = [d[v] for v in d] if isinstance(d, Dataset) else [d]
+    order = tuple(dl.dims)
+    tail = (z_dim, y_dim, x_dim)
+    if (int(coarsening_factor) != 8 or order[-3:] != tail or any(tuple(a.dims) != order or a.shape != dl.shape for a in das)
+            or tuple(ar.dims[-2:]) != (y_dim, x_dim) or tuple(ar.dims[:-2]) != order[: len(ar.dims) - 2]):
+        return two_calls()
+    delp_t, area_t = on_device(dl.data), on_device(ar.data)
+    if area_t.dtype != torch_float32():
+        return two_calls()
+    delp_coarse = ops.weighted_block_average(delp_t, area_t, 8)
+    phalf_fine = ops.pressure_at_interface(delp_t, toa_pressure, -3)
+    phalf_coarse = ops.pressure_at_interface(delp_coarse, toa_pressure, -3)
+    level = ops.pressure_at_midpoint_log(delp_coarse, toa_pressure, -3) if extrapolate else None
+    fields = [on_device(a.data) for a in das]
+    if any(f.dtype != phalf_fine.dtype for f in fields):
+        return two_calls()
+    means = ops.mappm_block_mean(phalf_fine, fields, phalf_coarse, area_t, level_coarse=level, iv=1, kord=1)
+    if means is None:
+        return two_calls()
+    from .coarsen import _coarsened_coords, coarsen_coords_coord_func
+
+    def label(t, a):
+        coords = _coarsened_coords(a, {x_dim: 8, y_dim: 8}, coarsen_coords_coord_func)
+        coords = {k: v for k, v in coords.items() if k != z_dim}   # (regrid_vertical drops the vertical coordinate)
+        return DataArray(like_input(t, a.data), dims=a.dims, name=a.name, attrs=a.attrs, coords=coords)
+
+    if not isinstance(d, Dataset):
+        return from_compat(label(means[0], das[0]), ds)
+    out = Dataset(attrs=d.attrs)
+    for v, m, a in zip(list(d), means, das):
+        out[v] = label(m, a)
+    return from_compat(out, ds)
+
+
+def torch_float32():
+    import torch
+
+    return torch.float32
+
+
 def compute_edge_delp(delp, edge: str, x_dim: str = FV_CORE_X_CENTER, y_dim: str = FV_CORE_Y_CENTER, step: int = 1):
     """Pressure thickness on grid cell edges (coarsen_restarts.py:825-853): ``delp`` interpolated
     across the cube's faces to the edges the ``edge``-directed wind component lives on; the new

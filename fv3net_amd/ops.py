@@ -898,6 +898,83 @@ def mappm_multi_coarse_target(pe1: torch.Tensor, fields: Sequence[torch.Tensor],
     return outs
 
 
+def mappm_block_mean(pe1: torch.Tensor, fields: Sequence[torch.Tensor], pe2_coarse: torch.Tensor, area: torch.Tensor,
+                     level_coarse: Optional[torch.Tensor] = None, factor: int = 8, iv: int = 1, kord: int = 1,
+                     arith: Optional[str] = None) -> Optional[list]:
+    """``weighted_block_average(mappm_multi_coarse_target(pe1, fields, pe2_coarse, factor), mask_weights(area, level, pe1, ...,
+    coarse_factor=factor), factor)`` in one kernel (regridz.py:149-220 followed by coarsen.py:183-218, as the pressure-level
+    restart pipelines call them): a wavefront owns one 8 x 8 block, sums its remapped, masked values in LDS and writes the
+    coarse means -- the fine remapped fields and the masked weights never exist.  ``level_coarse``: the coarse midpoint
+    pressures [.., kn, ny/8, nx/8] (``extrapolate=True``); None compares each layer's bottom interface (``pe2_coarse``).
+    ``area`` [.., ny, nx] float32 with leading dims that lead the fields' (shared by the rest).  Arrays in [.., z, y, x] order.
+    Bit-identical to the three calls above in the same ``arith``.  Returns None where the kernel does not apply (factor != 8,
+    extents not multiples of 8, a non-float32 area, kord > 3, ...): the caller takes the three calls."""
+    fields = list(fields)
+    if not fields:
+        return []
+    q1 = fields[0]
+    nd = q1.dim()
+    if int(factor) != 8 or nd < 3 or area.dtype != torch.float32:
+        return None
+    dev = _require_device(pe1, pe2_coarse, area, *fields)
+    lvl, cmp_offset = (pe2_coarse, 1) if level_coarse is None else (level_coarse, 0)
+    dtypes = {t.dtype for t in (pe1, pe2_coarse, lvl, *fields)}
+    if len(dtypes) > 1:
+        return None
+    km, kn = int(q1.shape[-3]), int(pe2_coarse.shape[-3]) - 1
+    ny, nx = int(q1.shape[-2]), int(q1.shape[-1])
+    batch = tuple(q1.shape[:-3])
+    if ny % 8 or nx % 8 or int(kord) > 3 or km < 8 or kn < 1 or kn + 1 > 128:
+        return None
+    if int(pe1.shape[-3]) != km + 1:
+        raise ValueError("f_in must have a vertical dimension one shorter than p_in")
+    coarse_hw = (ny // 8, nx // 8)
+    if (any(tuple(q.shape) != tuple(q1.shape) for q in fields) or tuple(pe1.shape) != batch + (km + 1, ny, nx)
+            or tuple(pe2_coarse.shape) != batch + (kn + 1,) + coarse_hw
+            or tuple(lvl.shape) != batch + (kn + cmp_offset,) + coarse_hw):
+        raise ValueError("All dimensions except vertical must be same size for p_in, f_in and (the upsampled) p_out")
+    lead = tuple(area.shape[:-2])
+    if tuple(area.shape[-2:]) != (ny, nx) or lead != batch[: len(lead)]:
+        raise ValueError(f"area of shape {tuple(area.shape)} does not lead the fields' {tuple(q1.shape)}")
+    nb = _prod(batch)
+    area_repeat = nb // max(_prod(lead), 1)
+    pe1, pe2_coarse, lvl, area = pe1.contiguous(), pe2_coarse.contiguous(), lvl.contiguous(), area.contiguous()
+    fields = [q.contiguous() for q in fields]
+    n = len(fields)
+    lib = _lib.load()
+    ws = _workspace(dev, int(lib.fv3hip_mappm_block_mean_workspace_bytes(nb * ny * nx, km)))
+    # fine-size rows that only evicted values and redone blocks pass through: one allocation, kept per (device, stream, size)
+    scratch = _scratch_rows(dev, n, nb * kn * ny * nx)
+    outs = [torch.empty(batch + (kn,) + coarse_hw, dtype=torch.float32, device=dev) for _ in fields]
+    q_ptrs = (ctypes.c_void_p * n)(*[q.data_ptr() for q in fields])
+    s_ptrs = (ctypes.c_void_p * n)(*[scratch[i % len(scratch)].data_ptr() for i in range(n)])  # (a sweep takes four fields)
+    o_ptrs = (ctypes.c_void_p * n)(*[o.data_ptr() for o in outs])
+    try:
+        _lib.call_on(dev, "fv3hip_mappm_block_mean", _ptr(pe1), q_ptrs, _ptr(pe2_coarse), _ptr(lvl), kn + cmp_offset, cmp_offset,
+                     _float_code(q1), _ptr(area), area_repeat, s_ptrs, o_ptrs, n, nb, ny, nx, 8, km, kn, int(iv), int(kord),
+                     _arith_code(arith), _ptr(ws), ws.numel(), _stream(dev))
+    except _lib.Fv3HipError as err:
+        if err.code != _lib.EUNSUPPORTED:
+            raise
+        return None
+    return outs
+
+
+_scratch = {}
+
+
+def _scratch_rows(dev, n: int, numel: int) -> list:
+    """``n`` float32 scratch arrays of ``numel`` elements for the fused remap + block mean, one set per (device, HIP stream)
+    like the remap's workspace: a sweep's four fields use the first four, the next sweep of the same call reuses them in
+    stream order."""
+    n = min(n, 4)
+    key = (dev.type, dev.index, torch.cuda.current_stream(dev).cuda_stream)
+    have = _scratch.get(key)
+    if have is None or have.numel() < n * numel:
+        have = _scratch[key] = torch.empty(n * numel, dtype=torch.float32, device=dev)
+    return [have[i * numel:(i + 1) * numel] for i in range(n)]
+
+
 class HipTimer:
     """HIP events recorded on torch's current stream (used by bench.py)."""
 

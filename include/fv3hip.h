@@ -332,6 +332,28 @@ int fv3hip_mappm_multi_coarse_target(const void *pe1, const void *const *q1, con
                                      int n_fields, int64_t n_batch, int ny, int nx, int factor, int km, int kn, int iv, int kord,
                                      int arith, void *workspace, size_t workspace_bytes, void *stream);
 
+/*
+ * Vertical remap to the coarse grid's pressure levels and the masked 8 x 8 block mean of the result in one pass -- what the
+ * pressure-level restart pipelines do with every cell-centred field (coarsen_restarts.py:483-495, 940-961:
+ * weighted_block_average(*regrid_to_area_weighted_pressure(ds, delp, area, ...)); regridz.py:149-220):
+ *   mean[f][b][k][Y][X] = sum_block(q2 * w) / sum_block(w),   q2 = mappm of q1[f] onto the interfaces pe2_coarse[b][.][Y][X],
+ *   w[y][x] = area[b / area_repeat][y][x]  where  level_coarse[b][k + cmp_offset][Y][X] < pe1[b][km][y][x] (the fine surface), else 0
+ * (cmp_offset 1 with level_coarse = pe2_coarse, cmp_levels = kn + 1: the layer's bottom interface, extrapolate=False;
+ * cmp_offset 0 with the coarse midpoint pressures, cmp_levels = kn: extrapolate=True).  pe1 / q1[f] are [n_batch][km(+1)][ny][nx],
+ * pe2_coarse / level_coarse [n_batch][levels][ny / 8][nx / 8] in the input dtype, area float32.  One wavefront owns one block;
+ * the remapped values are summed in LDS in the order of fv3hip_weighted_block_average and never written: the means are
+ * bit-identical to fv3hip_mappm_multi_coarse_target + fv3hip_mask_weights_coarse + fv3hip_weighted_block_average in the same
+ * `arith` (blocks with an ill-formed column -- NaN or non-monotone pressures -- are redone through the sequential routine, i.e.
+ * in EXACT arithmetic).  scratch[f]: [n_batch][kn][ny][nx] float32 each, touched only by values a lane has to park outside
+ * LDS and by redone blocks.  q1 / scratch / mean are HOST arrays of n_fields device pointers.
+ * FV3HIP_EUNSUPPORTED unless factor == 8, ny % 8 == 0, nx % 8 == 0, kord <= 3, km >= 8, kn + 1 <= 128.
+ */
+size_t fv3hip_mappm_block_mean_workspace_bytes(int64_t ncol, int km);
+int fv3hip_mappm_block_mean(const void *pe1, const void *const *q1, const void *pe2_coarse, const void *level_coarse,
+                            int cmp_levels, int cmp_offset, int in_dtype, const float *area, int64_t area_repeat,
+                            float *const *scratch, float *const *mean, int n_fields, int64_t n_batch, int ny, int nx, int factor,
+                            int km, int kn, int iv, int kord, int arith, void *workspace, size_t workspace_bytes, void *stream);
+
 /* ------------------------------------------------------------------------------------------
  * Column MLP (fv3fit dense model / Zhao-Carr microphysics emulator)
  * ------------------------------------------------------------------------------------------ */
