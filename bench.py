@@ -538,7 +538,7 @@ def restart_pipeline_benchmark(dev, n=384, f=8, reps=6, tiles=tuple(range(6)), w
                        lambda: coarsen_restarts_via_blended_method(f, grid, 300.0, restarts, coarsen_agrid_winds=True))}
     for key in which:
         label, fn = fns[key]
-        for _ in range(3):
+        for _ in range(6):   # (memory handed between the pipelines' streams returns to the allocator an event later: a few calls until its pools have settled)
             fn()
         sync()
         t0 = time.perf_counter()

@@ -33,8 +33,7 @@ from .constants import (
     SFC_DATA_Y_CENTER,
 )
 from .regridz import (EdgeLines, area_weighted_pressure_means, compute_edge_delp, edge_weighted_pressure_means,
-                      fused_block_mean_enabled, pressure_at_midpoint_log, regrid_to_area_weighted_pressure,
-                      regrid_to_edge_weighted_pressure)  # (pressure_at_midpoint_log: thermo imports this package's device helpers)
+                      pressure_at_midpoint_log, regrid_to_area_weighted_pressure, regrid_to_edge_weighted_pressure)  # (pressure_at_midpoint_log: thermo imports this package's device helpers)
 from .sfc_data import _coarse_grain_sfc_data_complex
 
 CATEGORY_LIST = ["fv_core.res", "fv_srf_wnd.res", "fv_tracer.res", "sfc_data"]
@@ -109,7 +108,8 @@ def _masked_core_vars(ds, coarsen_agrid_winds):
     return masked_area_weighted_vars
 
 
-def _area_weighted_pressure_means(core, tracer, delp, area, toa_pressure, coarsening_factor, coarsen_agrid_winds, extrapolate):
+def _area_weighted_pressure_means(core, tracer, delp, area, toa_pressure, coarsening_factor, coarsen_agrid_winds, extrapolate,
+                                  side_stream=None, side_work=None):
     """The cell-centred fields of fv_core (W, T, ua, va) and all tracers are remapped between the same two pressure
     grids with the same masked area weights (coarsen_restarts.py:483-495 and :940-961 compute them twice): here
     once -- one pressure context and one multi-field remap for the 11-13 fields -- with identical results per field.
@@ -118,13 +118,10 @@ def _area_weighted_pressure_means(core, tracer, delp, area, toa_pressure, coarse
     names_tracer = FRACTION_TRACERS + NON_FRACTION_TRACERS
     t = to_compat(tracer)[names_tracer].rename({FV_TRACER_Y_CENTER: FV_CORE_Y_CENTER})
     both = merge([to_compat(core)[names_core], t])
-    if fused_block_mean_enabled():  # (opt-in: the remap and the masked mean in one kernel, same values)
-        means = to_compat(area_weighted_pressure_means(both, delp, area, toa_pressure, coarsening_factor, x_dim=FV_CORE_X_CENTER,
-                                                       y_dim=FV_CORE_Y_CENTER, extrapolate=extrapolate))
-        return means[names_core], means[names_tracer].rename({FV_CORE_Y_CENTER: FV_TRACER_Y_CENTER})
-    regridded, masked_area = regrid_to_area_weighted_pressure(
-        both, delp, area, toa_pressure, coarsening_factor, x_dim=FV_CORE_X_CENTER, y_dim=FV_CORE_Y_CENTER, extrapolate=extrapolate)
-    means = to_compat(weighted_block_average(regridded, masked_area, coarsening_factor, x_dim=FV_CORE_X_CENTER, y_dim=FV_CORE_Y_CENTER))
+    # (regrid_to_area_weighted_pressure + weighted_block_average as a two-stream pipeline over groups of four fields)
+    means = to_compat(area_weighted_pressure_means(both, delp, area, toa_pressure, coarsening_factor, x_dim=FV_CORE_X_CENTER,
+                                                   y_dim=FV_CORE_Y_CENTER, extrapolate=extrapolate, side_stream=side_stream,
+                                                   side_work=side_work))
     return means[names_core], means[names_tracer].rename({FV_CORE_Y_CENTER: FV_TRACER_Y_CENTER})
 
 
@@ -132,7 +129,6 @@ def _coarse_grain_fv_core_on_pressure(ds, delp, area, dx, dy, toa_pressure, coar
                                       extrapolate=False, area_means=None, edge_lines=None):
     """coarsen_restarts.py:430-556: delp, DZ, phis on model surfaces, the rest on surfaces of constant pressure.
     ``area_means``: the coarse W, T, (ua, va) when the caller has them already (``_area_weighted_pressure_means``)."""
-    area_weighted_vars = ["phis", "delp", "DZ"]
     masked_area_weighted_vars = _masked_core_vars(ds, coarsen_agrid_winds)
     if area_means is None:
         area_regridded, masked_area = regrid_to_area_weighted_pressure(
@@ -140,6 +136,13 @@ def _coarse_grain_fv_core_on_pressure(ds, delp, area, dx, dy, toa_pressure, coar
             y_dim=FV_CORE_Y_CENTER, extrapolate=extrapolate)
         area_means = weighted_block_average(area_regridded, masked_area, coarsening_factor, x_dim=FV_CORE_X_CENTER,
                                             y_dim=FV_CORE_Y_CENTER)
+    plain, u_mean, v_mean = _fv_core_on_pressure_beside(ds, delp, area, dx, dy, toa_pressure, coarsening_factor, extrapolate, edge_lines)
+    return merge([plain, area_means, u_mean, v_mean])
+
+
+def _fv_core_on_pressure_beside(ds, delp, area, dx, dy, toa_pressure, coarsening_factor, extrapolate=False, edge_lines=None):
+    """What ``_coarse_grain_fv_core_on_pressure`` computes beside the remapped cell-centred fields, none of it depending on
+    them: (phis, delp, DZ on model surfaces; the pressure-level mean of u; of v)."""
     # the D-grid winds: remapped and averaged on the edge lines the average keeps (regridz.edge_weighted_pressure_means ==
     # edge_weighted_block_average(*regrid_to_edge_weighted_pressure(...)), coarsen_restarts.py:497-540)
     edge_lines = edge_lines or {}
@@ -147,12 +150,8 @@ def _coarse_grain_fv_core_on_pressure(ds, delp, area, dx, dy, toa_pressure, coar
                                           y_dim=FV_CORE_Y_OUTER, edge="x", extrapolate=extrapolate, lines=edge_lines.get("x"))
     v_mean = edge_weighted_pressure_means(ds[["v"]], delp, dy, toa_pressure, coarsening_factor, x_dim=FV_CORE_X_OUTER,
                                           y_dim=FV_CORE_Y_CENTER, edge="y", extrapolate=extrapolate, lines=edge_lines.get("y"))
-    return merge([
-        weighted_block_average(ds[area_weighted_vars], area, coarsening_factor, x_dim=FV_CORE_X_CENTER, y_dim=FV_CORE_Y_CENTER),
-        area_means,
-        u_mean,
-        v_mean,
-    ])
+    plain = weighted_block_average(ds[["phis", "delp", "DZ"]], area, coarsening_factor, x_dim=FV_CORE_X_CENTER, y_dim=FV_CORE_Y_CENTER)
+    return plain, u_mean, v_mean
 
 
 def _coarse_grain_fv_tracer_on_pressure(ds, delp, area, toa_pressure, coarsening_factor, extrapolate=False):
@@ -263,12 +262,18 @@ def _names(ds, with_z: bool):
 def _coarse_grain_fv_core_via_blended_method(ds, delp, area, dx, dy, toa_pressure, coarsening_factor, coarsen_agrid_winds=False,
                                              mass_weighted=True, area_means=None):
     """coarsen_restarts.py:679-778."""
+    beside = _fv_core_blended_beside(ds, delp, area, dx, dy, toa_pressure, coarsening_factor, coarsen_agrid_winds, mass_weighted)
+    return _fv_core_blended_finish(ds, beside, area_means, delp, area, toa_pressure, coarsening_factor, coarsen_agrid_winds)
+
+
+def _fv_core_blended_beside(ds, delp, area, dx, dy, toa_pressure, coarsening_factor, coarsen_agrid_winds=False, mass_weighted=True):
+    """Everything of the blended fv_core result that does not depend on the remapped cell-centred fields: the pressure-level
+    winds and model-surface fields, the whole model-level result, the three sets of blending weights."""
     # the edge thicknesses of u and v on the lines their means keep: one interpolation across the cube faces per component,
     # shared by the pressure-level remap and the blending weights
     edge_lines = {"x": EdgeLines(delp, dx, coarsening_factor, "x", FV_CORE_X_CENTER, FV_CORE_Y_OUTER),
                   "y": EdgeLines(delp, dy, coarsening_factor, "y", FV_CORE_X_OUTER, FV_CORE_Y_CENTER)}
-    pressure_level = to_compat(_coarse_grain_fv_core_on_pressure(ds, delp, area, dx, dy, toa_pressure, coarsening_factor,
-                                                                  coarsen_agrid_winds, area_means=area_means, edge_lines=edge_lines))
+    on_pressure = _fv_core_on_pressure_beside(ds, delp, area, dx, dy, toa_pressure, coarsening_factor, False, edge_lines)
     model_level = to_compat(_coarse_grain_fv_core(ds, delp, area, dx, dy, coarsening_factor, coarsen_agrid_winds, mass_weighted))
     weights_agrid = _compute_blending_weights_agrid(delp, area, toa_pressure, coarsening_factor, x_dim=FV_CORE_X_CENTER,
                                                     y_dim=FV_CORE_Y_CENTER)
@@ -276,6 +281,17 @@ def _coarse_grain_fv_core_via_blended_method(ds, delp, area, dx, dy, toa_pressur
                                                 y_dim=FV_CORE_Y_OUTER, lines=edge_lines["x"])
     weights_v = _compute_blending_weights_dgrid(delp, dy, toa_pressure, coarsening_factor, "y", x_dim=FV_CORE_X_OUTER,
                                                 y_dim=FV_CORE_Y_CENTER, lines=edge_lines["y"])
+    return on_pressure, model_level, weights_agrid, weights_u, weights_v
+
+
+def _fv_core_blended_finish(ds, beside, area_means, delp, area, toa_pressure, coarsening_factor, coarsen_agrid_winds):
+    on_pressure, model_level, weights_agrid, weights_u, weights_v = beside
+    if area_means is None:
+        regridded, masked_area = regrid_to_area_weighted_pressure(
+            ds[_masked_core_vars(ds, coarsen_agrid_winds)], delp, area, toa_pressure, coarsening_factor, x_dim=FV_CORE_X_CENTER,
+            y_dim=FV_CORE_Y_CENTER)
+        area_means = weighted_block_average(regridded, masked_area, coarsening_factor, x_dim=FV_CORE_X_CENTER, y_dim=FV_CORE_Y_CENTER)
+    pressure_level = to_compat(merge([on_pressure[0], area_means, on_pressure[1], on_pressure[2]]))
     d = to_compat(ds)
     ignore = ["u", "v"] + ([] if coarsen_agrid_winds else ["ua", "va"])
     names_2d = _names(d, False)
@@ -293,10 +309,16 @@ def _coarse_grain_fv_tracer_via_blended_method(ds, delp, area, toa_pressure, coa
     """coarsen_restarts.py:781-822.  ``pressure_level``: the pressure-level result when the caller has it already."""
     if pressure_level is None:
         pressure_level = _coarse_grain_fv_tracer_on_pressure(ds, delp, area, toa_pressure, coarsening_factor)
+    weights, model_level = _fv_tracer_blended_beside(ds, delp, area, toa_pressure, coarsening_factor, mass_weighted)
+    return blend(weights, pressure_level, model_level)
+
+
+def _fv_tracer_blended_beside(ds, delp, area, toa_pressure, coarsening_factor, mass_weighted=True):
+    """(blending weights, model-level tracers): what the blended tracers need beside their pressure-level means."""
     model_level = _coarse_grain_fv_tracer(ds, delp, area, coarsening_factor, mass_weighted)
     weights = _compute_blending_weights_agrid(delp, area, toa_pressure, coarsening_factor, x_dim=FV_TRACER_X_CENTER,
                                               y_dim=FV_TRACER_Y_CENTER)
-    return blend(weights, pressure_level, model_level)
+    return weights, model_level
 
 
 # ------------------------------------------------------------------------------------------------
@@ -341,6 +363,44 @@ def _entry_event():
     return ev
 
 
+def _side_stream(name, entry_event):
+    """The side stream ``name`` of the device, made to wait for the pipeline's inputs (``entry_event``).  Two side streams
+    per pipeline at most (this one and the surface categories'): the HIP runtime multiplexes streams onto four hardware
+    queues, and kernels of independent streams that share a queue run one after the other."""
+    import torch
+
+    from ._device import compute_device
+
+    dev = compute_device()
+    side = _SIDE_STREAMS.get((dev.index, name))
+    if side is None:
+        side = _SIDE_STREAMS[(dev.index, name)] = torch.cuda.Stream(device=dev)
+    side.wait_event(entry_event)
+    return side
+
+
+def _join(result, side):
+    import torch
+
+    from ._device import compute_device
+
+    main = torch.cuda.current_stream(compute_device())
+    main.wait_stream(side)
+
+    def hand_over(x):  # memory allocated on the side stream, used by the caller's stream from here on
+        if isinstance(x, (tuple, list)):
+            for y in x:
+                hand_over(y)
+            return
+        c = to_compat(x)
+        for da in (c.values() if isinstance(c, Dataset) else [c]):
+            if isinstance(da.data, torch.Tensor) and da.data.is_cuda:
+                da.data.record_stream(main)
+
+    hand_over(result)
+    return result
+
+
 def _common_beside(coarsening_factor, grid_spec, restarts, entry_event):
     """``_common`` on a second HIP stream: the surface categories are some 150 launches on 2-D fields (a few microseconds of
     device time each) that depend on nothing the 3-D categories produce -- issued after them, on a stream of their own that
@@ -352,9 +412,9 @@ def _common_beside(coarsening_factor, grid_spec, restarts, entry_event):
 
     dev = compute_device()
     main = torch.cuda.current_stream(dev)
-    side = _SIDE_STREAMS.get(dev.index)
+    side = _SIDE_STREAMS.get((dev.index, "surface"))
     if side is None:
-        side = _SIDE_STREAMS[dev.index] = torch.cuda.Stream(device=dev)
+        side = _SIDE_STREAMS[(dev.index, "surface")] = torch.cuda.Stream(device=dev)
     side.wait_event(entry_event)
     with torch.cuda.stream(side):
         out = _common(coarsening_factor, grid_spec, restarts)
@@ -394,12 +454,19 @@ def coarsen_restarts_on_pressure(coarsening_factor: int, grid_spec, toa_pressure
     core = to_compat(restarts["fv_core.res"])
     coarsened, entered = {}, _entry_event()
     area = _grid(grid_spec, "area", FV_CORE_X_CENTER, FV_CORE_Y_CENTER)
+    # Two branches that meet at the merge: the remap sweeps of the 11-13 cell-centred fields (latency-bound kernels that fill
+    # the chip's wave slots but not its memory system) on the calling stream, and beside them -- on a stream of its own that
+    # waits only for the inputs -- the D-grid winds on their edge lines and the model-surface fields (short launches, 1 ms).
+    # (the sweeps are ENQUEUED first -- a few launches -- so that the device has its long kernels while the host is still
+    # issuing the many short ones of the other branch: eager calls are bound by the ~20 us of Python per launch)
+    side, beside = _side_stream("beside", entered), []
     core_means, coarsened["fv_tracer.res"] = _area_weighted_pressure_means(
-        core, restarts["fv_tracer.res"], core["delp"], area, toa_pressure, coarsening_factor, coarsen_agrid_winds, extrapolate)
-    coarsened["fv_core.res"] = _coarse_grain_fv_core_on_pressure(
-        core, core["delp"], area, _grid(grid_spec, "dx", FV_CORE_X_CENTER, FV_CORE_Y_OUTER),
-        _grid(grid_spec, "dy", FV_CORE_X_OUTER, FV_CORE_Y_CENTER), toa_pressure, coarsening_factor, coarsen_agrid_winds,
-        extrapolate=extrapolate, area_means=core_means)
+        core, restarts["fv_tracer.res"], core["delp"], area, toa_pressure, coarsening_factor, coarsen_agrid_winds, extrapolate,
+        side_stream=side, side_work=lambda: beside.append(_fv_core_on_pressure_beside(
+            core, core["delp"], area, _grid(grid_spec, "dx", FV_CORE_X_CENTER, FV_CORE_Y_OUTER),
+            _grid(grid_spec, "dy", FV_CORE_X_OUTER, FV_CORE_Y_CENTER), toa_pressure, coarsening_factor, extrapolate)))
+    plain, u_mean, v_mean = _join(beside[0], side)
+    coarsened["fv_core.res"] = merge([plain, core_means, u_mean, v_mean])
     coarsened["fv_core.res"] = _impose_hydrostatic_balance(coarsened["fv_core.res"], coarsened["fv_tracer.res"], toa_pressure)
     coarsened.update(_common_beside(coarsening_factor, grid_spec, restarts, entered))
     return _finish(coarsened, restarts)
@@ -411,16 +478,23 @@ def coarsen_restarts_via_blended_method(coarsening_factor: int, grid_spec, toa_p
     core = to_compat(restarts["fv_core.res"])
     coarsened, entered = {}, _entry_event()
     area = _grid(grid_spec, "area", FV_CORE_X_CENTER, FV_CORE_Y_CENTER)
+    delp_t = core["delp"].rename({FV_CORE_Y_CENTER: FV_TRACER_Y_CENTER})
+    area_t = _grid(grid_spec, "area", FV_TRACER_X_CENTER, FV_TRACER_Y_CENTER)
+    # as in coarsen_restarts_on_pressure: the remap sweeps on the calling stream; beside them everything the blend needs
+    # that does not come out of a sweep (pressure-level winds, the whole model-level result, the blending weights -- HBM-bound
+    # passes that fit beside the latency-bound sweeps)
+    side, beside = _side_stream("beside", entered), []
     core_means, tracer_means = _area_weighted_pressure_means(
-        core, restarts["fv_tracer.res"], core["delp"], area, toa_pressure, coarsening_factor, coarsen_agrid_winds, False)
-    coarsened["fv_core.res"] = _coarse_grain_fv_core_via_blended_method(
-        core, core["delp"], area, _grid(grid_spec, "dx", FV_CORE_X_CENTER, FV_CORE_Y_OUTER),
-        _grid(grid_spec, "dy", FV_CORE_X_OUTER, FV_CORE_Y_CENTER), toa_pressure, coarsening_factor, coarsen_agrid_winds,
-        mass_weighted, area_means=core_means)
-    coarsened["fv_tracer.res"] = _coarse_grain_fv_tracer_via_blended_method(
-        restarts["fv_tracer.res"], core["delp"].rename({FV_CORE_Y_CENTER: FV_TRACER_Y_CENTER}),
-        _grid(grid_spec, "area", FV_TRACER_X_CENTER, FV_TRACER_Y_CENTER), toa_pressure, coarsening_factor, mass_weighted,
-        pressure_level=tracer_means)
+        core, restarts["fv_tracer.res"], core["delp"], area, toa_pressure, coarsening_factor, coarsen_agrid_winds, False,
+        side_stream=side, side_work=lambda: beside.append((
+            _fv_core_blended_beside(core, core["delp"], area, _grid(grid_spec, "dx", FV_CORE_X_CENTER, FV_CORE_Y_OUTER),
+                                    _grid(grid_spec, "dy", FV_CORE_X_OUTER, FV_CORE_Y_CENTER), toa_pressure, coarsening_factor,
+                                    coarsen_agrid_winds, mass_weighted),
+            _fv_tracer_blended_beside(restarts["fv_tracer.res"], delp_t, area_t, toa_pressure, coarsening_factor, mass_weighted))))
+    core_beside, (tracer_weights, tracer_model_level) = _join(beside[0], side)
+    coarsened["fv_core.res"] = _fv_core_blended_finish(core, core_beside, core_means, core["delp"], area, toa_pressure,
+                                                      coarsening_factor, coarsen_agrid_winds)
+    coarsened["fv_tracer.res"] = blend(tracer_weights, tracer_means, tracer_model_level)
     coarsened["fv_core.res"] = _impose_hydrostatic_balance(coarsened["fv_core.res"], coarsened["fv_tracer.res"], toa_pressure)
     coarsened.update(_common_beside(coarsening_factor, grid_spec, restarts, entered))
     return _finish(coarsened, restarts)

@@ -184,12 +184,24 @@ def fused_block_mean_enabled() -> bool:
 
 
 def area_weighted_pressure_means(ds, delp, area, toa_pressure: float, coarsening_factor: int, x_dim: str = FV_CORE_X_CENTER,
-                                 y_dim: str = FV_CORE_Y_CENTER, z_dim: str = RESTART_Z_CENTER, extrapolate: bool = False):
+                                 y_dim: str = FV_CORE_Y_CENTER, z_dim: str = RESTART_Z_CENTER, extrapolate: bool = False,
+                                 side_stream=None, side_work=None):
     """``weighted_block_average(*regrid_to_area_weighted_pressure(ds, delp, area, ...), coarsening_factor)`` -- what the
-    pressure-level restart pipelines do with every cell-centred field (coarsen_restarts.py:483-495, 940-961) -- with the
-    remapped fine fields and the masked area never materialised where the fused kernel applies (factor 8, float32 area,
-    [.., z, y, x] order); anything else takes the two calls.  Identical values and labels either way."""
+    pressure-level restart pipelines do with every cell-centred field (coarsen_restarts.py:483-495, 940-961) -- as a
+    two-stream pipeline over groups of four fields: the remap sweep of group g + 1 (latency-bound, it fills the chip's
+    wave slots but not its memory system) runs on the calling stream while the masked block mean of group g (HBM-bound) and,
+    first of all, the masked area run on a stream beside it.  Same kernels, same values and labels as the two calls.
+    With ``FV3NET_AMD_FUSED_BLOCK_MEAN=1`` (and factor 8, a float32 area) one fused kernel per group instead.
+    Arrays must come in [.., z, y, x] order (the restart files'); anything else takes the two calls.
+    ``side_stream``: the stream to use beside the caller's (the HIP runtime multiplexes streams onto four hardware queues:
+    a pipeline that spreads over more than two or three streams serialises on queue sharing); ``side_work``: a callable that
+    is run -- under ``side_stream`` -- once the first sweep is enqueued, i.e. while the device is busy with it."""
+    import torch
+
     def two_calls():
+        if side_work is not None:
+            with torch.cuda.stream(side_stream):
+                side_work()
         regridded, masked = regrid_to_area_weighted_pressure(ds, delp, area, toa_pressure, coarsening_factor, x_dim=x_dim, y_dim=y_dim,
                                                              z_dim=z_dim, extrapolate=extrapolate)
         return weighted_block_average(regridded, masked, coarsening_factor, x_dim=x_dim, y_dim=y_dim)
@@ -197,27 +209,59 @@ def area_weighted_pressure_means(ds, delp, area, toa_pressure: float, coarsening
     d, dl, ar = to_compat(ds), to_compat(delp), to_compat(area)
     das = [d[v] for v in d] if isinstance(d, Dataset) else [d]
     order = tuple(dl.dims)
-    tail = (z_dim, y_dim, x_dim)
-    if (int(coarsening_factor) != 8 or order[-3:] != tail or any(tuple(a.dims) != order or a.shape != dl.shape for a in das)
-            or tuple(ar.dims[-2:]) != (y_dim, x_dim) or tuple(ar.dims[:-2]) != order[: len(ar.dims) - 2]):
+    f = int(coarsening_factor)
+    if (f < 2 or order[-3:] != (z_dim, y_dim, x_dim) or any(tuple(a.dims) != order or a.shape != dl.shape for a in das)
+            or tuple(ar.dims[-2:]) != (y_dim, x_dim) or tuple(ar.dims[:-2]) != order[: len(ar.dims) - 2]
+            or dl.sizes[y_dim] % f or dl.sizes[x_dim] % f):
         return two_calls()
     delp_t, area_t = on_device(dl.data), on_device(ar.data)
-    if area_t.dtype != torch_float32():
+    fields = [on_device(a.data) for a in das]
+    if any(q.dtype != delp_t.dtype for q in fields) or not delp_t.is_cuda:
         return two_calls()
-    delp_coarse = ops.weighted_block_average(delp_t, area_t, 8)
+    delp_coarse = ops.weighted_block_average(delp_t, area_t, f)
     phalf_fine = ops.pressure_at_interface(delp_t, toa_pressure, -3)
     phalf_coarse = ops.pressure_at_interface(delp_coarse, toa_pressure, -3)
     level = ops.pressure_at_midpoint_log(delp_coarse, toa_pressure, -3) if extrapolate else None
-    fields = [on_device(a.data) for a in das]
-    if any(f.dtype != phalf_fine.dtype for f in fields):
-        return two_calls()
-    means = ops.mappm_block_mean(phalf_fine, fields, phalf_coarse, area_t, level_coarse=level, iv=1, kord=1)
+    means = None
+    if fused_block_mean_enabled() and f == 8 and area_t.dtype == torch.float32:
+        means = ops.mappm_block_mean(phalf_fine, fields, phalf_coarse, area_t, level_coarse=level, iv=1, kord=1)
     if means is None:
-        return two_calls()
+        dev = delp_t.device
+        main = torch.cuda.current_stream(dev)
+        side = side_stream or _MEAN_STREAMS.get((dev.index, main.cuda_stream))
+        if side is None:
+            side = _MEAN_STREAMS[(dev.index, main.cuda_stream)] = torch.cuda.Stream(device=dev)
+        batch = tuple(phalf_fine.shape[:-3])
+        w = area_t
+        if tuple(w.shape[:-2]) != batch:  # the area [tile, y, x] shared by the time axis
+            w = w.reshape(tuple(w.shape[:-2]) + (1,) * (len(batch) - (w.dim() - 2)) + tuple(w.shape[-2:])).expand(*batch, *w.shape[-2:]).contiguous()
+        side.wait_stream(main)
+        with torch.cuda.stream(side):
+            masked = ops.mask_weights(w, level if extrapolate else phalf_coarse, phalf_fine, -3, extrapolate=extrapolate, coarse_factor=f)
+        means = []
+        for g0 in range(0, len(fields), 4):
+            q2 = ops.mappm_multi_coarse_target(phalf_fine, fields[g0:g0 + 4], phalf_coarse, f, iv=1, kord=1, z_axis=-3)
+            if g0 == 0 and side_work is not None:
+                with torch.cuda.stream(side):
+                    side_work()
+                side_work = None
+            side.wait_stream(main)
+            with torch.cuda.stream(side):
+                means.extend(ops.weighted_block_average_multi(q2, masked, f) if len(q2) > 1 else [ops.weighted_block_average(q2[0], masked, f)])
+            for t in q2:
+                t.record_stream(side)
+        main.wait_stream(side)
+        for t in means:   # allocated on the side stream, used by the caller's from here on
+            t.record_stream(main)
+        for t in [w, phalf_fine, phalf_coarse] + ([level] if level is not None else []):   # ... and the other way round
+            t.record_stream(side)
+    if side_work is not None:   # (the fused route, or no field at all)
+        with torch.cuda.stream(side_stream):
+            side_work()
     from .coarsen import _coarsened_coords, coarsen_coords_coord_func
 
     def label(t, a):
-        coords = _coarsened_coords(a, {x_dim: 8, y_dim: 8}, coarsen_coords_coord_func)
+        coords = _coarsened_coords(a, {x_dim: f, y_dim: f}, coarsen_coords_coord_func)
         coords = {k: v for k, v in coords.items() if k != z_dim}   # (regrid_vertical drops the vertical coordinate)
         return DataArray(like_input(t, a.data), dims=a.dims, name=a.name, attrs=a.attrs, coords=coords)
 
@@ -227,6 +271,9 @@ def area_weighted_pressure_means(ds, delp, area, toa_pressure: float, coarsening
     for v, m, a in zip(list(d), means, das):
         out[v] = label(m, a)
     return from_compat(out, ds)
+
+
+_MEAN_STREAMS = {}
 
 
 def torch_float32():
