@@ -843,6 +843,16 @@ __global__ void ew_kernel(int op, const T *__restrict__ a, const T *__restrict__
             case FV3HIP_EW_CLIP01: v = (x != x) ? x : (x < (T)0 ? (T)0 : (x > (T)1 ? (T)1 : x)); break;  // np.clip(a, 0, 1)
             case FV3HIP_EW_POW_BASE_S: v = (T)pow((double)s, (double)x); break;                            // scalar ** a
             case FV3HIP_EW_MINIMUM_S: v = (x != x) ? x : (x < s ? x : s); break;                           // np.minimum(a, scalar)
+            case FV3HIP_EW_DIV: v = x / y; break;
+            case FV3HIP_EW_WHERE_POS_S: v = (y > (T)0) ? x : s; break;                                     // xr.where(b > 0, a, scalar)
+            case FV3HIP_EW_SIGN: v = (x != x) ? x : (x > (T)0 ? (T)1 : (x < (T)0 ? (T)-1 : (T)0)); break;  // np.sign: NaN stays, +-0 -> 0
+            case FV3HIP_EW_ABS: v = (x < 0) ? -x : ((x == 0) ? (T)0 : x); break;                           // np.abs (-0 -> +0)
+            case FV3HIP_EW_RSUB_S: v = s - x; break;
+            case FV3HIP_EW_RDIV_S: v = s / x; break;
+            case FV3HIP_EW_WHERE_GT_S: v = (x > s) ? x : s; break;                                         // a.where(a > scalar, scalar): a NaN becomes scalar
+            case FV3HIP_EW_LE_S: v = (x <= s) ? (T)1 : (T)0; break;
+            case FV3HIP_EW_SIN: v = sin(x); break;
+            case FV3HIP_EW_COS: v = cos(x); break;
             case FV3HIP_EW_INCLOUD_TO_GRIDCELL: {  // vcm/calc/clouds.py:40-66 (a = cloud fraction, b = in-cloud condensate; CLIMIT1 = 1e-3, CLIMIT2 = 5e-2)
                 const T rectified = (x > (T)5.0e-2) ? x : (T)5.0e-2;
                 v = (x <= (T)1.0e-3) ? y : y * rectified;
@@ -1173,7 +1183,7 @@ extern "C" int fv3hip_ew(int op, const void *a, const void *b, const void *c, do
                          int64_t inner, int64_t b_rep, int64_t c_rep, void *out, void *stream)
 {
     FV3HIP_REQUIRE(dtype == FV3HIP_F32 || dtype == FV3HIP_F64, "dtype must be F32 or F64");
-    FV3HIP_REQUIRE(op >= FV3HIP_EW_MUL && op <= FV3HIP_EW_MINIMUM_S, "unknown elementwise op %d", op);
+    FV3HIP_REQUIRE(op >= FV3HIP_EW_MUL && op <= FV3HIP_EW_COS, "unknown elementwise op %d", op);
     FV3HIP_REQUIRE(n >= 0 && inner >= 1 && b_rep >= 1 && c_rep >= 1, "bad extents");
     if (n == 0) return FV3HIP_OK;
     FV3HIP_REQUIRE(a && out, "null pointer");

@@ -1,9 +1,8 @@
 """``DerivedMapping`` for the variables that ML predictions are turned into right after the network
 (external/vcm/vcm/derived_mapping.py:8-112 for the mechanics; :197-250 the surface shortwave fluxes via albedo /
 transmissivity, :417-448 Q1 / Q2 / pQ1 / pQ2) and ``DerivedModel`` (external/fv3fit/fv3fit/_shared/models.py:110-220).
-The element-wise arithmetic runs on the device (``fv3hip_ew``).  The rest of the reference's mapping (winds,
-cos zenith angle, land / sea masks, EAMXX radiation splits, ...) derives model *inputs* and is not part of this path:
-asking for such a variable fails like an unknown name does in the reference."""
+The element-wise arithmetic runs on the device (``fv3hip_ew``).  The rest of the reference's mapping (winds, cos zenith
+angle, land / sea masks, EAMXX radiation splits, column integrals, ...) registers itself from ``derived_more``."""
 import os
 from typing import Callable, Hashable, Iterable, List, Mapping, MutableMapping, Sequence
 
@@ -208,3 +207,6 @@ class DerivedModel(Predictor):
         if len(invalid) > 0:
             raise ValueError(f"Invalid variables {invalid} provided in init arg derived_output_variables. Variables in this "
                              "arg must be available as derived variables in vcm.DerivedMapping.")
+
+
+from . import derived_more  # noqa: E402,F401  (registers the rest of the reference's derived variables)

@@ -506,7 +506,8 @@ def interpolate_2d(xp: torch.Tensor, x: torch.Tensor, y: torch.Tensor, fill_valu
 EW_OPS = {"mul": 0, "isclose": 1, "isclose_s": 2, "where_nan": 3, "select": 4, "select_s": 5, "gt_s": 6, "lt_s": 7,
           "fillna_s": 8, "and": 9, "min_s": 10, "blend": 11, "mul_s": 12, "where_s": 13, "add": 14, "add_s": 15,
           "sub": 16, "log_floor_s": 17, "exp": 18, "relu_threshold_s": 19, "below_s": 20, "div_s": 21, "incloud_to_gridcell": 22,
-          "clip01": 23, "pow_base_s": 24, "minimum_s": 25}
+          "clip01": 23, "pow_base_s": 24, "minimum_s": 25, "div": 26, "where_pos_s": 27, "sign": 28, "abs": 29, "rsub_s": 30,
+          "rdiv_s": 31, "where_gt_s": 32, "le_s": 33, "sin": 34, "cos": 35}
 
 
 def ew(op: str, a: torch.Tensor, b: Optional[torch.Tensor] = None, c: Optional[torch.Tensor] = None,

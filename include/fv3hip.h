@@ -199,6 +199,17 @@ int fv3hip_block_upsample(const void *in, int elem_size, int64_t n_outer, int ny
 #define FV3HIP_EW_CLIP01 23            /* np.clip(a, 0, 1), a NaN stays        (taper_ramp, fv3fit/_shared/taper_function.py:41-51) */
 #define FV3HIP_EW_POW_BASE_S 24        /* scalar ** a                          (taper_decay, taper_function.py:54-64) */
 #define FV3HIP_EW_MINIMUM_S 25         /* np.minimum(a, scalar), a NaN stays   (taper_decay) */
+/* ... and of the derived variables of vcm.DerivedMapping (external/vcm/vcm/derived_mapping.py) */
+#define FV3HIP_EW_DIV 26               /* a / b                                (flux fractions, transmissivity :247-262) */
+#define FV3HIP_EW_WHERE_POS_S 27       /* a where b > 0 else scalar            (_limit_sw_positive :243-244) */
+#define FV3HIP_EW_SIGN 28              /* np.sign(a)                           (tendencies parallel to the wind :167-176) */
+#define FV3HIP_EW_ABS 29               /* |a| */
+#define FV3HIP_EW_RSUB_S 30            /* scalar - a                           (1 - fraction :293-295) */
+#define FV3HIP_EW_RDIV_S 31            /* scalar / a                           (gridcell_to_incloud_condensate, calc/clouds.py:33) */
+#define FV3HIP_EW_WHERE_GT_S 32        /* a.where(a > scalar, other=scalar)    (calc/clouds.py:33) */
+#define FV3HIP_EW_LE_S 33              /* a <= scalar                          (calc/clouds.py:34-36) */
+#define FV3HIP_EW_SIN 34               /* sin(a)                               (cos_zenith_angle, calc/_zenith_angle.py:226-242) */
+#define FV3HIP_EW_COS 35               /* cos(a) */
 int fv3hip_ew(int op, const void *a, const void *b, const void *c, double scalar, int dtype,
               int64_t n, int64_t inner, int64_t b_rep, int64_t c_rep, void *out, void *stream);
 
