@@ -27,6 +27,10 @@ python3 $R/benchmarks/remap_sweep_timing.py --label r03 > $O/remap_timing_iid.js
 python3 $R/benchmarks/remap_sweep_timing.py --label r03 --noise 0.1 > $O/remap_timing_smooth.json 2>/dev/null
 # 7. the pressure-level pipeline: kernel statistics of five calls
 rocprofv3 --kernel-trace --stats --output-format csv -d $O/stats_pipeline -- python3 $R/benchmarks/pressure_pipeline_once.py > $O/stats_pipeline.log 2>&1 || exit 1
+# 7b. the fused remap + block mean against the three launches, both data sets; the pipelines in both arithmetics
+python3 $R/benchmarks/block_mean_timing.py > $O/block_mean_iid.json 2>/dev/null
+python3 $R/benchmarks/block_mean_timing.py --noise 0.1 > $O/block_mean_smooth.json 2>/dev/null
+python3 $R/benchmarks/pipelines_quick.py > $O/pipelines_quick.jsonl 2>/dev/null
 # 8. vector-instruction issue rates
 $R/benchmarks/valu_ubench/valu_rate > $O/r03_valu_issue_rates.txt 2>&1
 find $O -name "*.csv" | wc -l
