@@ -403,7 +403,7 @@ def remap_benchmark(dev, steps):
                     torch.cuda.synchronize(dev)
                     ms = time_kernel(fn, reps, dev)
                     alg = ncol * ((NZ + 1) * e + nf * NZ * e + nf * NZ * 4) + p2.numel() * e
-                    name = f"mappm_sweep_kernel<{dname}, {1 if nf == 1 else 2}, {1 if nf == 1 else 2}, {'true' if arith == 'fast' else 'false'}, true>"
+                    name = f"mappm_sweep_kernel<{dname}, {1 if nf == 1 else 2}, {1 if nf == 1 else 2}, {'true' if arith == 'fast' else 'false'}, true, false>"
                     out.append({
                         "kernel": f"{name} (arith={arith})",
                         "workload": f"C384 884736 columns x {nf} field(s), km=kn=79, coarse-pressure target, {data_label}",

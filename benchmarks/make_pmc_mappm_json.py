@@ -23,17 +23,17 @@ csv.field_size_limit(1 << 30)
 def static_resources():
     d = tempfile.mkdtemp()
     flags = "-O3 -std=c++17 -fPIC --offload-arch=gfx950 -ffp-contract=off -Wno-unused-value -mllvm -pragma-unroll-threshold=262144".split()
-    subprocess.run(["/opt/rocm/bin/hipcc", *flags, "--save-temps=obj", "-c", os.path.join(ROOT, "fv3net_amd", "csrc", "remap.hip"),
+    subprocess.run(["/opt/rocm/bin/hipcc", *flags, "--save-temps=obj", "-DFV3HIP_REMAP_PART_SWEEP", "-I" + os.path.join(ROOT, "include"), "-c", os.path.join(ROOT, "fv3net_amd", "csrc", "remap.hip"),
                     "-o", os.path.join(d, "x.o")], check=True, capture_output=True)
     asm = open([os.path.join(d, f) for f in os.listdir(d) if f.endswith("gfx950.s")][0]).read()
     out = {}
     for m in re.finditer(r"\.name:\s+(\S+)\n(.*?)\.vgpr_count:\s+(\d+)", asm, re.S):
         name, body, vgpr = m.group(1), m.group(2), int(m.group(3))
-        t = re.search(r"mappm_sweep_kernelI([fd])Li(\d)ELi(\d)ELb([01])ELb([01])E", name)
+        t = re.search(r"mappm_sweep_kernelI([fd])Li(\d)ELi(\d)ELb([01])ELb([01])ELb([01])E", name)
         if not t:
             continue
-        key = "mappm_sweep_kernel<%s, %s, %s, %s, %s>" % ("float" if t.group(1) == "f" else "double", t.group(2), t.group(3),
-                                                          "true" if t.group(4) == "1" else "false", "true" if t.group(5) == "1" else "false")
+        tf = lambda g: "true" if t.group(g) == "1" else "false"
+        key = "mappm_sweep_kernel<%s, %s, %s, %s, %s, %s>" % ("float" if t.group(1) == "f" else "double", t.group(2), t.group(3), tf(4), tf(5), tf(6))
         sg = re.search(r"\.sgpr_count:\s+(\d+)", body)
         out[key] = {"vgpr": vgpr, "sgpr": int(sg.group(1)) if sg else None, "waves_per_simd_by_vgpr": min(8, 512 // (-(-vgpr // 8) * 8))}
     return out
