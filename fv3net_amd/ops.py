@@ -938,6 +938,8 @@ def mappm_block_mean(pe1: torch.Tensor, fields: Sequence[torch.Tensor], pe2_coar
     if tuple(area.shape[-2:]) != (ny, nx) or lead != batch[: len(lead)]:
         raise ValueError(f"area of shape {tuple(area.shape)} does not lead the fields' {tuple(q1.shape)}")
     nb = _prod(batch)
+    if min(len(fields), 4) * nb * kn * ny * nx * 4 > _BLOCK_MEAN_SCRATCH_LIMIT:
+        return None   # (the scratch rows are fine-size: 71 GB for a whole C3072 cube -- such calls take the three launches)
     area_repeat = nb // max(_prod(lead), 1)
     pe1, pe2_coarse, lvl, area = pe1.contiguous(), pe2_coarse.contiguous(), lvl.contiguous(), area.contiguous()
     fields = [q.contiguous() for q in fields]
@@ -962,6 +964,7 @@ def mappm_block_mean(pe1: torch.Tensor, fields: Sequence[torch.Tensor], pe2_coar
 
 
 _scratch = {}
+_BLOCK_MEAN_SCRATCH_LIMIT = 24 << 30   # bytes of scratch the fused remap + block mean may hold per (device, stream)
 
 
 def _scratch_rows(dev, n: int, numel: int) -> list:
