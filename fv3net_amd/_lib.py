@@ -82,6 +82,7 @@ class MlpDesc(ctypes.Structure):
 SIGNATURES = {
     "fv3hip_last_error": (c_char_p, []),
     "fv3hip_abi_version": (c_int, []),
+    "fv3hip_spin": (c_int, [c_int64, c_int, c_void_p]),
     "fv3hip_init": (c_int, [c_int]),
     "fv3hip_device_info": (c_int, [POINTER(DeviceInfo)]),
     "fv3hip_weighted_block_average": (

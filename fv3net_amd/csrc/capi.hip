@@ -64,6 +64,26 @@ struct fv3hip_timer {
     hipEvent_t start, stop;
 };
 
+// Wavefronts that do nothing for `microseconds` each (bounded: the loop ends when the 100 MHz wall clock has advanced that far).
+// For the host layer's stream calibration: how soon does a small kernel on one stream start beside a grid on another that takes
+// several rounds to dispatch?  At once where the two streams sit on different dispatch pipes, after the grid where they share
+// one (the runtime multiplexes streams onto four hardware queues) -- see fv3net_amd/cubedsphere/_device.py.
+__global__ void spin_kernel(long long ticks)
+{
+    const long long t0 = wall_clock64();
+    while (wall_clock64() - t0 < ticks) {
+    }
+}
+
+extern "C" int fv3hip_spin(int64_t microseconds, int n_workgroups, void *stream)
+{
+    FV3HIP_REQUIRE(microseconds >= 0 && microseconds <= 100000, "spin time must be within [0, 100000] microseconds");
+    FV3HIP_REQUIRE(n_workgroups >= 1 && n_workgroups <= (1 << 20), "n_workgroups must be within [1, 2^20]");
+    hipLaunchKernelGGL(spin_kernel, dim3((unsigned)n_workgroups), dim3(64), 0, static_cast<hipStream_t>(stream), (long long)microseconds * 100);
+    if (hipGetLastError() != hipSuccess) return fail(FV3HIP_EHIP, "spin_kernel launch failed");
+    return FV3HIP_OK;
+}
+
 extern "C" int fv3hip_timer_create(fv3hip_timer_t *out)
 {
     FV3HIP_REQUIRE(out, "null pointer");

@@ -8,6 +8,7 @@ on the ``grid_xt/grid_yt/grid_x/grid_y`` dims.  Returns the same mapping, ``coar
 coarser.  The reference's regression fixtures for all seven configurations are reproduced through
 these functions (tests/test_gpu_api.py).
 """
+import os
 from typing import Hashable, Mapping
 
 from .. import ops
@@ -347,9 +348,6 @@ def _common(coarsening_factor, grid_spec, restarts):
     return out
 
 
-_SIDE_STREAMS = {}
-
-
 def _entry_event():
     """An event on the calling stream at the moment a pipeline is entered: what the surface categories' side stream has to
     wait for (the caller's inputs) -- not the 3-D work the pipeline enqueues afterwards."""
@@ -372,32 +370,26 @@ def _side_stream(name, entry_event):
     from ._device import compute_device
 
     dev = compute_device()
-    side = _SIDE_STREAMS.get((dev.index, name))
-    if side is None:
-        side = _SIDE_STREAMS[(dev.index, name)] = torch.cuda.Stream(device=dev)
+    if os.environ.get("FV3NET_AMD_PIPELINE_STREAMS", "1") == "0":   # (everything on the calling stream: for A/B timing)
+        return torch.cuda.current_stream(dev)
+    from ._device import side_streams
+
+    side = side_streams(dev)[{"beside": 0, "surface": 1}[name]]
     side.wait_event(entry_event)
     return side
 
 
 def _join(result, side):
+    """The calling stream waits for ``side``; ``result`` (memory of the side stream's pool) is the caller's from here on.
+    No ``record_stream``: a block that returns to the side stream's pool is handed out again only to work on that stream, and
+    every use of a side stream begins by waiting for an event the calling stream records at the NEXT pipeline entry --
+    after whatever the caller enqueued on these results before dropping them.  (Recording ~70 small arrays per call made
+    the allocator track an event per array and cost the eager call more than the overlap gained.)"""
     import torch
 
     from ._device import compute_device
 
-    main = torch.cuda.current_stream(compute_device())
-    main.wait_stream(side)
-
-    def hand_over(x):  # memory allocated on the side stream, used by the caller's stream from here on
-        if isinstance(x, (tuple, list)):
-            for y in x:
-                hand_over(y)
-            return
-        c = to_compat(x)
-        for da in (c.values() if isinstance(c, Dataset) else [c]):
-            if isinstance(da.data, torch.Tensor) and da.data.is_cuda:
-                da.data.record_stream(main)
-
-    hand_over(result)
+    torch.cuda.current_stream(compute_device()).wait_stream(side)
     return result
 
 
@@ -412,17 +404,13 @@ def _common_beside(coarsening_factor, grid_spec, restarts, entry_event):
 
     dev = compute_device()
     main = torch.cuda.current_stream(dev)
-    side = _SIDE_STREAMS.get((dev.index, "surface"))
-    if side is None:
-        side = _SIDE_STREAMS[(dev.index, "surface")] = torch.cuda.Stream(device=dev)
+    from ._device import side_streams
+
+    side = side_streams(dev)[1]   # (also under the A/B switch, which moves the 3-D branches only)
     side.wait_event(entry_event)
     with torch.cuda.stream(side):
         out = _common(coarsening_factor, grid_spec, restarts)
-    main.wait_stream(side)
-    for ds in out.values():  # memory allocated on the side stream, used by the caller's stream from here on
-        for da in to_compat(ds).values():
-            if isinstance(da.data, torch.Tensor) and da.data.is_cuda:
-                da.data.record_stream(main)
+    main.wait_stream(side)   # (memory of the side stream's pool, the caller's from here on: see _join)
     return out
 
 

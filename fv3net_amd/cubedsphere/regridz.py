@@ -228,9 +228,11 @@ def area_weighted_pressure_means(ds, delp, area, toa_pressure: float, coarsening
     if means is None:
         dev = delp_t.device
         main = torch.cuda.current_stream(dev)
-        side = side_stream or _MEAN_STREAMS.get((dev.index, main.cuda_stream))
-        if side is None:
-            side = _MEAN_STREAMS[(dev.index, main.cuda_stream)] = torch.cuda.Stream(device=dev)
+        if side_stream is None:
+            from ._device import side_streams
+
+            side_stream = side_streams(dev)[0]
+        side = side_stream
         batch = tuple(phalf_fine.shape[:-3])
         w = area_t
         if tuple(w.shape[:-2]) != batch:  # the area [tile, y, x] shared by the time axis
@@ -238,7 +240,7 @@ def area_weighted_pressure_means(ds, delp, area, toa_pressure: float, coarsening
         side.wait_stream(main)
         with torch.cuda.stream(side):
             masked = ops.mask_weights(w, level if extrapolate else phalf_coarse, phalf_fine, -3, extrapolate=extrapolate, coarse_factor=f)
-        means = []
+        means, remapped = [], []
         for g0 in range(0, len(fields), 4):
             q2 = ops.mappm_multi_coarse_target(phalf_fine, fields[g0:g0 + 4], phalf_coarse, f, iv=1, kord=1, z_axis=-3)
             if g0 == 0 and side_work is not None:
@@ -248,13 +250,13 @@ def area_weighted_pressure_means(ds, delp, area, toa_pressure: float, coarsening
             side.wait_stream(main)
             with torch.cuda.stream(side):
                 means.extend(ops.weighted_block_average_multi(q2, masked, f) if len(q2) > 1 else [ops.weighted_block_average(q2[0], masked, f)])
-            for t in q2:
-                t.record_stream(side)
+            remapped.append(q2)   # (kept until the join: freed now, the next sweep would write into it while the mean still reads)
         main.wait_stream(side)
-        for t in means:   # allocated on the side stream, used by the caller's from here on
-            t.record_stream(main)
-        for t in [w, phalf_fine, phalf_coarse] + ([level] if level is not None else []):   # ... and the other way round
-            t.record_stream(side)
+        # Memory crossed the two streams in both directions without `record_stream`: what the calling stream allocated and the
+        # side stream read (remapped fields, pressures, weights) stays referenced until this join; what the side stream
+        # allocated (the means) returns to ITS pool when the caller drops it, and that pool serves only work that begins by
+        # waiting for the calling stream again.
+        del remapped
     if side_work is not None:   # (the fused route, or no field at all)
         with torch.cuda.stream(side_stream):
             side_work()
@@ -271,9 +273,6 @@ def area_weighted_pressure_means(ds, delp, area, toa_pressure: float, coarsening
     for v, m, a in zip(list(d), means, das):
         out[v] = label(m, a)
     return from_compat(out, ds)
-
-
-_MEAN_STREAMS = {}
 
 
 def torch_float32():

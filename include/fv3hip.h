@@ -477,6 +477,10 @@ int64_t fv3hip_mlp3_flops_per_sample(fv3hip_mlp3_t model);
 int fv3hip_mlp3_predict(fv3hip_mlp3_t model, const void *const *sources, const int64_t *src_feat_stride, int64_t n_samples,
                         void *const *outputs, const int64_t *out_feat_stride, void *stream);
 
+/* `n_workgroups` idle wavefronts of `microseconds` (<= 100000) each on `stream`: the host layer times a small one beside a large one
+ * on another stream to learn which streams the runtime lets run side by side (cubedsphere/_device.py: the pipelines' side streams). */
+int fv3hip_spin(int64_t microseconds, int n_workgroups, void *stream);
+
 /* ------------------------------------------------------------------------------------------
  * Timing helper: HIP events on the caller's stream (bench.py measures kernels with these
  * because torch.cuda.Event only sees torch's current stream).
