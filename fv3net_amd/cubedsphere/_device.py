@@ -91,7 +91,7 @@ def side_streams(dev: torch.device, n: int = 2):
     if picked is None:
         import ctypes
 
-        candidates = [torch.cuda.Stream(device=dev) for _ in range(5)]
+        candidates = [torch.cuda.Stream(device=dev) for _ in range(5)]   # (stream priorities changed nothing measurable)
         spin = lambda stream, us, wgs: _lib.call_on(dev, "fv3hip_spin", us, wgs, ctypes.c_void_p(stream.cuda_stream))
         for s in candidates + [main]:   # first use (the runtime binds a stream to its queue lazily)
             spin(s, 20, 1)
