@@ -5,18 +5,20 @@ R=$(cd "$(dirname "$0")/.." && pwd)
 O=$R/gpurun_out/r03_profiles
 P=$R/profiles
 cp $O/r03_bench.json $P/r03_bench.json
-cp $O/stats_headline/*/*_kernel_stats.csv $P/r03_bench_kernel_stats.csv
-cp $O/stats_all/*/*_kernel_stats.csv $P/r03_bench_kernel_stats_with_secondary.csv
-cp $O/stats_pipeline/*/*_kernel_stats.csv $P/r03_pressure_pipeline_kernel_stats.csv
+newest() { ls -t $1 | head -1; }   # (gpurun merges every call's files into gpurun_out/: take the latest run of each pass)
+cp $(newest "$O/stats_headline/*/*_kernel_stats.csv") $P/r03_bench_kernel_stats.csv
+cp $(newest "$O/stats_all/*/*_kernel_stats.csv") $P/r03_bench_kernel_stats_with_secondary.csv
+cp $(newest "$O/stats_pipeline/*/*_kernel_stats.csv") $P/r03_pressure_pipeline_kernel_stats.csv
 cp $O/remap_timing_iid.json $P/r03_remap_timing_iid.json
 cp $O/remap_timing_smooth.json $P/r03_remap_timing_smooth.json
-cp $O/r03_valu_issue_rates.txt $P/r03_valu_issue_rates.txt
+grep -q "No such file" $O/r03_valu_issue_rates.txt || cp $O/r03_valu_issue_rates.txt $P/r03_valu_issue_rates.txt   # (the microbenchmark binary is built by hand: benchmarks/valu_ubench)
 cp $O/pipelines_quick.jsonl $P/r03_pipelines_eager_and_graph.jsonl
 python3 - $O $P <<'PY'
 import csv, glob, json, sys
 O, P = sys.argv[1:3]
 # the headline's dispatches one by one: 10 warm-ups, then the 10 timed (bench.py --steps 10 --warmup 10 --no-parity)
-rows = [r for r in csv.DictReader(open(glob.glob(f"{O}/stats_headline/*/*_kernel_trace.csv")[0])) if "mlp_fused_kernel" in r["Kernel_Name"]]
+import os
+rows = [r for r in csv.DictReader(open(max(glob.glob(f"{O}/stats_headline/*/*_kernel_trace.csv"), key=os.path.getmtime))) if "mlp_fused_kernel" in r["Kernel_Name"]]
 rows.sort(key=lambda r: int(r["Start_Timestamp"]))
 with open(f"{P}/r03_bench_kernel_trace_headline.csv", "w", newline="") as f:
     w = csv.writer(f)
@@ -32,13 +34,13 @@ json.dump({"command": "python benchmarks/block_mean_timing.py [--noise 0.1]  (HI
            "configs[2] data (iid delp)": json.load(open(f"{O}/block_mean_iid.json")),
            "smooth delp (a tenth of the spread)": json.load(open(f"{O}/block_mean_smooth.json"))}, open(f"{P}/r03_block_mean_timing.json", "w"), indent=1)
 PY
-F=$(ls $O/pmc_fetch/*/*_counter_collection.csv); W=$(ls $O/pmc_write/*/*_counter_collection.csv)
+F=$(newest "$O/pmc_fetch/*/*_counter_collection.csv"); W=$(newest "$O/pmc_write/*/*_counter_collection.csv")
 python3 $R/benchmarks/make_pmc_json.py traffic $P/r03_pmc_traffic.json \
   "mlp_fused_kernel<8,false,true,false,false,false> epilogue=residual::=mlp_fused_kernel<8, false, true, false, false, false>:wide:max" \
   "wavg_block_kernel<float,float,8> C3072->C384::=wavg_block_kernel<float, float, 8>:wide:max" \
   "mass_wavg_block_kernel<double,float,8,4> C384::=mass_wavg_block_kernel<double, float, 8, 4>:wide:max" \
   "mappm_sweep_kernel<double,2,2,true,true>::=mappm_sweep_kernel<double, 2, 2, true, true, false>:max" -- $F $W
 rm -rf /tmp/iid /tmp/smooth; mkdir -p /tmp/iid /tmp/smooth
-for p in pmc_mappm1 pmc_mappm2 pmc_mappm3; do mkdir -p /tmp/iid/$p; cp $O/$p/*/*_counter_collection.csv /tmp/iid/$p/; done
-mkdir -p /tmp/smooth/pmc_mappm1; cp $O/pmc_mappm1s/*/*_counter_collection.csv /tmp/smooth/pmc_mappm1/
+for p in pmc_mappm1 pmc_mappm2 pmc_mappm3; do mkdir -p /tmp/iid/$p; cp $(newest "$O/$p/*/*_counter_collection.csv") /tmp/iid/$p/; done
+mkdir -p /tmp/smooth/pmc_mappm1; cp $(newest "$O/pmc_mappm1s/*/*_counter_collection.csv") /tmp/smooth/pmc_mappm1/
 python3 $R/benchmarks/make_pmc_mappm_json.py $P/r03_pmc_mappm.json "configs[2] data (iid delp)=/tmp/iid" "smooth delp (0.1 of the spread)=/tmp/smooth"

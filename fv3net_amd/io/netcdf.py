@@ -35,6 +35,18 @@ def _open(path: str, mode: str = "r"):
     return netcdf_file(path, mode, mmap=(mode == "r"), version=2)
 
 
+_POOL = None
+
+
+def _copy_pool():
+    global _POOL
+    if _POOL is None:
+        from concurrent.futures import ThreadPoolExecutor
+
+        _POOL = ThreadPoolExecutor(max_workers=max(1, min(8, os.cpu_count() or 1)), thread_name_prefix="fv3net-amd-nc")
+    return _POOL
+
+
 class SubtileSet:
     """The sub-tile files of one tile, opened (memory-mapped) together."""
 
@@ -78,7 +90,7 @@ class SubtileSet:
             out = np.empty(shape, dtype=self.dtypes[name])
         elif tuple(out.shape) != shape:
             raise ValueError(f"out has shape {out.shape}, variable {name!r} of this tile has {shape}")
-        covered = 0
+        covered, pieces = 0, []
         for f in self.files:
             var = f.variables[name]
             sel = []
@@ -92,10 +104,13 @@ class SubtileSet:
                 if not np.array_equal(axis[i0:i0 + c.size], c):
                     raise ValueError(f"coordinate {dim!r} of {f.filename} is not a contiguous run of the tile's axis")
                 sel.append(slice(i0, i0 + c.size))
-            np.copyto(out[tuple(sel)], var.data)  # (byte swap from the file's big-endian values)
+            pieces.append((tuple(sel), var.data))
             covered += int(np.prod(var.shape))
         if covered != int(np.prod(shape)):
             raise ValueError(f"the sub-tiles of {name!r} cover {covered} of {int(np.prod(shape))} points")
+        # the copies byte-swap the files' big-endian values into place; numpy releases the GIL inside them, so the sub-tiles of a
+        # tile are copied side by side (page-cache reads at 3 GB/s with one thread)
+        list(_copy_pool().map(lambda piece: np.copyto(out[piece[0]], piece[1]), pieces))
         return out
 
     def coords(self) -> Dict[str, np.ndarray]:

@@ -191,3 +191,30 @@ def test_pipelines_with_the_fused_route_are_unchanged(method, monkeypatch):
             assert np.array_equal(np.asarray(g.values), np.asarray(w.values), equal_nan=True), (category, var)
             n += 1
     assert n >= 55
+
+
+def test_side_streams_and_the_one_stream_switch(monkeypatch):
+    """The pipelines' two side streams come from a one-time probe of the hardware queues (cubedsphere/_device.py); with
+    FV3NET_AMD_PIPELINE_STREAMS=0 the three-dimensional branches share the calling stream -- the same values either way."""
+    from fv3net_amd.cubedsphere import coarsen_restarts_on_pressure
+    from fv3net_amd.cubedsphere._device import side_streams
+    from fv3net_amd.xr_compat import DataArray, Dataset
+    import coarsen_restarts_cases as cases
+
+    dev = _dev()
+    a, b = side_streams(dev)
+    main = torch.cuda.current_stream(dev)
+    assert len({a.cuda_stream, b.cuda_stream, main.cuda_stream}) == 3
+    assert [s.cuda_stream for s in side_streams(dev)] == [a.cuda_stream, b.cuda_stream]   # cached
+    meta, _ = cases.load()
+    inp = cases.medium_inputs(meta, 32, 16, seed=9)
+    dataset = lambda c: Dataset({v: DataArray(x, dims=d, name=v) for v, (d, x) in inp[c].items()})
+    restarts = {c: dataset(c) for c in ("fv_core.res", "fv_tracer.res", "fv_srf_wnd.res", "sfc_data")}
+    grid_spec = dataset("grid")
+    monkeypatch.setenv("FV3NET_AMD_PIPELINE_STREAMS", "1")
+    two = coarsen_restarts_on_pressure(8, grid_spec, 300.0, restarts, coarsen_agrid_winds=True)
+    monkeypatch.setenv("FV3NET_AMD_PIPELINE_STREAMS", "0")
+    one = coarsen_restarts_on_pressure(8, grid_spec, 300.0, restarts, coarsen_agrid_winds=True)
+    for category in two:
+        for var in two[category]:
+            assert np.array_equal(np.asarray(two[category][var].values), np.asarray(one[category][var].values), equal_nan=True), (category, var)
