@@ -174,13 +174,53 @@ def regrid_to_area_weighted_pressure(ds, delp, area, toa_pressure: float, coarse
                               extrapolate=extrapolate)
 
 
-def fused_block_mean_enabled() -> bool:
-    """``FV3NET_AMD_FUSED_BLOCK_MEAN=1`` routes the pressure-level means of cell-centred fields through the fused remap +
-    block-mean kernel (``ops.mappm_block_mean``).  Off by default: identical results, faster only where the 64 columns of
-    a coarse cell stay within a few target layers of each other."""
+def fused_block_mean_mode() -> str:
+    """``FV3NET_AMD_FUSED_BLOCK_MEAN`` = ``0`` | ``1`` | ``auto`` (default): whether the pressure-level means of cell-centred
+    fields go through the fused remap + block-mean kernel (``ops.mappm_block_mean``) -- never, always, or while it pays:
+    the kernel is faster where the 64 columns of a coarse cell stay within a few target layers of each other (a real restart
+    file; 12-14 % of a whole pressure-level pipeline call) and slower where they do not (BASELINE configs[2]'s iid
+    thicknesses), the values are the same either way, and the kernel counts the blocks whose waves ran out of
+    ring.  ``auto`` starts fused, reads that count -- asynchronously, when the next call of the same shape begins -- and
+    takes the three launches while more than 40 % of the blocks gave up, looking again every 64th call."""
     import os
 
-    return os.environ.get("FV3NET_AMD_FUSED_BLOCK_MEAN", "0").lower() in ("1", "true", "on")
+    v = os.environ.get("FV3NET_AMD_FUSED_BLOCK_MEAN", "auto").lower()
+    return {"0": "0", "false": "0", "off": "0", "1": "1", "true": "1", "on": "1"}.get(v, "auto")
+
+
+_FUSED_ROUTE = {}   # (device, shape, dtype, fields) -> the adaptive route's state
+
+
+def _use_fused(key, n_blocks: int) -> bool:
+    mode = fused_block_mean_mode()
+    if mode != "auto":
+        return mode == "1"
+    import torch
+
+    if torch.cuda.is_current_stream_capturing():   # (a captured call keeps the route it is captured with: the static default)
+        return False
+    st = _FUSED_ROUTE.setdefault(key, {"fused": True, "pending": None, "calls_since": 0})
+    pending = st["pending"]
+    if pending is not None and pending[1].query():
+        st["fused"] = int(pending[0][2]) * 10 <= 4 * n_blocks   # blocks whose waves gave up summing, of the last sweep
+        st["pending"], st["calls_since"] = None, 0
+    st["calls_since"] += 1
+    if not st["fused"] and st["calls_since"] > 64:
+        st["fused"] = True   # the data may have changed: look again
+    return st["fused"]
+
+
+def _watch_fused(key, dev):
+    """A pinned buffer for the call's counters and the event that says they have arrived (``auto`` mode only)."""
+    if fused_block_mean_mode() != "auto":
+        return None
+    import torch
+
+    st = _FUSED_ROUTE.get(key)
+    if st is None or st["pending"] is not None:
+        return None
+    st["pending"] = (torch.zeros(4, dtype=torch.int32).pin_memory(), torch.cuda.Event())
+    return st["pending"]
 
 
 def area_weighted_pressure_means(ds, delp, area, toa_pressure: float, coarsening_factor: int, x_dim: str = FV_CORE_X_CENTER,
@@ -191,7 +231,7 @@ def area_weighted_pressure_means(ds, delp, area, toa_pressure: float, coarsening
     two-stream pipeline over groups of four fields: the remap sweep of group g + 1 (latency-bound, it fills the chip's
     wave slots but not its memory system) runs on the calling stream while the masked block mean of group g (HBM-bound) and,
     first of all, the masked area run on a stream beside it.  Same kernels, same values and labels as the two calls.
-    With ``FV3NET_AMD_FUSED_BLOCK_MEAN=1`` (and factor 8, a float32 area) one fused kernel per group instead.
+    With factor 8 and a float32 area one fused kernel per group instead where that pays (``fused_block_mean_mode``).
     Arrays must come in [.., z, y, x] order (the restart files'); anything else takes the two calls.
     ``side_stream``: the stream to use beside the caller's (the HIP runtime multiplexes streams onto four hardware queues:
     a pipeline that spreads over more than two or three streams serialises on queue sharing); ``side_work``: a callable that
@@ -223,8 +263,18 @@ def area_weighted_pressure_means(ds, delp, area, toa_pressure: float, coarsening
     phalf_coarse = ops.pressure_at_interface(delp_coarse, toa_pressure, -3)
     level = ops.pressure_at_midpoint_log(delp_coarse, toa_pressure, -3) if extrapolate else None
     means = None
-    if fused_block_mean_enabled() and f == 8 and area_t.dtype == torch.float32:
-        means = ops.mappm_block_mean(phalf_fine, fields, phalf_coarse, area_t, level_coarse=level, iv=1, kord=1)
+    if f == 8 and area_t.dtype == torch.float32:
+        key = (delp_t.device.index, tuple(delp_t.shape), str(delp_t.dtype), len(fields), bool(extrapolate), ops.MAPPM_ARITHMETIC)
+        n_blocks = min(delp_t.numel() // int(delp_t.shape[-3]) // 64, (1 << 20) // 64)   # (the counters are those of the last launch: <= 2^20 columns)
+        if _use_fused(key, n_blocks):
+            watch = _watch_fused(key, delp_t.device)
+            means = ops.mappm_block_mean(phalf_fine, fields, phalf_coarse, area_t, level_coarse=level, iv=1, kord=1,
+                                         counters=None if watch is None else watch[0])
+            if watch is not None:
+                if means is None:
+                    _FUSED_ROUTE[key]["pending"] = None
+                else:
+                    watch[1].record(torch.cuda.current_stream(delp_t.device))
     if means is None:
         dev = delp_t.device
         main = torch.cuda.current_stream(dev)

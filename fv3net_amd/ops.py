@@ -901,7 +901,7 @@ def mappm_multi_coarse_target(pe1: torch.Tensor, fields: Sequence[torch.Tensor],
 
 def mappm_block_mean(pe1: torch.Tensor, fields: Sequence[torch.Tensor], pe2_coarse: torch.Tensor, area: torch.Tensor,
                      level_coarse: Optional[torch.Tensor] = None, factor: int = 8, iv: int = 1, kord: int = 1,
-                     arith: Optional[str] = None) -> Optional[list]:
+                     arith: Optional[str] = None, counters: Optional[torch.Tensor] = None) -> Optional[list]:
     """``weighted_block_average(mappm_multi_coarse_target(pe1, fields, pe2_coarse, factor), mask_weights(area, level, pe1, ...,
     coarse_factor=factor), factor)`` in one kernel (regridz.py:149-220 followed by coarsen.py:183-218, as the pressure-level
     restart pipelines call them): a wavefront owns one 8 x 8 block, sums its remapped, masked values in LDS and writes the
@@ -909,7 +909,10 @@ def mappm_block_mean(pe1: torch.Tensor, fields: Sequence[torch.Tensor], pe2_coar
     pressures [.., kn, ny/8, nx/8] (``extrapolate=True``); None compares each layer's bottom interface (``pe2_coarse``).
     ``area`` [.., ny, nx] float32 with leading dims that lead the fields' (shared by the rest).  Arrays in [.., z, y, x] order.
     Bit-identical to the three calls above in the same ``arith``.  Returns None where the kernel does not apply (factor != 8,
-    extents not multiples of 8, a non-float32 area, kord > 3, ...): the caller takes the three calls."""
+    extents not multiples of 8, a non-float32 area, kord > 3, ...): the caller takes the three calls.
+    ``counters``: a pinned int32 host tensor of 4 elements that receives, asynchronously on the current stream, the call's
+    last [columns listed for the sequential routine, blocks redone, blocks whose waves gave up summing, 0] -- what an adaptive
+    caller looks at before it chooses the route of its next call (``regridz.area_weighted_pressure_means``)."""
     fields = list(fields)
     if not fields:
         return []
@@ -960,6 +963,8 @@ def mappm_block_mean(pe1: torch.Tensor, fields: Sequence[torch.Tensor], pe2_coar
         if err.code != _lib.EUNSUPPORTED:
             raise
         return None
+    if counters is not None:
+        counters.copy_(ws[:16].view(torch.int32), non_blocking=True)
     return outs
 
 

@@ -218,3 +218,35 @@ def test_side_streams_and_the_one_stream_switch(monkeypatch):
     for category in two:
         for var in two[category]:
             assert np.array_equal(np.asarray(two[category][var].values), np.asarray(one[category][var].values), equal_nan=True), (category, var)
+
+
+def test_the_adaptive_route_follows_the_data(monkeypatch):
+    """FV3NET_AMD_FUSED_BLOCK_MEAN=auto (the default): the first call of a shape is fused; the kernel's count of blocks whose
+    waves gave up summing decides the next ones -- the three launches on BASELINE configs[2]'s iid thicknesses, the fused
+    kernel on smooth ones -- and the values never depend on the route."""
+    from fv3net_amd.cubedsphere import regridz
+    from fv3net_amd.xr_compat import DataArray, Dataset
+
+    rng = np.random.default_rng(8)
+    dims = ["tile", "zaxis_1", "yaxis_2", "xaxis_1"]
+    calls = []
+    real = ops.mappm_block_mean
+    monkeypatch.setattr(ops, "mappm_block_mean", lambda *a, **k: calls.append(1) or real(*a, **k))
+    for spread, expect_fused_later in ((1.0, False), (0.05, True)):
+        nt, nz, n = 2, 79, 32
+        delp = np.maximum(900.0 + spread * (rng.uniform(300, 1500, (nt, nz, n, n)) - 900.0), 20.0)
+        ds = Dataset({k: DataArray(rng.uniform(-5, 5, (nt, nz, n, n)), dims=dims) for k in ("a", "b", "c")})
+        delp_da, area = DataArray(delp, dims=dims), DataArray(rng.uniform(0.5, 1, (nt, n, n)).astype(np.float32), dims=["tile", "yaxis_2", "xaxis_1"])
+        monkeypatch.setenv("FV3NET_AMD_FUSED_BLOCK_MEAN", "0")
+        want = regridz.area_weighted_pressure_means(ds, delp_da, area, 300.0, 8)
+        monkeypatch.setenv("FV3NET_AMD_FUSED_BLOCK_MEAN", "auto")
+        regridz._FUSED_ROUTE.clear()
+        seen = []
+        for _ in range(4):
+            del calls[:]
+            got = regridz.area_weighted_pressure_means(ds, delp_da, area, 300.0, 8)
+            torch.cuda.synchronize()
+            seen.append(bool(calls))
+            for v in want:
+                assert np.array_equal(np.asarray(got[v].values), np.asarray(want[v].values), equal_nan=True), (spread, v)
+        assert seen[0] is True and seen[-1] is expect_fused_later, (spread, seen)
