@@ -1,5 +1,6 @@
 #!/bin/bash
-# An experiment build of the library with other -D knobs for csrc/remap.hip (the float64 four-field instantiations only):
+# An experiment build of the library with other -D knobs for the fused-mean part of csrc/remap.hip (float64, four fields only;
+# the sweep part is the tree's remap.o):
 #   benchmarks/build_remap_variant.sh NAME [-DMEAN_KOUT=8 ...]   ->  gpurun_variants/libfv3hip_NAME.so
 # Select it at run time with FV3HIP_LIBRARY=... (benchmarks/block_mean_timing.py, remap_sweep_timing.py).
 set -e
@@ -8,8 +9,8 @@ name=$1; shift
 mkdir -p $R/gpurun_variants
 cd $R/fv3net_amd/csrc
 /opt/rocm/bin/hipcc -O3 -std=c++17 -fPIC --offload-arch=gfx950 -ffp-contract=off -Wno-unused-value -Wno-inline-asm -Wno-unused-function \
-    -mllvm -pragma-unroll-threshold=262144 -DFV3HIP_REMAP_SUBSET "$@" -Rpass-analysis=kernel-resource-usage -c remap.hip -o /tmp/remap_$name.o 2> /tmp/remap_$name.log
-/opt/rocm/bin/hipcc --offload-arch=gfx950 -shared -fPIC -o $R/gpurun_variants/libfv3hip_$name.so capi.o coarsen.o vertical.o /tmp/remap_$name.o mlp.o mlp_bf16x3.o emulation.o local.o fit.o
+    -mllvm -pragma-unroll-threshold=262144 -DFV3HIP_REMAP_SUBSET -DFV3HIP_REMAP_PART_MEAN "$@" -Rpass-analysis=kernel-resource-usage -c remap.hip -o /tmp/remap_$name.o 2> /tmp/remap_$name.log
+/opt/rocm/bin/hipcc --offload-arch=gfx950 -shared -fPIC -o $R/gpurun_variants/libfv3hip_$name.so capi.o coarsen.o vertical.o remap.o /tmp/remap_$name.o mlp.o mlp_bf16x3.o emulation.o local.o fit.o
 python3 - $name <<'PY'
 import re,subprocess,sys
 t=open(f'/tmp/remap_{sys.argv[1]}.log').read()

@@ -1,5 +1,5 @@
 cd $GRAFT_REPO_ROOT
-for v in k8 k12; do
+for v in base w4; do
   for noise in 1.0 0.1; do
     FV3HIP_LIBRARY=$GRAFT_REPO_ROOT/gpurun_variants/libfv3hip_$v.so timeout -k 10 120 python benchmarks/block_mean_timing.py --fields 4 --dtype f64 --noise $noise --label $v 2>/dev/null | python -c "
 import json,sys

@@ -212,14 +212,17 @@ __device__ __forceinline__ void mean_reduce(const float *ring, int slot0, int ro
     const bool act = ri < nrows;   // (ri < kMeanGroup follows: nrows <= kMeanGroup)
     const float *src = ring + ((slot0 + (act ? ri : 0)) * NF + f) * kMeanStride + half * 32;
     typedef float f32x4 __attribute__((ext_vector_type(4)));
+#ifndef MEAN_RBATCH
+#define MEAN_RBATCH 4
+#endif
     float s = 0.f;
 #pragma unroll
-    for (int h = 0; h < 2; ++h) {  // (two batches of four reads: 16 registers in flight, not 32 -- the call sits inside the sweep's loop)
-        f32x4 v[4];
+    for (int h = 0; h < 8 / MEAN_RBATCH; ++h) {  // (batches of reads: 16 registers in flight, not 32 -- the call sits inside the sweep's loop)
+        f32x4 v[MEAN_RBATCH];
 #pragma unroll
-        for (int t = 0; t < 4; ++t) v[t] = *reinterpret_cast<const f32x4 *>(src + 16 * h + 4 * t);
+        for (int t = 0; t < MEAN_RBATCH; ++t) v[t] = *reinterpret_cast<const f32x4 *>(src + 4 * MEAN_RBATCH * h + 4 * t);
 #pragma unroll
-        for (int t = 0; t < 4; ++t) {
+        for (int t = 0; t < MEAN_RBATCH; ++t) {
             s += v[t][0];
             s += v[t][1];
             s += v[t][2];
@@ -234,8 +237,11 @@ __device__ __forceinline__ void mean_reduce(const float *ring, int slot0, int ro
     }
 }
 
+#ifndef SWEEP_KERNEL_ATTR
+#define SWEEP_KERNEL_ATTR
+#endif
 template <typename Tin, int NV, int W, bool FAST, bool TGT, bool MEAN = false>
-__global__ __launch_bounds__(64) void mappm_sweep_kernel(const SweepArgs a)
+__global__ __launch_bounds__(64) SWEEP_KERNEL_ATTR void mappm_sweep_kernel(const SweepArgs a)
 {
     static_assert(!MEAN || TGT, "the fused block mean keeps its (single) target column in LDS");
     using V = typename FieldVec<W>::type;
@@ -563,19 +569,20 @@ __global__ __launch_bounds__(64) void mappm_sweep_kernel(const SweepArgs a)
     int spill_row = 0;    // uniform: first row that was not summed here
     // (spilled rows lie BLOCK-major in the scratch -- [block][row][lane], a row of the wave = 256 contiguous bytes -- so they
     // leave and come back as whole rows; the fine layout would cut them into the block's eight 32-byte pieces)
-    char *s_b[NF];
+    char *s_b[NF];   // (uniform: the lane's 4 bytes are added at the store)
 #pragma unroll
     for (int f = 0; f < NF; ++f) s_b[f] = nullptr;
     if constexpr (MEAN) {
 #pragma unroll
-        for (int f = 0; f < NF; ++f) s_b[f] = reinterpret_cast<char *>(a.q2[f] + (a.col0 / 64 + wid) * (int64_t)kn * 64) + lane * 4;
+        for (int f = 0; f < NF; ++f) s_b[f] = reinterpret_cast<char *>(a.q2[f] + (a.col0 / 64 + wid) * (int64_t)kn * 64);
     }
+    const unsigned int lane4 = (unsigned int)lane * 4u;
     auto out_end_mean = [&]() {
         const int r = k - 1, slot = oslot;
         if (r - kOut >= (rl > rf ? rl : rf)) {  // the slot still holds this lane's row r - kOut: that one goes to the scratch now
 #pragma unroll
             for (int f = 0; f < NF; ++f)
-                *reinterpret_cast<float *>(s_b[f] + (r - kOut) * 256) = m_ring[(slot * NF + f) * kMeanStride + mpos];
+                *reinterpret_cast<float *>(s_b[f] + ((unsigned int)(r - kOut) * 256u + lane4)) = m_ring[(slot * NF + f) * kMeanStride + mpos];
             rl = r - kOut + 1;
             *m_flag = 1.f;
         }
@@ -607,7 +614,7 @@ __global__ __launch_bounds__(64) void mappm_sweep_kernel(const SweepArgs a)
             if (rl <= rf) {
 #pragma unroll
                 for (int f = 0; f < NF; ++f)
-                    *reinterpret_cast<float *>(s_b[f] + rf * 256) = m_ring[(fslot * NF + f) * kMeanStride + mpos];
+                    *reinterpret_cast<float *>(s_b[f] + ((unsigned int)rf * 256u + lane4)) = m_ring[(fslot * NF + f) * kMeanStride + mpos];
             }
             ++rf;
             fslot = (fslot + 1 == kOut) ? 0 : fslot + 1;
