@@ -19,6 +19,7 @@ ap = argparse.ArgumentParser()
 ap.add_argument("--reps", type=int, default=20)
 ap.add_argument("--n", type=int, default=384)
 ap.add_argument("--noise", type=float, default=1.0)
+ap.add_argument("--terrain", action="store_true", help="hybrid sigma-pressure thicknesses over a surface pressure with mountains instead of --noise")
 ap.add_argument("--fields", default="1,4")
 ap.add_argument("--dtype", default="f64,f32")
 ap.add_argument("--label", default=os.environ.get("FV3HIP_LIBRARY", "in-tree"))
@@ -28,6 +29,27 @@ dev = torch.device("cuda:0")
 g = torch.Generator(device=dev).manual_seed(0)
 n, NZ, F = args.n, 79, 8
 delp = 900 + (torch.rand((6, NZ, n, n), device=dev, generator=g, dtype=torch.float64) - 0.5) * 1200 * args.noise
+if args.terrain:
+    # A hybrid sigma-pressure column as the model has it -- delp(k) = dak(k) + dbk(k) ps -- over a surface pressure with terrain:
+    # 40 Gaussian mountains per tile, 2 to 6 cells wide, up to 400 hPa deep (the Andes / Tibet at C384's 25 km), on 1000 hPa
+    # with +-10 hPa of smooth weather.  Layers: pure pressure above 250 hPa, terrain-following below, thinnest at the surface.
+    import math
+    s01 = torch.linspace(0, 1, NZ + 1, device=dev, dtype=torch.float64)
+    p_ref = 300.0 + (1.0e5 - 300.0) * torch.sin(0.5 * math.pi * s01) ** 1.5            # interfaces at ps = 1000 hPa: thin layers at both ends
+    sig = torch.clamp((p_ref - 2.5e4) / 7.5e4, min=0) ** 1.3                           # bk: 0 above 250 hPa, 1 at the surface
+    ak = p_ref - sig * 1.0e5                                                           # pe(ps) = ak + bk ps = p_ref + bk (ps - 1000 hPa)
+    yy, xx = torch.meshgrid(torch.arange(n, device=dev, dtype=torch.float64), torch.arange(n, device=dev, dtype=torch.float64), indexing="ij")
+    ps = torch.full((6, n, n), 1.0e5, device=dev, dtype=torch.float64)
+    cpu = torch.Generator().manual_seed(1)
+    for t in range(6):
+        for _ in range(40):
+            cy, cx, w, depth = (torch.rand(4, generator=cpu).tolist())
+            ps[t] -= (depth * 4.0e4) * torch.exp(-(((yy - cy * n) ** 2 + (xx - cx * n) ** 2) / (2 * (2 + 4 * w) ** 2)))
+        ps[t] += 1.0e3 * torch.sin(2 * math.pi * (yy / n * 1.5 + t / 6)) * torch.cos(2 * math.pi * xx / n * 2.5)
+    ps.clamp_(min=5.0e4)
+    pe = ak.view(1, NZ + 1, 1, 1) + sig.view(1, NZ + 1, 1, 1) * ps.view(6, 1, n, n)
+    delp = (pe[:, 1:] - pe[:, :-1]).contiguous()
+    assert float(delp.min()) > 0
 area = (torch.rand((6, n, n), device=dev, generator=g, dtype=torch.float64) * 0.5 + 0.5).float()
 pe1 = ops.pressure_at_interface(delp, 300.0, 1)
 pe2c = ops.pressure_at_interface(ops.weighted_block_average(delp, area, F), 300.0, 1)
@@ -54,7 +76,12 @@ def unfused(p1, fs, p2, arith):
     return ops.weighted_block_average_multi(q2, mw, F) if len(q2) > 1 else [ops.weighted_block_average(q2[0], mw, F)]
 
 
-out = {"label": args.label, "noise": args.noise, "columns": ncol, "cases": {}}
+out = {"label": args.label, "noise": "terrain" if args.terrain else args.noise, "columns": ncol, "cases": {}}
+if True:   # how many of the blocks run out of ring (the count the adaptive route looks at)
+    counters = torch.zeros(4, dtype=torch.int32).pin_memory()
+    ops.mappm_block_mean(pe1, qs, pe2c, area, arith="exact", counters=counters)
+    torch.cuda.synchronize()
+    out["blocks_that_gave_up_summing"] = [int(counters[2]), ncol // 64]
 for dname in args.dtype.split(","):
     dt = torch.float32 if dname == "f32" else torch.float64
     p1, p2, fs = pe1.to(dt), pe2c.to(dt), [q.to(dt) for q in qs]
