@@ -17,6 +17,13 @@ rocprofv3 --kernel-trace --stats --output-format csv -d $O/stats_all -- python3 
 # 4. HBM traffic of the headline and the coarsening kernels (FETCH_SIZE / WRITE_SIZE, separate passes)
 rocprofv3 --pmc FETCH_SIZE --kernel-trace --output-format csv -d $O/pmc_fetch -- python3 $R/bench.py --steps 3 --warmup 1 --no-cpu --no-parity > $O/pmc_fetch.log 2>&1 || exit 1
 rocprofv3 --pmc WRITE_SIZE --kernel-trace --output-format csv -d $O/pmc_write -- python3 $R/bench.py --steps 3 --warmup 1 --no-cpu --no-parity > $O/pmc_write.log 2>&1 || exit 1
+# (gpurun merges at most 64 MiB back: of the two traffic passes keep the rows of the kernels that profiles/r03_pmc_traffic.json quotes)
+for d in pmc_fetch pmc_write; do
+  for f in $O/$d/*/*_counter_collection.csv; do
+    (head -1 $f; grep -E 'mlp_fused_kernel<8, false, true, false, false, false>|wavg_block_kernel<float, float, 8>|mass_wavg_block_kernel<double, float, 8, 4>|mappm_sweep_kernel<double, 2, 2, true, true, false>' $f) > $f.kept && mv $f.kept $f
+  done
+  rm -f $O/$d/*/*_kernel_trace.csv
+done
 # 5. the remap sweep: occupancy / stall / instruction counters, three passes
 rocprofv3 --pmc SQ_WAVES SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_ACTIVE_INST_VALU SQ_INSTS_VALU --kernel-trace --output-format csv -d $O/pmc_mappm1 -- python3 $R/benchmarks/remap_sweep_timing.py --reps 3 > $O/pmc_mappm1.log 2>&1 || exit 1
 rocprofv3 --pmc SQ_INSTS_SALU SQ_INSTS_LDS SQ_INSTS_VMEM_RD SQ_INSTS_VMEM_WR SQ_ACTIVE_INST_SCA SQ_ACTIVE_INST_LDS SQ_INSTS_VALU_TRANS_F32 GRBM_GUI_ACTIVE --kernel-trace --output-format csv -d $O/pmc_mappm2 -- python3 $R/benchmarks/remap_sweep_timing.py --reps 3 > $O/pmc_mappm2.log 2>&1 || exit 1

@@ -70,8 +70,9 @@ struct fv3hip_timer {
 // one (the runtime multiplexes streams onto four hardware queues) -- see fv3net_amd/cubedsphere/_device.py.
 __global__ void spin_kernel(long long ticks)
 {
-    const long long t0 = wall_clock64();
-    while (wall_clock64() - t0 < ticks) {
+    // (two clocks: the constant 100 MHz one decides; the shader clock -- at most 2.5 GHz -- bounds the loop should the first not run)
+    const long long t0 = wall_clock64(), c0 = clock64();
+    while (wall_clock64() - t0 < ticks && clock64() - c0 < ticks * 40) {
     }
 }
 
