@@ -417,7 +417,7 @@ def remap_benchmark(dev, steps):
 
 
 def block_mean_benchmark(dev, steps):
-    """The opt-in fused remap + masked block mean (fv3hip_mappm_block_mean; FV3NET_AMD_FUSED_BLOCK_MEAN=1 in the pipelines)
+    """The fused remap + masked block mean (fv3hip_mappm_block_mean; the pipelines take it where it pays: FV3NET_AMD_FUSED_BLOCK_MEAN)
     beside the three launches it replaces, 4 float64 fields, on both data sets: one entry, times in ms."""
     from fv3net_amd import ops
 
@@ -446,7 +446,7 @@ def block_mean_benchmark(dev, steps):
         torch.cuda.empty_cache()
     alg = ncol * ((NZ + 1) * 8 + 4 * NZ * 8 + 4)
     best = min(v["fused_ms"] for v in table.values())
-    return [{"kernel": "mappm_sweep_kernel<double, 2, 2, *, true, MEAN> + mean_rest_kernel (opt-in fused remap + masked 8x8 block mean)",
+    return [{"kernel": "mappm_sweep_kernel<double, 2, 2, *, true, MEAN> + mean_rest_kernel (fused remap + masked 8x8 block mean; the pipelines' route where the data allow)",
              "workload": "C384 -> C48: 884736 columns x 4 float64 fields, km=kn=79, against mappm_multi_coarse_target + mask_weights + weighted_block_average",
              "ms": best, "calls": table,
              "roofline": {"bound": "hbm", "achieved": alg / best / 1e6, "peak": PEAK_HBM_GBPS, "unit": "GB/s", "frac": alg / best / 1e6 / PEAK_HBM_GBPS,
@@ -486,7 +486,7 @@ def secondary_benchmarks(dev, steps):
     _guarded(out, streaming_benchmark, dev)                        # PCIe-inclusive
     _guarded(out, io_pipeline_benchmark, dev)                      # file I/O inclusive
     _guarded(out, rank_latency_benchmark, dev)                     # one model rank's columns per call
-    _guarded(out, block_mean_benchmark, dev, steps)                # opt-in fused remap + block mean
+    _guarded(out, block_mean_benchmark, dev, steps)                # fused remap + block mean
     _guarded(out, plain_network_benchmark, dev, steps)
     _guarded(out, wavg_benchmark, dev, steps, "C384->C48", 384)
     _guarded(out, remap_benchmark, dev, steps)

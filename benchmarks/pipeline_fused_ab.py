@@ -1,4 +1,4 @@
-"""The pressure-level pipeline with and without the opt-in fused remap + block mean (FV3NET_AMD_FUSED_BLOCK_MEAN), on configs[2]'s
+"""The pressure-level pipeline with the fused remap + block mean pinned off and on (FV3NET_AMD_FUSED_BLOCK_MEAN = 0 | 1; the default follows the data), on configs[2]'s
 iid thicknesses and on smooth ones (a tenth of the spread), both remap arithmetics: `python benchmarks/pipeline_fused_ab.py`."""
 import json, os, sys
 import torch
