@@ -43,7 +43,8 @@ def _copy_pool():
     if _POOL is None:
         from concurrent.futures import ThreadPoolExecutor
 
-        _POOL = ThreadPoolExecutor(max_workers=max(1, min(8, os.cpu_count() or 1)), thread_name_prefix="fv3net-amd-nc")
+        workers = int(os.environ.get("FV3NET_AMD_IO_THREADS", "0")) or min(4, os.cpu_count() or 1)
+        _POOL = ThreadPoolExecutor(max_workers=max(1, workers), thread_name_prefix="fv3net-amd-nc")
     return _POOL
 
 
