@@ -36,8 +36,9 @@ struct SweepArgs {
     unsigned int *rest_blocks; // (block, first row not summed) of the waves that went into spill mode (counter: n_bad[2])
 };
 
-// LEVEL_COL layout, kord <= 3, km >= 8, n_inner % 64 == 0, every row offset of a batch below 4 GiB
-bool mappm_sweep_eligible(int64_t n_inner, int km, int kn, int kord, int layout, int in_dtype);
+// LEVEL_COL layout, kord <= 3, km >= 8, n_inner % 64 == 0, and the three offsets the kernel keeps in 32 bits below 4 GiB (a level
+// of the inputs, a result column, the target array of a batch: `pe2_plane` = the target's plane where it lives on a coarser grid)
+bool mappm_sweep_eligible(int64_t n_inner, int km, int kn, int kord, int layout, int in_dtype, int64_t pe2_plane = 0);
 // columns [a.col0, col_end) -- whole waves -- of up to 4 fields; fast = reciprocal arithmetic (remap.hip)
 void mappm_sweep_launch(const SweepArgs &a, int nf, int in_dtype, int64_t col_end, bool fast, hipStream_t st);
 // the fused remap + masked 8 x 8 block mean: shapes it takes, the launch of blocks [a.col0 / 64, col_end / 64), and the pass that

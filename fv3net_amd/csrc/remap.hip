@@ -1072,10 +1072,11 @@ void launch_mean1(const SweepArgs &a, int nf, int64_t n_waves, bool fast, hipStr
 #ifndef FV3HIP_REMAP_PART_SWEEP
 bool mappm_mean_eligible(int ny, int nx, int factor, int km, int kn, int kord, int in_dtype)
 {
+    // (32-bit in the kernel: the byte distance between two levels of an input; everything else it addresses -- the coarse
+    // tables, the block-major scratch rows, the means -- goes through 64-bit pointers per wave)
     const int64_t esz = (in_dtype == FV3HIP_F64) ? 8 : 4;
-    const int64_t levels = (km + 1 > kn + 1 ? km + 1 : kn + 1) + 5;
     return factor == 8 && ny > 0 && nx > 0 && ny % 8 == 0 && nx % 8 == 0 && kord <= 3 && km >= 8 && kn >= 1 && kn + 1 <= 128 &&
-           (int64_t)ny * nx * esz * levels < ((int64_t)1 << 32);
+           (int64_t)ny * nx * esz < ((int64_t)1 << 32);
 }
 
 void mappm_mean_launch(const SweepArgs &a, int nf, int in_dtype, int64_t col_end, bool fast, hipStream_t st)
@@ -1117,12 +1118,18 @@ void mappm_mean_redo_launch(const SweepArgs &a, int nf, int in_dtype, hipStream_
 
 #endif  // mean part
 #ifndef FV3HIP_REMAP_PART_MEAN
-bool mappm_sweep_eligible(int64_t n_inner, int km, int kn, int kord, int layout, int in_dtype)
+bool mappm_sweep_eligible(int64_t n_inner, int km, int kn, int kord, int layout, int in_dtype, int64_t pe2_plane)
 {
-    const int64_t esz = (in_dtype == FV3HIP_F64) ? 8 : 4;
-    const int64_t levels = (km + 1 > kn + 1 ? km + 1 : kn + 1) + 5;
+    // What the kernel holds in 32 bits: the byte distance between two levels of an input (row_in), a lane's offset into its
+    // result column (offq <= kn result rows of 4-byte values), and -- on the paths that read target interfaces from memory
+    // per lane -- the offset of an interface inside the target array of the batch ((kn + 1) rows of pe2_plane values; the
+    // target's own plane when it lives on a coarser grid).  Row and batch bases are 64-bit pointers per wave.  A C3072 tile
+    // of float64 restarts (9.4 M columns: 75 MB per level) remapped to its coarse grid's levels fits; the same tile remapped
+    // to a target on its own grid does not ((kn + 1) x 75 MB) and takes the merge kernels.
+    const int64_t esz = (in_dtype == FV3HIP_F64) ? 8 : 4, lim = (int64_t)1 << 32;
+    if (pe2_plane <= 0) pe2_plane = n_inner;
     return layout == FV3HIP_LAYOUT_LEVEL_COL && kord <= 3 && km >= 8 && kn >= 1 && n_inner > 0 && n_inner % 64 == 0 &&
-           n_inner * esz * levels < ((int64_t)1 << 32);
+           n_inner * esz < lim && (int64_t)(kn + 1) * n_inner * 4 < lim && (int64_t)(kn + 2) * pe2_plane * esz < lim;
 }
 
 void mappm_sweep_launch(const SweepArgs &a, int nf, int in_dtype, int64_t col_end, bool fast, hipStream_t st)

@@ -1742,10 +1742,10 @@ extern "C" int fv3hip_mappm_multi_coarse_target(const void *pe1, const void *con
     FV3HIP_REQUIRE(km >= 4, "km must be >= 4 (ppm_profile reads a4(2,i,3)), got %d", km);
     const int64_t n_inner = (int64_t)ny * nx, ncol = n_batch * n_inner;
     if (ncol == 0 || kn == 0) return FV3HIP_OK;
-    if (factor < 2 || !mappm_sweep_eligible(n_inner, km, kn, kord, FV3HIP_LAYOUT_LEVEL_COL, in_dtype))
-        return fail(FV3HIP_EUNSUPPORTED, "coarse-target remap needs factor >= 2 and a shape the sweep kernel takes");
     const int nyc = coarse_extent(ny, factor), nxc = coarse_extent(nx, factor);
     const int64_t plane2 = (int64_t)nyc * nxc;
+    if (factor < 2 || !mappm_sweep_eligible(n_inner, km, kn, kord, FV3HIP_LAYOUT_LEVEL_COL, in_dtype, plane2))
+        return fail(FV3HIP_EUNSUPPORTED, "coarse-target remap needs factor >= 2 and a shape the sweep kernel takes");
     FV3HIP_REQUIRE(pe1 && pe2_coarse, "null pointer");
     for (int f = 0; f < n_fields; ++f) FV3HIP_REQUIRE(q1[f] && q2[f], "null field pointer");
     FV3HIP_REQUIRE(workspace && workspace_bytes >= fv3hip_mappm_workspace_bytes(ncol, km),

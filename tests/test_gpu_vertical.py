@@ -719,3 +719,32 @@ def test_coarse_target_remap_equals_the_upsampled_one(device, dtype, ny, nx, nfi
         want = ops.mask_weights(w, ops.block_upsample(pc, f), pe1, 1, extrapolate=extrapolate)
         got = ops.mask_weights(w, pc, pe1, 1, extrapolate=extrapolate, coarse_factor=f)
         assert torch.equal(got, want) and 0 < float((got == 0).float().mean()) < 1
+
+
+def test_coarse_target_sweep_on_a_plane_of_more_than_4_gib_of_levels(device):
+    """A C3072 tile of float64 restarts is 75 MB per level and 6 GB per field: the byte offsets of its levels exceed 32 bits
+    although nothing the sweep kernel keeps in 32 bits does (a level's stride, a result column, the coarse target array).
+    2688 x 2688 float64 columns x 79 levels (4.6 GB of interfaces) in the FAST arithmetic -- which only the sweep kernel has -- must
+    equal the same columns remapped in two halves, each below the old all-in-32-bits rule."""
+    from fv3net_amd import ops
+
+    n, km, f = 2688, 79, 8
+    g = torch.Generator(device=device).manual_seed(5)
+    delp = torch.rand((1, km, n, n), device=device, generator=g, dtype=torch.float64) * 1200 + 300
+    delp_c = ops.weighted_block_average(delp, torch.ones((1, n, n), device=device, dtype=torch.float32), f)
+    pe1 = ops.pressure_at_interface(delp, 300.0, 1)
+    pe2c = ops.pressure_at_interface(delp_c, 300.0, 1)
+    del delp
+    qs = [torch.rand((1, km, n, n), device=device, generator=g, dtype=torch.float64) * 200 - 100 for _ in range(2)]
+    assert pe1.numel() * 8 > 2 ** 32
+    whole = ops.mappm_multi_coarse_target(pe1, qs, pe2c, f, z_axis=1, arith="fast")
+    h = n // 2
+    for rows, crow in ((slice(0, h), slice(0, h // f)), (slice(h, n), slice(h // f, n // f))):
+        part = ops.mappm_multi_coarse_target(pe1[:, :, rows].contiguous(), [q[:, :, rows].contiguous() for q in qs],
+                                             pe2c[:, :, crow].contiguous(), f, z_axis=1, arith="fast")
+        for a, b in zip(whole, part):
+            assert torch.equal(a[:, :, rows], b)
+    exact = ops.mappm_multi_coarse_target(pe1, qs[:1], pe2c, f, z_axis=1, arith="exact")[0]
+    assert not torch.equal(exact, whole[0])   # (the fast arithmetic really ran: the merge kernels the old rule fell back to have none)
+    del whole, exact
+    torch.cuda.empty_cache()
