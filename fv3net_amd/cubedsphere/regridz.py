@@ -325,12 +325,6 @@ def area_weighted_pressure_means(ds, delp, area, toa_pressure: float, coarsening
     return from_compat(out, ds)
 
 
-def torch_float32():
-    import torch
-
-    return torch.float32
-
-
 def compute_edge_delp(delp, edge: str, x_dim: str = FV_CORE_X_CENTER, y_dim: str = FV_CORE_Y_CENTER, step: int = 1):
     """Pressure thickness on grid cell edges (coarsen_restarts.py:825-853): ``delp`` interpolated
     across the cube's faces to the edges the ``edge``-directed wind component lives on; the new
