@@ -39,6 +39,6 @@ python3 $R/benchmarks/block_mean_timing.py > $O/block_mean_iid.json 2>/dev/null
 python3 $R/benchmarks/block_mean_timing.py --noise 0.1 > $O/block_mean_smooth.json 2>/dev/null
 python3 $R/benchmarks/pipelines_quick.py > $O/pipelines_quick.jsonl 2>/dev/null
 # 8. vector-instruction issue rates
-$R/benchmarks/valu_ubench/valu_rate > $O/r03_valu_issue_rates.txt 2>&1
+make -s -C $R/benchmarks/valu_ubench && $R/benchmarks/valu_ubench/valu_rate > $O/r03_valu_issue_rates.txt 2>&1
 find $O -name "*.csv" | wc -l
 du -sh $O
